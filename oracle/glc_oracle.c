@@ -1,0 +1,563 @@
+/*
+ * glc_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE)
+ *
+ * A plain-C restatement of the reference algorithms on the hot path named by
+ * BASELINE.json (CUDPP cudppCompress = BWT -> MTF -> Huffman, and the CULZSS
+ * match/pack/decode path).  It exists so that tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg can check / time the HIP implementation
+ * against an independent statement of the reference semantics.  Nothing in the
+ * product library (gpu-lossless-compression_amd/csrc) includes, links or calls
+ * this file.
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose behaviour it restates.  No reference source text is copied; the
+ * algorithms are re-expressed from the behaviour documented in SURVEY.md
+ * App. A and read from the cited lines.
+ *
+ * PINNING STATUS
+ *   - suffix array / BWT / MTF: pinned against the reference's own CPU gold
+ *     (cudpp-inpar/apps/cudpp_testrig/sa_gold.cpp compiled unmodified into
+ *     oracle/_ref/libsagold.so, plus the computeBwtGold/computeMtfGold
+ *     semantics of test_compress.cpp:79-125) on the reference's own test
+ *     inputs (glibc srand(95835)); see tests/golden/make_golden.py.
+ *   - Huffman tree: the node-merge order restates huffman_build_tree_cpu
+ *     (test_compress.cpp:127-186), which is itself the CPU twin of the device
+ *     kernel (compress_kernel.cuh:2306-2392); the reference test only checks
+ *     decode round trip, so the packed bitstream is pinned by round trip
+ *     through the gold *decoder* semantics (test_compress.cpp:240-311), not
+ *     by a reference-produced byte vector: "bitstream parity unpinned".
+ *   - CULZSS: the reference has no test; restated from gpu_compress.cu /
+ *     gpu_decompress.cu and pinned only by encode->decode round trip:
+ *     "parity unpinned".
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* constants that are part of the cudppCompress bitstream format             */
+/* (cudpp-inpar/src/cudpp/cudpp_globals.h:58-66)                             */
+/* ------------------------------------------------------------------------- */
+#define HUFF_BLOCK_SYMS   4096          /* HUFF_THREADS_PER_BLOCK(128) * HUFF_WORK_PER_THREAD(32) */
+#define HUFF_NUM_SYMS     257           /* 256 byte values + EOF(256) */
+#define HUFF_EOF          256
+#define HUFF_NODES        (2 * HUFF_NUM_SYMS - 1)
+#define HUFF_BLOCK_WORDS  1536          /* HUFF_CODE_BYTES: capacity of encoded::code[] */
+
+/* ========================================================================= */
+/* 1. Suffix array with an implicit unique minimal sentinel                  */
+/*    Restates the RESULT of cudppSuffixArrayDispatch (sa_app.cu:365-391,    */
+/*    strConstruct/resultConstruct sa_kernel.cuh:47-82): SA of (in[i]+1)     */
+/*    followed by sentinel 0, sentinel row dropped, 0-based.  The algorithm  */
+/*    here is prefix doubling with counting sorts (NOT the reference's skew  */
+/*    algorithm): the SA of a string with a unique sentinel is unique, so    */
+/*    any correct sorter gives identical output.                             */
+/* ========================================================================= */
+ORC_API void orc_suffix_array(const uint8_t *s, uint32_t n, uint32_t *sa)
+{
+    if (n == 0) return;
+    uint32_t  nb  = (n > 258 ? n : 258) + 2;
+    uint32_t *rk  = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *sa2 = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint32_t *cnt = (uint32_t *)malloc(sizeof(uint32_t) * nb);
+    uint32_t  i, j, k, r;
+
+    /* order by first symbol (ranks 1..256; 0 is reserved for "past the end") */
+    memset(cnt, 0, sizeof(uint32_t) * nb);
+    for (i = 0; i < n; i++) { rk[i] = (uint32_t)s[i] + 1; cnt[rk[i]]++; }
+    for (i = 1; i < nb; i++) cnt[i] += cnt[i - 1];
+    for (i = n; i-- > 0;) sa[--cnt[rk[i]]] = i;
+    /* compress ranks to 1..r (group number) */
+    r = 1; tmp[sa[0]] = 1;
+    for (j = 1; j < n; j++) { if (rk[sa[j]] != rk[sa[j - 1]]) r++; tmp[sa[j]] = r; }
+    memcpy(rk, tmp, sizeof(uint32_t) * n);
+
+    for (k = 1; r < n; k <<= 1) {
+        /* order by second key rk[i+k] (0 when i+k >= n): suffixes with an
+         * empty second half come first, then the rest in SA order shifted */
+        uint32_t p = 0, start = (n > k) ? n - k : 0;
+        for (i = start; i < n; i++) sa2[p++] = i;
+        for (j = 0; j < n; j++) if (sa[j] >= k) sa2[p++] = sa[j] - k;
+        /* stable counting sort by first key */
+        memset(cnt, 0, sizeof(uint32_t) * (r + 2));
+        for (i = 0; i < n; i++) cnt[rk[i]]++;
+        for (i = 1; i <= r; i++) cnt[i] += cnt[i - 1];
+        for (j = n; j-- > 0;) sa[--cnt[rk[sa2[j]]]] = sa2[j];
+        /* re-rank */
+        uint32_t nr = 1; tmp[sa[0]] = 1;
+        for (j = 1; j < n; j++) {
+            uint32_t a = sa[j - 1], b = sa[j];
+            uint32_t a2 = (a + k < n) ? rk[a + k] : 0, b2 = (b + k < n) ? rk[b + k] : 0;
+            if (rk[a] != rk[b] || a2 != b2) nr++;
+            tmp[b] = nr;
+        }
+        memcpy(rk, tmp, sizeof(uint32_t) * n);
+        r = nr;
+    }
+    free(rk); free(tmp); free(sa2); free(cnt);
+}
+
+/* ========================================================================= */
+/* 2. BWT: bwt_compute_final_kernel (compress_kernel.cuh:55-74) and          */
+/*    computeBwtGold (test_compress.cpp:79-91):                              */
+/*    out[i] = SA[i]==0 ? in[n-1] : in[SA[i]-1]; index = i where SA[i]==0    */
+/* ========================================================================= */
+ORC_API void orc_bwt(const uint8_t *in, uint32_t n, uint8_t *out, int32_t *index)
+{
+    uint32_t *sa = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    orc_suffix_array(in, n, sa);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t v = sa[i];
+        if (v == 0) { *index = (int32_t)i; out[i] = in[n - 1]; }
+        else out[i] = in[v - 1];
+    }
+    free(sa);
+}
+
+/* ========================================================================= */
+/* 3. MTF with identity initial list: computeMtfGold (test_compress.cpp:     */
+/*    93-125); the device path (compress_kernel.cuh:1339-2023) computes the  */
+/*    same function via a list scan.                                         */
+/* ========================================================================= */
+ORC_API void orc_mtf(const uint8_t *in, uint32_t n, uint8_t *out)
+{
+    uint8_t list[256];
+    for (int i = 0; i < 256; i++) list[i] = (uint8_t)i;
+    for (uint32_t i = 0; i < n; i++) {
+        uint8_t c = in[i];
+        int j = 0;
+        while (list[j] != c) j++;
+        out[i] = (uint8_t)j;
+        memmove(list + 1, list, (size_t)j);
+        list[0] = c;
+    }
+}
+
+ORC_API void orc_imtf(const uint8_t *in, uint32_t n, uint8_t *out)
+{   /* inverse, as in computeCompressGold (test_compress.cpp:293-310) */
+    uint8_t list[256];
+    for (int i = 0; i < 256; i++) list[i] = (uint8_t)i;
+    for (uint32_t i = 0; i < n; i++) {
+        int j = in[i];
+        uint8_t c = list[j];
+        out[i] = c;
+        memmove(list + 1, list, (size_t)j);
+        list[0] = c;
+    }
+}
+
+/* ========================================================================= */
+/* 4. Huffman tree + codes                                                   */
+/*    node layout and merge rule: huffman_build_tree_kernel                  */
+/*    (compress_kernel.cuh:2238-2392), FindMinimumCount                      */
+/*    (cta/compress_cta.cuh:550-571), CPU twin huffman_build_tree_cpu        */
+/*    (test_compress.cpp:127-186).                                           */
+/* ========================================================================= */
+typedef struct {
+    int32_t  value;            /* symbol, or -1 for a composite node */
+    uint32_t count;
+    int32_t  ignore;
+    int32_t  level;
+    int32_t  left, right, parent;
+} orc_node;
+
+static int orc_find_min(const orc_node *t, int elements)
+{   /* lowest count, then lowest level, then lowest slot index (strict '<') */
+    int best = -1; uint32_t bc = 0x7fffffffu; int32_t bl = 0x7fffffff;
+    for (int i = 0; i < elements; i++) {
+        if (!t[i].ignore && (t[i].count < bc || (t[i].count == bc && t[i].level < bl))) {
+            best = i; bc = t[i].count; bl = t[i].level;
+        }
+    }
+    return best;
+}
+
+/* hist256: counts of the MTF bytes.  Returns the head slot; fills tree[513]. */
+static int orc_build_tree(const uint32_t *hist256, orc_node *t, int *n_leaves)
+{
+    int n = 0;
+    for (int j = 0; j < HUFF_NODES; j++) {
+        t[j].value = (j < HUFF_NUM_SYMS) ? j : 0;
+        t[j].count = 0; t[j].ignore = 1; t[j].level = 0;
+        t[j].left = t[j].right = t[j].parent = -1;
+    }
+    for (int j = 0; j < HUFF_NUM_SYMS; j++) {
+        uint32_t c = (j == HUFF_EOF) ? 1u : hist256[j];   /* EOF gets count 1 (compress_kernel.cuh:2250) */
+        if (c > 0) { t[n].count = c; t[n].ignore = 0; t[n].value = j; n++; }
+    }
+    *n_leaves = n;
+    int min1 = -1, min2;
+    for (;;) {
+        min1 = orc_find_min(t, n);
+        if (min1 < 0) break;
+        t[min1].ignore = 1;
+        min2 = orc_find_min(t, n);
+        if (min2 < 0) break;
+        /* relocate min1 to the first free slot >= n; it becomes the LEFT child */
+        t[min1].ignore = 0;
+        int moved = 0;
+        for (int i = n; i < HUFF_NODES; i++) {
+            if (t[i].count == 0) {
+                t[i] = t[min1];
+                t[i].ignore = 1;
+                t[i].parent = min1;
+                if (t[i].left  >= 0) t[t[i].left ].parent = i;
+                if (t[i].right >= 0) t[t[i].right].parent = i;
+                t[min1].left = i;
+                moved = 1;
+                break;
+            }
+        }
+        if (!moved) break;
+        t[min2].ignore = 1;
+        t[min1].value  = -1;
+        t[min1].ignore = 0;
+        t[min1].count  = t[min1].count + t[min2].count;
+        t[min1].level  = (t[min1].level > t[min2].level ? t[min1].level : t[min2].level) + 1;
+        t[min1].right  = min2;
+        t[min2].parent = min1;
+        t[min1].parent = -1;
+    }
+    return min1;
+}
+
+/* DFS, left = 0 / right = 1 (compress_kernel.cuh:2416-2496). */
+static void orc_assign_codes(const orc_node *t, int node, uint64_t code, int depth,
+                             uint64_t *codes, uint8_t *lens)
+{
+    if (t[node].left < 0) {             /* leaf */
+        codes[t[node].value] = code; lens[t[node].value] = (uint8_t)depth;
+        return;
+    }
+    orc_assign_codes(t, t[node].left,  (code << 1),     depth + 1, codes, lens);
+    orc_assign_codes(t, t[node].right, (code << 1) | 1, depth + 1, codes, lens);
+}
+
+/* public: code table for a histogram (codes[257], lens[257]); returns #leaves */
+ORC_API int orc_huff_codes(const uint32_t *hist256, uint32_t *codes_out, uint8_t *lens_out)
+{
+    orc_node t[HUFF_NODES]; int n;
+    uint64_t codes[HUFF_NUM_SYMS]; uint8_t lens[HUFF_NUM_SYMS];
+    memset(codes, 0, sizeof codes); memset(lens, 0, sizeof lens);
+    int head = orc_build_tree(hist256, t, &n);
+    if (n >= 2) orc_assign_codes(t, head, 0, 0, codes, lens);
+    for (int i = 0; i < HUFF_NUM_SYMS; i++) { codes_out[i] = (uint32_t)codes[i]; lens_out[i] = lens[i]; }
+    return n;
+}
+
+/* ========================================================================= */
+/* 5. cudppCompress end to end                     */
+/*    huffmanEncoding (compress_app.cu:65-117): histogram, tree, per-4096-   */
+/*    symbol block MSB-first packing (huffman_kernel_en,                     */
+/*    compress_kernel.cuh:2524-2708), datapack (:2716-2750).                 */
+/*    Returns 0 on success, 1 if some block needs more than 1536 words       */
+/*    (reference writes out of bounds there; stream is still produced).      */
+/*    compressed must hold ceil(n/4096) * (1 + worst) words; callers use     */
+/*    (1536+1)*256 like test_compress.cpp:717-718.                           */
+/* ========================================================================= */
+ORC_API int orc_huff_encode(const uint8_t *mtf, uint32_t n, uint32_t *hist256,
+                            uint32_t *encode_offset, uint32_t *compressed_size,
+                            uint32_t *compressed, uint32_t compressed_capacity_words)
+{
+    uint32_t codes[HUFF_NUM_SYMS]; uint8_t lens[HUFF_NUM_SYMS];
+    memset(hist256, 0, 256 * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; i++) hist256[mtf[i]]++;
+    orc_huff_codes(hist256, codes, lens);
+
+    uint32_t nblocks = (n + HUFF_BLOCK_SYMS - 1) / HUFF_BLOCK_SYMS;
+    uint32_t woff = 0; int overflow = 0;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        uint32_t lo = b * HUFF_BLOCK_SYMS, hi = lo + HUFF_BLOCK_SYMS; if (hi > n) hi = n;
+        uint64_t bits = 0;
+        for (uint32_t i = lo; i < hi; i++) bits += lens[mtf[i]];
+        uint32_t words = (uint32_t)((bits + 31) / 32);
+        if (words > HUFF_BLOCK_WORDS) overflow = 1;
+        if ((uint64_t)woff + 1 + words > compressed_capacity_words) return 2;
+        encode_offset[b] = woff;
+        compressed[woff] = words;
+        uint32_t *w = compressed + woff + 1;
+        memset(w, 0, sizeof(uint32_t) * words);
+        uint64_t bp = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            uint32_t c = codes[mtf[i]]; int l = lens[mtf[i]];
+            for (int k = l - 1; k >= 0; k--, bp++)
+                if ((c >> k) & 1u) w[bp >> 5] |= 0x80000000u >> (bp & 31);
+        }
+        woff += 1 + words;
+    }
+    *compressed_size = woff;
+    return overflow;
+}
+
+ORC_API int orc_compress(const uint8_t *in, uint32_t n, int32_t *bwt_index, uint32_t *hist256,
+                         uint32_t *encode_offset, uint32_t *compressed_size,
+                         uint32_t *compressed, uint32_t compressed_capacity_words)
+{
+    uint8_t *bwt = (uint8_t *)malloc(n ? n : 1), *mtf = (uint8_t *)malloc(n ? n : 1);
+    orc_bwt(in, n, bwt, bwt_index);
+    orc_mtf(bwt, n, mtf);
+    int rc = orc_huff_encode(mtf, n, hist256, encode_offset, compressed_size, compressed,
+                             compressed_capacity_words);
+    free(bwt); free(mtf);
+    return rc;
+}
+
+/* ========================================================================= */
+/* 6. Decoder: the gold decoder of computeCompressGold                       */
+/*    (test_compress.cpp:192-311: rebuild the tree from d_hist, walk it      */
+/*    bit by bit MSB-first, block b starts at word 1+encodeOffset[b]) ->     */
+/*    inverse MTF (:293-310) -> inverse BWT.  The gold inverse BWT           */
+/*    (:351-354) is the plain LF walk, valid only when the input ends in a   */
+/*    unique minimal byte; here the sentinel-aware inverse of SURVEY 8(f)1   */
+/*    is used so every input round-trips.                                    */
+/* ========================================================================= */
+ORC_API void orc_ibwt(const uint8_t *L, uint32_t n, int32_t index, uint8_t *out)
+{
+    /* L is the suffix-order BWT of T$ with the '$' row dropped and row
+     * `index` (the row of suffix 0, whose preceding char is '$') holding the
+     * wrapped char T[n-1].  Full column L' (n+1 rows): row 0 = '$'-suffix
+     * whose preceding char is T[n-1]; rows 1..n = L rows 0..n-1, with row
+     * index+1 being '$'.  Standard LF walk from the '$'-suffix row. */
+    if (n == 0) return;
+    uint32_t cnt[257]; memset(cnt, 0, sizeof cnt);
+    uint32_t *lf = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    /* symbols: '$' -> 0, byte c -> c+1 */
+    #define LSYM(r) ((r) == 0 ? (uint32_t)L[index] + 1 : ((r) == (uint32_t)index + 1 ? 0u : (uint32_t)L[(r) - 1] + 1))
+    for (uint32_t r = 0; r <= n; r++) cnt[LSYM(r)]++;
+    uint32_t sum = 0;
+    for (int c = 0; c < 257; c++) { uint32_t t = cnt[c]; cnt[c] = sum; sum += t; }
+    for (uint32_t r = 0; r <= n; r++) lf[r] = cnt[LSYM(r)]++;
+    /* row 0 is the suffix "$"; its L char is T[n-1]; walk backwards */
+    uint32_t r = 0;
+    for (uint32_t k = n; k-- > 0;) {
+        uint32_t sym = LSYM(r);
+        out[k] = (uint8_t)(sym - 1);
+        r = lf[r];
+    }
+    #undef LSYM
+    free(lf);
+}
+
+ORC_API int orc_decompress(int32_t bwt_index, const uint32_t *hist256, const uint32_t *encode_offset,
+                           const uint32_t *compressed, uint32_t n, uint8_t *out)
+{
+    orc_node t[HUFF_NODES]; int nl;
+    int head = orc_build_tree(hist256, t, &nl);
+    uint8_t *mtf = (uint8_t *)malloc(n ? n : 1), *bwt = (uint8_t *)malloc(n ? n : 1);
+    uint32_t nblocks = (n + HUFF_BLOCK_SYMS - 1) / HUFF_BLOCK_SYMS;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        uint32_t lo = b * HUFF_BLOCK_SYMS, hi = lo + HUFF_BLOCK_SYMS; if (hi > n) hi = n;
+        const uint32_t *w = compressed + encode_offset[b] + 1;
+        uint64_t bp = 0; int node = head;
+        for (uint32_t i = lo; i < hi;) {
+            uint32_t bit = (w[bp >> 5] >> (31 - (bp & 31))) & 1u; bp++;
+            node = bit ? t[node].right : t[node].left;
+            if (node < 0) { free(mtf); free(bwt); return 1; }
+            if (t[node].value != -1) {
+                if (t[node].value == HUFF_EOF) { free(mtf); free(bwt); return 1; }
+                mtf[i++] = (uint8_t)t[node].value; node = head;
+            }
+        }
+    }
+    orc_imtf(mtf, n, bwt);
+    orc_ibwt(bwt, n, bwt_index, out);
+    free(mtf); free(bwt);
+    return 0;
+}
+
+/* ========================================================================= */
+/* 7. CULZSS                                                                 */
+/*    constants: gpu_compress.h:62-69 (WINDOW_SIZE 128, MAX_CODED 128,       */
+/*    MAX_UNCODED 2, PCKTSIZE 4096)                                          */
+/* ========================================================================= */
+#define LZ_WIN   128
+#define LZ_MAXC  128
+#define LZ_RING  256
+#define LZ_PCKT  4096
+
+/* FindMatch (gpu_compress.cu:104-168) for lane tx. */
+static void orc_lz_find(const uint8_t *win, const uint8_t *la, int windowHead, int uncodedHead,
+                        int tx, int lastcheck, int *len_out, int *off_out)
+{
+    int length = 1, offset = 1;
+    int i = windowHead, j = 0, matching = 0, loop = 0;
+    int maxcheck = LZ_MAXC - tx * lastcheck;
+    while (loop < LZ_WIN) {
+        if (win[i] == la[(uncodedHead + j) % LZ_RING]) { j++; matching = 1; }
+        else {
+            if (matching && j > length) {
+                length = j;
+                int t = i - j; if (t < 0) t += LZ_RING;
+                offset = t;
+            }
+            j = 0; matching = 0;
+        }
+        i = (i + 1) % LZ_RING;
+        loop++;
+        if (loop >= maxcheck - 1) loop = LZ_WIN;
+    }
+    if (j > length && matching) {
+        length = j;
+        int t = i - j; if (t < 0) t += LZ_RING;
+        offset = t;
+    }
+    *len_out = length; *off_out = offset;
+}
+
+static void orc_lz_emit(uint8_t *out, int wfile, int tx, int len, int off, uint8_t lit)
+{   /* gpu_compress.cu:251-274 */
+    if (len >= LZ_MAXC) len = LZ_MAXC - 1;
+    if (len <= 2) { out[wfile + 2 * tx] = 1; out[wfile + 2 * tx + 1] = lit; }
+    else { out[wfile + 2 * tx] = (uint8_t)len; out[wfile + 2 * tx + 1] = (uint8_t)off; }
+}
+
+/* EncodeKernel (gpu_compress.cu:182-350), one 4096-byte packet, lock-step over
+ * 128 lanes; phases are separated exactly where the kernel has __syncthreads. */
+static void orc_lz_encode_packet(const uint8_t *in, uint8_t *out)
+{
+    uint8_t win[LZ_RING], la[LZ_RING];
+    int len[LZ_MAXC], off[LZ_MAXC];
+    int tx, filepoint = 0, wfile = 0, lastcheck = 0;
+    int whead0 = 0, uhead0 = 0;             /* lane tx has head = (tx + head0) % 256 */
+    memset(win, 0, sizeof win);
+    for (tx = 0; tx < LZ_MAXC; tx++) win[tx] = ' ';
+    for (tx = 0; tx < LZ_MAXC; tx++) la[tx] = in[tx];
+    filepoint += LZ_MAXC;
+    for (tx = 0; tx < LZ_MAXC; tx++) win[(tx + LZ_WIN) % LZ_RING] = la[tx];
+    for (tx = 0; tx < LZ_MAXC; tx++) la[LZ_MAXC + tx] = in[filepoint + tx];
+    filepoint += LZ_MAXC;
+    for (tx = 0; tx < LZ_MAXC; tx++)
+        orc_lz_find(win, la, (tx + whead0) % LZ_RING, (tx + uhead0) % LZ_RING, tx, 0, &len[tx], &off[tx]);
+
+    while (filepoint <= LZ_PCKT && !lastcheck) {
+        for (tx = 0; tx < LZ_MAXC; tx++)
+            orc_lz_emit(out, wfile, tx, len[tx], off[tx], la[(tx + uhead0) % LZ_RING]);
+        wfile += 2 * LZ_MAXC;
+        whead0 = (whead0 + LZ_MAXC) % LZ_RING;
+        uhead0 = (uhead0 + LZ_MAXC) % LZ_RING;
+        if (filepoint < LZ_PCKT) {
+            for (tx = 0; tx < LZ_MAXC; tx++)
+                la[(tx + uhead0 + LZ_MAXC) % LZ_RING] = in[filepoint + tx];
+            filepoint += LZ_MAXC;
+            for (tx = 0; tx < LZ_MAXC; tx++)
+                win[(tx + whead0 + LZ_WIN) % LZ_RING] = la[(tx + uhead0) % LZ_RING];
+        } else {
+            lastcheck++;
+            for (tx = 0; tx < LZ_MAXC; tx++)
+                win[(tx + whead0 + LZ_MAXC) % LZ_RING] = '^';
+        }
+        for (tx = 0; tx < LZ_MAXC; tx++)
+            orc_lz_find(win, la, (tx + whead0) % LZ_RING, (tx + uhead0) % LZ_RING, tx, lastcheck,
+                        &len[tx], &off[tx]);
+    }
+    if (lastcheck == 1)
+        for (tx = 0; tx < LZ_MAXC; tx++)
+            if (len[tx] > LZ_MAXC - tx) len[tx] = LZ_MAXC - tx;
+    for (tx = 0; tx < LZ_MAXC; tx++)
+        orc_lz_emit(out, wfile, tx, len[tx], off[tx], la[(tx + uhead0) % LZ_RING]);
+}
+
+/* candidates for a whole buffer: out = 2 bytes per input byte.
+ * (compression_kernel_wrapper gpu_compress.cu:426-460: 16 slices x 16 CTAs,
+ * each CTA one packet -> packet g at in[g*4096], out[g*8192]) */
+ORC_API void orc_lzss_candidates(const uint8_t *in, int buf_length, uint8_t *out)
+{
+    int npk = buf_length / LZ_PCKT;
+    for (int g = 0; g < npk; g++) orc_lz_encode_packet(in + (size_t)g * LZ_PCKT, out + (size_t)g * 2 * LZ_PCKT);
+}
+
+/* aftercomp + aftercompression_wrapper (gpu_compress.cu:462-670), NWORKERS=1.
+ * cand: 2*buf_length candidate bytes; packed: output (reference writes it in
+ * place over the input buffer; capacity here must be >= buf_length + 16 +
+ * 2*npk + 6).  Returns 1 and *comp_length on success, 0 when the packed form
+ * outgrew buf_length while scanning ("store raw"). */
+ORC_API int orc_lzss_pack(const uint8_t *cand, int buf_length, uint8_t *packed, int *comp_length)
+{
+    int npk = buf_length / LZ_PCKT;
+    int *header = (int *)malloc(sizeof(int) * (npk > 0 ? npk : 1));
+    int i = 0, j = 0, k = 0, tempj = 0, hold = 0, m;
+    uint8_t flags = 0, flagpos = 1, holdbuf[16];
+    int finish = buf_length;
+    while (i < finish * 2) {
+        if (j > finish) { free(header); return 0; }
+        int t = cand[i];
+        if (t == 1) { flags |= flagpos; holdbuf[hold++] = cand[i + 1]; i += 2; }
+        else { holdbuf[hold++] = (uint8_t)t; holdbuf[hold++] = cand[i + 1]; i += t * 2; }
+        if (flagpos == 0x80) {
+            packed[j++] = flags;
+            for (m = 0; m < hold; m++) packed[j++] = holdbuf[m];
+            flags = 0; flagpos = 1; hold = 0;
+        } else flagpos <<= 1;
+        if (i % (2 * LZ_PCKT) == 0 && i > 0) {
+            if (hold > 0) {
+                packed[j++] = flags;
+                for (m = 0; m < hold; m++) packed[j++] = holdbuf[m];
+                hold = 0;
+            }
+            flags = 0; flagpos = 1;
+            header[k++] = j - tempj; tempj = j;
+        }
+    }
+    for (i = 0; i < npk; i++) { packed[j++] = (uint8_t)(header[i] >> 8); packed[j++] = (uint8_t)header[i]; }
+    packed[j++] = (uint8_t)(buf_length >> 24); packed[j++] = (uint8_t)(buf_length >> 16);
+    packed[j++] = (uint8_t)(buf_length >> 8);  packed[j++] = (uint8_t)buf_length;
+    packed[j++] = 0; packed[j++] = 0;           /* pad size, always 0 (gpu_compress.cu:648-655) */
+    *comp_length = j;
+    free(header);
+    return 1;
+}
+
+/* DecodeKernel + trailer parse of decompression_kernel_wrapper
+ * (gpu_decompress.cu:120-294), numthre = 1. */
+ORC_API int orc_lzss_decode(const uint8_t *buf, int buf_length, uint8_t *out, int *decomp_length)
+{
+    int orig = ((int)buf[buf_length - 6] << 24) ^ ((int)buf[buf_length - 5] << 16) ^
+               ((int)buf[buf_length - 4] << 8) ^ (int)buf[buf_length - 3];
+    int pad = ((int)buf[buf_length - 2] << 8) ^ (int)buf[buf_length - 1];
+    int npk = orig / LZ_PCKT;
+    int start = 0;
+    for (int p = 0; p < npk; p++) {
+        int base = buf_length - 2 * npk - 6 + 2 * p;
+        int size = ((int)buf[base] << 8) ^ (int)buf[base + 1];
+        const uint8_t *src = buf + start;
+        uint8_t *dst = out + (size_t)p * LZ_PCKT;
+        uint8_t win[LZ_WIN], tmp[LZ_MAXC];
+        memset(win, ' ', sizeof win);
+        int fp = 0, wp = 0, next = 0, flags = 0, used = 7;
+        for (;;) {
+            flags >>= 1; used++;
+            if (used == 8) { if (fp >= size) break; flags = src[fp++]; used = 0; }
+            if (flags & 1) {
+                if (fp >= size) break;
+                dst[wp++] = src[fp]; win[next] = src[fp]; next = (next + 1) % LZ_WIN; fp++;
+            } else {
+                if (fp >= size) break;
+                int len = src[fp++];
+                if (fp >= size) break;
+                int off = src[fp++];
+                for (int i = 0; i < len; i++) { tmp[i] = win[(off + i) % LZ_WIN]; dst[wp++] = tmp[i]; }
+                for (int i = 0; i < len; i++) win[(next + i) % LZ_WIN] = tmp[i];
+                next = (next + len) % LZ_WIN;
+            }
+        }
+        start += size;
+    }
+    *decomp_length = orig - pad;
+    return 1;
+}
+
+/* ========================================================================= */
+/* 8. helpers for tests                                                      */
+/* ========================================================================= */
+ORC_API uint32_t orc_crc32(const uint8_t *p, size_t n)
+{   /* reflected 0xEDB88320, init/xorout 0xFFFFFFFF */
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) {
+        c ^= p[i];
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    }
+    return c ^ 0xFFFFFFFFu;
+}

@@ -1,0 +1,233 @@
+"""ctypes access to the CPU oracle (oracle/libglc_oracle.so) and, when it was
+built, the reference's own gold suffix-array routine (oracle/_ref/libsagold.so,
+compiled unmodified from cudpp-inpar/apps/cudpp_testrig/sa_gold.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product path never touches it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libglc_oracle.so")
+SAGOLD_SO = os.path.join(ORACLE_DIR, "_ref", "libsagold.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+
+
+def build_oracle():
+    """Compile the oracle (and _ref when /root/reference exists)."""
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+
+
+def _load():
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    lib = C.CDLL(ORACLE_SO)
+    lib.orc_suffix_array.argtypes = [_u8p, C.c_uint32, _u32p]
+    lib.orc_bwt.argtypes = [_u8p, C.c_uint32, _u8p, _i32p]
+    lib.orc_mtf.argtypes = [_u8p, C.c_uint32, _u8p]
+    lib.orc_imtf.argtypes = [_u8p, C.c_uint32, _u8p]
+    lib.orc_ibwt.argtypes = [_u8p, C.c_uint32, C.c_int32, _u8p]
+    lib.orc_huff_codes.argtypes = [_u32p, _u32p, _u8p]
+    lib.orc_huff_codes.restype = C.c_int
+    lib.orc_huff_encode.argtypes = [_u8p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint32]
+    lib.orc_huff_encode.restype = C.c_int
+    lib.orc_compress.argtypes = [_u8p, C.c_uint32, _i32p, _u32p, _u32p, _u32p, _u32p, C.c_uint32]
+    lib.orc_compress.restype = C.c_int
+    lib.orc_decompress.argtypes = [C.c_int32, _u32p, _u32p, _u32p, C.c_uint32, _u8p]
+    lib.orc_decompress.restype = C.c_int
+    lib.orc_lzss_candidates.argtypes = [_u8p, C.c_int, _u8p]
+    lib.orc_lzss_pack.argtypes = [_u8p, C.c_int, _u8p, C.POINTER(C.c_int)]
+    lib.orc_lzss_pack.restype = C.c_int
+    lib.orc_lzss_decode.argtypes = [_u8p, C.c_int, _u8p, C.POINTER(C.c_int)]
+    lib.orc_lzss_decode.restype = C.c_int
+    lib.orc_crc32.argtypes = [_u8p, C.c_size_t]
+    lib.orc_crc32.restype = C.c_uint32
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _p8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_u32p)
+
+
+def _as_u8(data):
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data,
+                             dtype=np.uint8)
+    return a
+
+
+HUFF_BLOCK = 4096
+MAX_BLOCK_WORDS = 1536
+
+
+def compressed_capacity_words(n):
+    nblk = (n + HUFF_BLOCK - 1) // HUFF_BLOCK
+    return max(1, nblk) * (MAX_BLOCK_WORDS + 1)
+
+
+def suffix_array(data):
+    a = _as_u8(data)
+    sa = np.zeros(max(1, a.size), dtype=np.uint32)
+    lib().orc_suffix_array(_p8(a), a.size, _p32(sa))
+    return sa[: a.size]
+
+
+def bwt(data):
+    a = _as_u8(data)
+    out = np.zeros(max(1, a.size), dtype=np.uint8)
+    idx = C.c_int32(-1)
+    lib().orc_bwt(_p8(a), a.size, _p8(out), C.byref(idx))
+    return out[: a.size], idx.value
+
+
+def ibwt(L, index):
+    a = _as_u8(L)
+    out = np.zeros(max(1, a.size), dtype=np.uint8)
+    lib().orc_ibwt(_p8(a), a.size, index, _p8(out))
+    return out[: a.size]
+
+
+def mtf(data):
+    a = _as_u8(data)
+    out = np.zeros(max(1, a.size), dtype=np.uint8)
+    lib().orc_mtf(_p8(a), a.size, _p8(out))
+    return out[: a.size]
+
+
+def imtf(data):
+    a = _as_u8(data)
+    out = np.zeros(max(1, a.size), dtype=np.uint8)
+    lib().orc_imtf(_p8(a), a.size, _p8(out))
+    return out[: a.size]
+
+
+def huff_codes(hist256):
+    h = np.ascontiguousarray(hist256, dtype=np.uint32)
+    codes = np.zeros(257, dtype=np.uint32)
+    lens = np.zeros(257, dtype=np.uint8)
+    n = lib().orc_huff_codes(_p32(h), _p32(codes), _p8(lens))
+    return codes, lens, n
+
+
+def huff_encode(mtf_bytes):
+    a = _as_u8(mtf_bytes)
+    cap = compressed_capacity_words(a.size)
+    nblk = (a.size + HUFF_BLOCK - 1) // HUFF_BLOCK
+    hist = np.zeros(256, dtype=np.uint32)
+    off = np.zeros(max(1, nblk), dtype=np.uint32)
+    size = C.c_uint32(0)
+    comp = np.zeros(cap, dtype=np.uint32)
+    rc = lib().orc_huff_encode(_p8(a), a.size, _p32(hist), _p32(off), C.byref(size), _p32(comp), cap)
+    return dict(rc=rc, hist=hist, offsets=off[:nblk], size=size.value, words=comp[: size.value])
+
+
+def compress(data):
+    """Oracle cudppCompress.  Returns dict(bwt_index, hist, offsets, size, words, rc)."""
+    a = _as_u8(data)
+    cap = compressed_capacity_words(a.size)
+    nblk = (a.size + HUFF_BLOCK - 1) // HUFF_BLOCK
+    hist = np.zeros(256, dtype=np.uint32)
+    off = np.zeros(max(1, nblk), dtype=np.uint32)
+    size = C.c_uint32(0)
+    comp = np.zeros(cap, dtype=np.uint32)
+    idx = C.c_int32(-1)
+    rc = lib().orc_compress(_p8(a), a.size, C.byref(idx), _p32(hist), _p32(off), C.byref(size), _p32(comp), cap)
+    return dict(rc=rc, bwt_index=idx.value, hist=hist, offsets=off[:nblk], size=size.value,
+                words=comp[: size.value])
+
+
+def decompress(bwt_index, hist, offsets, words, n):
+    hist = np.ascontiguousarray(hist, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.zeros(max(1, n), dtype=np.uint8)
+    rc = lib().orc_decompress(bwt_index, _p32(hist), _p32(offsets), _p32(words), n, _p8(out))
+    if rc != 0:
+        raise ValueError("oracle decoder: corrupt stream")
+    return out[:n]
+
+
+def lzss_candidates(data):
+    a = _as_u8(data)
+    assert a.size % 4096 == 0
+    out = np.zeros(2 * a.size, dtype=np.uint8)
+    lib().orc_lzss_candidates(_p8(a), a.size, _p8(out))
+    return out
+
+
+def lzss_pack(cand, buf_length):
+    c = _as_u8(cand)
+    out = np.zeros(buf_length + 64 + 2 * (buf_length // 4096), dtype=np.uint8)
+    n = C.c_int(0)
+    ok = lib().orc_lzss_pack(_p8(c), buf_length, _p8(out), C.byref(n))
+    if not ok:
+        return None
+    return out[: n.value].copy()
+
+
+def lzss_decode(packed):
+    p = _as_u8(packed)
+    orig = int.from_bytes(bytes(p[-6:-2]), "big")
+    out = np.zeros(max(1, orig) + 4096, dtype=np.uint8)
+    n = C.c_int(0)
+    lib().orc_lzss_decode(_p8(p), p.size, _p8(out), C.byref(n))
+    return out[: n.value].copy()
+
+
+def crc32(data):
+    a = _as_u8(data)
+    return lib().orc_crc32(_p8(a), a.size)
+
+
+# --------------------------------------------------------------------------
+# the reference's own gold (only where oracle/_ref was built)
+# --------------------------------------------------------------------------
+def have_ref_gold():
+    return os.path.exists(SAGOLD_SO)
+
+
+_gold = None
+
+
+def ref_sa_gold(data):
+    """computeSaGold (sa_gold.cpp:110-119), the reference's CPU skew SA."""
+    global _gold
+    if _gold is None:
+        _gold = C.CDLL(SAGOLD_SO)
+        _gold._Z13computeSaGoldPhPjm.argtypes = [_u8p, _u32p, C.c_size_t]
+    a = _as_u8(data).copy()
+    ref = np.zeros(a.size + 3, dtype=np.uint32)
+    _gold._Z13computeSaGoldPhPjm(_p8(a), _p32(ref), a.size)
+    return ref[: a.size]
+
+
+# --------------------------------------------------------------------------
+# the reference test-input generators (glibc rand, srand(95835))
+# test_compress.cpp:439-441,552-556,687-692 ; test_sa.cpp:124-126
+# --------------------------------------------------------------------------
+def glibc_rand_bytes(n, mod, seed=95835):
+    libc = C.CDLL("libc.so.6")
+    libc.srand(seed)
+    rand = libc.rand
+    return np.fromiter(((rand() % mod) + 1 for _ in range(n)), dtype=np.uint8, count=n)
