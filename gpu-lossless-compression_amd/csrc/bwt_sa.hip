@@ -1,0 +1,510 @@
+// bwt_sa.hip -- suffix array + BWT for blocks of <= 2^20 bytes, many blocks per
+// launch (blockIdx.y = block).  gfx950 / wave64.
+//
+// Replaces, result-for-result, the reference's
+//   cudppSuffixArrayDispatch / ComputeSA     (cudpp-inpar/src/cudpp/app/sa_app.cu:125-298,365-391)
+//   strConstruct / resultConstruct           (kernel/sa_kernel.cuh:47-82)
+//   bwt_compute_final_kernel                 (kernel/compress_kernel.cuh:55-74)
+// The reference builds the SA with a recursive skew/DC3 on cub + moderngpu.  The
+// SA of (in[i]+1)$ with a unique minimal sentinel is unique, so this file uses a
+// different, MI355X-shaped algorithm and still produces identical bytes:
+//
+//   round 0 : one 64-bit word per suffix = [41-bit mixed-radix code of the first
+//             5 symbols (symbol = byte+1, 0 past the end) | 20-bit suffix index],
+//             LSD radix sort on the 41 key bits, LDS-staged digit buckets.
+//   round r : prefix doubling on the *unresolved* suffixes only (Larsson-Sadakane
+//             style): word = [rank(i):21 | rank(i+h):21 | i:20], same radix sort,
+//             results scattered back to their SA slots, ranks refined, singletons
+//             dropped.  h = 5, 10, 20, ...
+//
+// One array of 8-byte words is the only thing the sort moves (key and payload are
+// the same word), so a radix pass costs 8 B read (histogram) + 8 B read + 8 B
+// written per live suffix.
+#include "glc_device.h"
+#include "glc_internal.h"
+
+namespace glc {
+
+constexpr int      SA_THREADS = 256;
+constexpr int      SA_ITEMS   = 8;
+constexpr int      SA_TILE    = SA_THREADS * SA_ITEMS;      // 2048 suffixes per workgroup
+constexpr int      SA_MAXRADIX = 512;
+constexpr uint32_t VAL_BITS   = 20;
+constexpr uint64_t VAL_MASK   = (1ull << VAL_BITS) - 1;
+constexpr uint32_t R1_SHIFT   = 41;                         // rank(i) field, rounds >= 1
+constexpr uint32_t R2_SHIFT   = 20;                         // rank(i+h) field
+
+__device__ __forceinline__ uint32_t live_count(const uint32_t *cnt, uint32_t nfixed, uint32_t b)
+{
+    return cnt ? cnt[b] : nfixed;
+}
+
+// ---------------------------------------------------------------------------
+// round-0 words: 5 symbols in base 257 (257^5 < 2^41) | suffix index
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(SA_THREADS) void k_sa_init_keys(const uint8_t *__restrict__ text,
+                                                             size_t text_stride, uint32_t n,
+                                                             uint64_t *__restrict__ key, uint32_t nmax)
+{
+    __shared__ uint16_t s_sym[SA_TILE + 8];
+    const uint32_t b = blockIdx.y, base = blockIdx.x * SA_TILE, tid = threadIdx.x;
+    const uint8_t *T = text + (size_t)b * text_stride;
+    for (uint32_t i = tid; i < SA_TILE + 4; i += SA_THREADS) {
+        uint32_t gi = base + i;
+        s_sym[i] = gi < n ? (uint16_t)(T[gi] + 1) : (uint16_t)0;
+    }
+    __syncthreads();
+    uint64_t *K = key + (size_t)b * nmax;
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        uint32_t li = r * SA_THREADS + tid, gi = base + li;
+        if (gi < n) {
+            uint64_t c = s_sym[li];
+            c = c * 257 + s_sym[li + 1];
+            c = c * 257 + s_sym[li + 2];
+            c = c * 257 + s_sym[li + 3];
+            c = c * 257 + s_sym[li + 4];
+            K[gi] = (c << VAL_BITS) | gi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// radix pass 1/3: per-tile digit histogram (LDS, one sub-histogram per wave)
+// ---------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(SA_THREADS) void k_rs_hist(const uint64_t *__restrict__ key,
+                                                        const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                        uint32_t shift, uint32_t *__restrict__ tile_hist,
+                                                        uint32_t nmax, uint32_t max_tiles)
+{
+    constexpr int RADIX = 1 << BITS;
+    __shared__ uint32_t s_h[4][RADIX];
+    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
+    const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
+    if (base >= m) return;
+    const uint32_t tile_n = min((uint32_t)SA_TILE, m - base);
+    for (uint32_t i = tid; i < 4 * RADIX; i += SA_THREADS) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t *K = key + (size_t)b * nmax + base;
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        uint32_t i = r * SA_THREADS + tid;
+        if (i < tile_n) atomicAdd(&s_h[w][(uint32_t)(K[i] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t *H = tile_hist + ((size_t)b * max_tiles + t) * SA_MAXRADIX;
+    for (uint32_t d = tid; d < RADIX; d += SA_THREADS) H[d] = s_h[0][d] + s_h[1][d] + s_h[2][d] + s_h[3][d];
+}
+
+// ---------------------------------------------------------------------------
+// radix pass 2/3: per block, turn tile histograms into per-(tile,digit)
+// exclusive prefixes and the per-digit base.  One 512-thread workgroup / block.
+// ---------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(512) void k_rs_scan(uint32_t *__restrict__ tile_hist,
+                                                 const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                 uint32_t *__restrict__ digit_base, uint32_t max_tiles)
+{
+    constexpr int RADIX = 1 << BITS;
+    __shared__ uint32_t s_tmp[16];
+    const uint32_t b = blockIdx.x, d = threadIdx.x;
+    const uint32_t m = live_count(cnt, nfixed, b);
+    const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
+    uint32_t run = 0;
+    if (d < RADIX) {
+        uint32_t *h = tile_hist + (size_t)b * max_tiles * SA_MAXRADIX + d;
+        for (uint32_t t0 = 0; t0 < ntiles; t0 += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = (t0 + j < ntiles) ? h[(size_t)(t0 + j) * SA_MAXRADIX] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (t0 + j < ntiles) { h[(size_t)(t0 + j) * SA_MAXRADIX] = run; run += x[j]; }
+        }
+    }
+    uint32_t ex = block_excl_add<512>(run, s_tmp);
+    if (d < RADIX) digit_base[(size_t)b * SA_MAXRADIX + d] = ex;
+}
+
+// ---------------------------------------------------------------------------
+// radix pass 3/3: stable scatter.  Each wave ranks its 512 words 64 at a time
+// with a ballot match on the digit (wave64), buckets are staged in LDS so the
+// global writes are runs of consecutive addresses per digit.
+// ---------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(SA_THREADS) void k_rs_scatter(const uint64_t *__restrict__ key_in,
+                                                           uint64_t *__restrict__ key_out,
+                                                           const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                           uint32_t shift,
+                                                           const uint32_t *__restrict__ tile_hist,
+                                                           const uint32_t *__restrict__ digit_base,
+                                                           uint32_t nmax, uint32_t max_tiles)
+{
+    constexpr int RADIX = 1 << BITS;
+    constexpr int DPT = RADIX / SA_THREADS;                 // digits per thread in the prefix step
+    __shared__ uint32_t s_wc[4][RADIX];
+    __shared__ uint32_t s_gbase[RADIX];
+    __shared__ uint64_t s_key[SA_TILE];
+    __shared__ uint32_t s_tmp[8];
+    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
+    if (base >= m) return;
+    const uint32_t tile_n = min((uint32_t)SA_TILE, m - base);
+    const uint64_t *K = key_in + (size_t)b * nmax + base;
+    uint64_t *KO = key_out + (size_t)b * nmax;
+
+    for (uint32_t i = tid; i < 4 * RADIX; i += SA_THREADS) (&s_wc[0][0])[i] = 0;
+    __syncthreads();
+
+    uint64_t k[SA_ITEMS];
+    uint32_t rk[SA_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        const uint32_t i = w * (SA_TILE / 4) + r * 64 + l;
+        const bool valid = i < tile_n;
+        k[r] = valid ? K[i] : 0ull;
+        const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < BITS; bit++) {
+            const bool set = (d >> bit) & 1u;
+            const uint64_t bal = __ballot(set);
+            peers &= set ? bal : ~bal;
+        }
+        const uint32_t pre = mbcnt(peers), tot = (uint32_t)__popcll(peers);
+        const uint32_t old = s_wc[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && pre == 0) s_wc[w][d] = old + tot;
+        __builtin_amdgcn_wave_barrier();
+        rk[r] = old + pre;
+    }
+    __syncthreads();
+
+    // tile-local bucket starts (exclusive scan over digits), per-wave starts, global bases
+    uint32_t c[DPT][4], tot[DPT], tsum = 0;
+#pragma unroll
+    for (int q = 0; q < DPT; q++) {
+        const uint32_t d = tid * DPT + q;
+        c[q][0] = s_wc[0][d]; c[q][1] = s_wc[1][d]; c[q][2] = s_wc[2][d]; c[q][3] = s_wc[3][d];
+        tot[q] = c[q][0] + c[q][1] + c[q][2] + c[q][3];
+        tsum += tot[q];
+    }
+    uint32_t run = block_excl_add<SA_THREADS>(tsum, s_tmp);
+    const uint32_t *TH = tile_hist + ((size_t)b * max_tiles + t) * SA_MAXRADIX;
+    const uint32_t *DB = digit_base + (size_t)b * SA_MAXRADIX;
+#pragma unroll
+    for (int q = 0; q < DPT; q++) {
+        const uint32_t d = tid * DPT + q;
+        s_wc[0][d] = run;
+        s_wc[1][d] = run + c[q][0];
+        s_wc[2][d] = run + c[q][0] + c[q][1];
+        s_wc[3][d] = run + c[q][0] + c[q][1] + c[q][2];
+        s_gbase[d] = DB[d] + TH[d] - run;
+        run += tot[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        const uint32_t i = w * (SA_TILE / 4) + r * 64 + l;
+        if (i < tile_n) {
+            const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
+            s_key[s_wc[w][d] + rk[r]] = k[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        const uint32_t p = r * SA_THREADS + tid;
+        if (p < tile_n) {
+            const uint64_t kk = s_key[p];
+            const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
+            KO[s_gbase[d] + p] = kk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// After a sort: group heads, ranks, write-back, compaction of unresolved.
+// APPLY=false: per-tile aggregates (last head index, #unresolved).
+// APPLY=true : uses the scanned aggregates and writes ISA / SA / next list.
+// A suffix is resolved when its group (equal sort key) is a singleton.
+// ---------------------------------------------------------------------------
+template <bool APPLY>
+__global__ __launch_bounds__(SA_THREADS) void k_sa_rank(const uint64_t *__restrict__ key,
+                                                        const uint32_t *__restrict__ pos,
+                                                        const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                        uint2 *__restrict__ tile_agg,
+                                                        uint32_t *__restrict__ isa, uint32_t *__restrict__ sa,
+                                                        uint64_t *__restrict__ key_next,
+                                                        uint32_t *__restrict__ pos_next,
+                                                        uint32_t nmax, uint32_t max_tiles)
+{
+    __shared__ uint32_t s_tmp[8];
+    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
+    if (base >= m) return;
+    const uint64_t *K = key + (size_t)b * nmax;
+    const uint32_t *P = pos ? pos + (size_t)b * nmax : nullptr;
+    const uint32_t e0 = base + tid * SA_ITEMS;
+
+    // kk[i] = word of element e0 - 1 + i  (i = 0..9); compare on the sort-key bits only
+    uint64_t kk[SA_ITEMS + 2];
+#pragma unroll
+    for (int i = 0; i < SA_ITEMS + 2; i++) {
+        const int64_t g = (int64_t)e0 - 1 + i;
+        kk[i] = (g >= 0 && g < (int64_t)m) ? (K[g] >> VAL_BITS) : 0ull;
+    }
+    uint32_t headm = 0, unresm = 0, lh = 0, uc = 0;
+#pragma unroll
+    for (int i = 0; i < SA_ITEMS; i++) {
+        const uint32_t e = e0 + i;
+        if (e < m) {
+            const bool head = (e == 0) || (kk[i + 1] != kk[i]);
+            const bool nhead = (e + 1 >= m) || (kk[i + 2] != kk[i + 1]);
+            if (head) { headm |= 1u << i; lh = e; }
+            if (!(head && nhead)) { unresm |= 1u << i; uc++; }
+        }
+    }
+    if (!APPLY) {
+        uint32_t mx = wave_max(lh), sm = wave_sum(uc);
+        if ((tid & 63) == 0) { s_tmp[tid >> 6] = mx; s_tmp[4 + (tid >> 6)] = sm; }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t a = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
+            uint32_t c = s_tmp[4] + s_tmp[5] + s_tmp[6] + s_tmp[7];
+            tile_agg[(size_t)b * max_tiles + t] = make_uint2(a, c);
+        }
+        return;
+    } else {
+        const uint2 agg = tile_agg[(size_t)b * max_tiles + t];     // (carry head, unresolved offset)
+        uint32_t carry = block_excl_max<SA_THREADS>(lh, s_tmp);
+        carry = max(carry, agg.x);
+        uint32_t off = agg.y + block_excl_add<SA_THREADS>(uc, s_tmp);
+        uint32_t *ISA = isa + (size_t)b * nmax, *SAo = sa + (size_t)b * nmax;
+        uint64_t *KN = key_next + (size_t)b * nmax;
+        uint32_t *PN = pos_next + (size_t)b * nmax;
+        uint32_t running = carry;
+#pragma unroll
+        for (int i = 0; i < SA_ITEMS; i++) {
+            const uint32_t e = e0 + i;
+            if (e < m) {
+                if (headm & (1u << i)) running = e;
+                const uint32_t grp = P ? P[running] : running;    // SA slot of the group head
+                const uint32_t v = (uint32_t)(K[e] & VAL_MASK);
+                const uint32_t slot = P ? P[e] : e;
+                ISA[v] = grp + 1;
+                SAo[slot] = v;
+                if (unresm & (1u << i)) {
+                    PN[off] = slot;
+                    KN[off] = ((uint64_t)(grp + 1) << R1_SHIFT) | v;
+                    off++;
+                }
+            }
+        }
+    }
+}
+
+// scan of the per-tile aggregates; one 512-thread workgroup per block
+__global__ __launch_bounds__(512) void k_sa_aggscan(uint2 *__restrict__ tile_agg,
+                                                    const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                    uint32_t *__restrict__ cnt_next,
+                                                    uint32_t *__restrict__ d_max_cnt, uint32_t max_tiles)
+{
+    __shared__ uint32_t s_tmp[16];
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint32_t m = live_count(cnt, nfixed, b);
+    const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
+    uint2 a = make_uint2(0, 0);
+    if (t < ntiles) a = tile_agg[(size_t)b * max_tiles + t];
+    uint32_t carry = block_excl_max<512>(a.x, s_tmp);
+    uint32_t total = 0;
+    uint32_t off = block_excl_add<512>(a.y, s_tmp, &total);
+    if (t < ntiles) tile_agg[(size_t)b * max_tiles + t] = make_uint2(carry, off);
+    if (t == 0) {
+        cnt_next[b] = total;
+        if (total) atomicMax(d_max_cnt, total);
+    }
+}
+
+// rounds >= 1: fill in rank(i+h)
+__global__ __launch_bounds__(SA_THREADS) void k_sa_fill_rank2(uint64_t *__restrict__ key,
+                                                              const uint32_t *__restrict__ cnt,
+                                                              const uint32_t *__restrict__ isa, uint32_t n,
+                                                              uint32_t h, uint32_t nmax)
+{
+    const uint32_t b = blockIdx.y, m = cnt[b];
+    uint64_t *K = key + (size_t)b * nmax;
+    const uint32_t *ISA = isa + (size_t)b * nmax;
+    for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
+        uint64_t k = K[i];
+        uint32_t v = (uint32_t)(k & VAL_MASK);
+        uint32_t r2 = (v + h < n) ? ISA[v + h] : 0u;
+        K[i] = k | ((uint64_t)r2 << R2_SHIFT);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BWT gather (bwt_compute_final_kernel, compress_kernel.cuh:55-74)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwt_gather(const uint8_t *__restrict__ text, size_t text_stride,
+                                                    const uint32_t *__restrict__ sa, size_t sa_stride,
+                                                    uint32_t n, uint8_t *__restrict__ out, size_t out_stride,
+                                                    int *__restrict__ d_index)
+{
+    const uint32_t b = blockIdx.y;
+    const uint8_t *T = text + (size_t)b * text_stride;
+    const uint32_t *S = sa + (size_t)b * sa_stride;
+    uint8_t *O = out + (size_t)b * out_stride;
+    // 4 outputs per thread so the store is one dword
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = i0 + j;
+        if (i < n) {
+            const uint32_t v = S[i];
+            uint8_t c;
+            if (v == 0) { c = T[n - 1]; d_index[b] = (int)i; }
+            else c = T[v - 1];
+            packed |= (uint32_t)c << (8 * j);
+        }
+    }
+    if (i0 + 3 < n && ((reinterpret_cast<uintptr_t>(O) & 3) == 0)) *reinterpret_cast<uint32_t *>(O + i0) = packed;
+    else for (int j = 0; j < 4 && i0 + j < n; j++) O[i0 + j] = (uint8_t)(packed >> (8 * j));
+}
+
+__global__ void k_sa_export(const uint32_t *__restrict__ sa, uint32_t n, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) out[0] = n;
+    if (i < n) out[i + 1] = sa[i];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+#define GLC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
+{
+    s.nmax = nmax; s.rows = rows; s.max_tiles = (nmax + SA_TILE - 1) / SA_TILE;
+    const size_t ne = (size_t)nmax * rows;
+    size_t total = 0;
+    auto A = [&](void **p, size_t bytes) -> hipError_t { total += bytes; return hipMalloc(p, bytes); };
+    GLC_TRY(A((void **)&s.keyA, ne * 8)); GLC_TRY(A((void **)&s.keyB, ne * 8));
+    GLC_TRY(A((void **)&s.posA, ne * 4)); GLC_TRY(A((void **)&s.posB, ne * 4));
+    GLC_TRY(A((void **)&s.isa, ne * 4));  GLC_TRY(A((void **)&s.sa, ne * 4));
+    GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.max_tiles * SA_MAXRADIX * 4));
+    GLC_TRY(A((void **)&s.digit_base, (size_t)rows * SA_MAXRADIX * 4));
+    GLC_TRY(A((void **)&s.tile_agg, (size_t)rows * s.max_tiles * sizeof(uint2)));
+    GLC_TRY(A((void **)&s.cntA, (size_t)rows * 4)); GLC_TRY(A((void **)&s.cntB, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.d_max_cnt, 4));
+    GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 4, hipHostMallocDefault));
+    s.bytes = total;
+    return hipSuccess;
+}
+
+void sa_scratch_free(SaScratch &s)
+{
+    void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.isa, s.sa, s.tile_hist, s.digit_base, s.tile_agg,
+                  s.cntA, s.cntB, s.d_max_cnt};
+    for (void *p : ps) if (p) (void)hipFree(p);
+    if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
+    s = SaScratch();
+}
+
+template <int BITS>
+static hipError_t radix_pass(hipStream_t st, const uint64_t *in, uint64_t *out, const uint32_t *cnt,
+                             uint32_t nfixed, uint32_t shift, uint32_t tiles, uint32_t nblk, SaScratch &s)
+{
+    dim3 g(tiles, nblk);
+    hipLaunchKernelGGL(k_rs_hist<BITS>, g, dim3(SA_THREADS), 0, st, in, cnt, nfixed, shift, s.tile_hist,
+                       s.nmax, s.max_tiles);
+    hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(nblk), dim3(512), 0, st, s.tile_hist, cnt, nfixed,
+                       s.digit_base, s.max_tiles);
+    hipLaunchKernelGGL(k_rs_scatter<BITS>, g, dim3(SA_THREADS), 0, st, in, out, cnt, nfixed, shift,
+                       s.tile_hist, s.digit_base, s.nmax, s.max_tiles);
+    return hipGetLastError();
+}
+
+hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                    SaScratch &s, int *rounds_out)
+{
+    if (n == 0 || n > s.nmax || n > MAX_BLOCK_ELEMS || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
+    uint32_t tiles = (n + SA_TILE - 1) / SA_TILE;
+    uint64_t *cur = s.keyA, *alt = s.keyB;
+    hipLaunchKernelGGL(k_sa_init_keys, dim3(tiles, nblk), dim3(SA_THREADS), 0, st, text, text_stride, n, cur,
+                       s.nmax);
+    // 41 key bits at [20, 61): 8+8+8+8+9
+    for (int p = 0; p < 4; p++) {
+        GLC_TRY(radix_pass<8>(st, cur, alt, nullptr, n, VAL_BITS + 8 * p, tiles, nblk, s));
+        uint64_t *x = cur; cur = alt; alt = x;
+    }
+    GLC_TRY(radix_pass<9>(st, cur, alt, nullptr, n, VAL_BITS + 32, tiles, nblk, s));
+    { uint64_t *x = cur; cur = alt; alt = x; }
+
+    uint32_t *cnt_cur = nullptr, *cnt_next = s.cntA, *cnt_spare = s.cntB;
+    uint32_t *pos_cur = nullptr, *pos_next = s.posA, *pos_spare = s.posB;
+    uint32_t h = 5, live = n;
+    int rounds = 0;
+    for (;;) {
+        dim3 g(tiles, nblk);
+        GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 4, st));
+        hipLaunchKernelGGL(k_sa_rank<false>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
+                           s.tile_agg, s.isa, s.sa, alt, pos_next, s.nmax, s.max_tiles);
+        hipLaunchKernelGGL(k_sa_aggscan, dim3(nblk), dim3(512), 0, st, s.tile_agg, cnt_cur, live, cnt_next,
+                           s.d_max_cnt, s.max_tiles);
+        hipLaunchKernelGGL(k_sa_rank<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
+                           s.tile_agg, s.isa, s.sa, alt, pos_next, s.nmax, s.max_tiles);
+        GLC_TRY(hipGetLastError());
+        GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 4, hipMemcpyDeviceToHost, st));
+        GLC_TRY(hipStreamSynchronize(st));
+        rounds++;
+        const uint32_t maxc = *s.h_max_cnt;
+        if (maxc == 0) break;
+        if (h >= 2u * n + 10u) return hipErrorUnknown;           // cannot happen: h >= n resolves everything
+        // next round works on the compacted list that k_sa_rank<true> wrote into `alt`
+        { uint64_t *x = cur; cur = alt; alt = x; }
+        if (cnt_cur == nullptr) { cnt_cur = cnt_next; cnt_next = cnt_spare; }
+        else { uint32_t *x = cnt_cur; cnt_cur = cnt_next; cnt_next = x; }
+        if (pos_cur == nullptr) { pos_cur = pos_next; pos_next = pos_spare; }
+        else { uint32_t *x = pos_cur; pos_cur = pos_next; pos_next = x; }
+        live = maxc;
+        tiles = (maxc + SA_TILE - 1) / SA_TILE;
+        uint32_t fill_blocks = (maxc + SA_THREADS * 4 - 1) / (SA_THREADS * 4);
+        hipLaunchKernelGGL(k_sa_fill_rank2, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur,
+                           s.isa, n, h, s.nmax);
+        // 42 key bits at [20, 62): 8+8+8+9+9
+        for (int p = 0; p < 3; p++) {
+            GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 * p, tiles, nblk, s));
+            uint64_t *x = cur; cur = alt; alt = x;
+        }
+        for (int p = 0; p < 2; p++) {
+            GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 24 + 9 * p, tiles, nblk, s));
+            uint64_t *x = cur; cur = alt; alt = x;
+        }
+        h *= 2;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return hipSuccess;
+}
+
+hipError_t bwt_gather(hipStream_t st, const uint8_t *text, size_t text_stride, const uint32_t *sa,
+                      size_t sa_stride, uint32_t n, uint32_t nblk, uint8_t *out, size_t out_stride,
+                      int *d_index)
+{
+    dim3 g((n + 1023) / 1024, nblk);
+    hipLaunchKernelGGL(k_bwt_gather, g, dim3(256), 0, st, text, text_stride, sa, sa_stride, n, out,
+                       out_stride, d_index);
+    return hipGetLastError();
+}
+
+hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out)
+{
+    hipLaunchKernelGGL(k_sa_export, dim3((n + 256) / 256), dim3(256), 0, st, sa, n, out);
+    return hipGetLastError();
+}
+
+} // namespace glc

@@ -1,0 +1,373 @@
+// cudpp_api.cpp -- the C ABI of include/cudpp.h: library/plan handles, argument
+// validation and the per-call orchestration of the HIP stages.
+//
+// Mirrors the reference's public layer (cudpp-inpar/src/cudpp/cudpp.cpp:764-919,
+// 1000-1034; cudpp_plan.cpp:29-46,81-292,712-799; cudpp_manager.cpp:40-63):
+// same entry points, same handle representation (a pointer cast to size_t,
+// cudpp_plan.h:51-54), same validation order and result codes.  Differences are
+// deliberate and listed in DESIGN.md: plans are reusable (the reference leaks /
+// drifts, sa_app.cu:201-202,340-351), nothing is allocated per call
+// (compress_app.cu:257,263; sa_app.cu:73-100), HIP failures are returned as
+// CUDPP_ERROR_UNKNOWN instead of exit() (cuda_util.h:13-21).
+#include "../../include/cudpp.h"
+#include "glc_internal.h"
+
+#include <new>
+
+using namespace glc;
+
+namespace {
+
+struct Manager {
+    int device = 0;
+};
+
+struct PlanBase {
+    CUDPPConfiguration config{};
+    uint32_t n = 0, rows = 1;
+    hipStream_t stream = nullptr;
+    uint32_t *d_status = nullptr;
+    uint32_t *h_status = nullptr;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    float last_ms[4] = {0, 0, 0, 0};
+
+    hipError_t init_common()
+    {
+        hipError_t e = hipMalloc((void **)&d_status, 4);
+        if (e != hipSuccess) return e;
+        e = hipMemset(d_status, 0, 4);
+        if (e != hipSuccess) return e;
+        return hipHostMalloc((void **)&h_status, 4, hipHostMallocDefault);
+    }
+    virtual ~PlanBase()
+    {
+        if (d_status) (void)hipFree(d_status);
+        if (h_status) (void)hipHostFree(h_status);
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
+
+struct SaPlan : PlanBase {                       // CUDPPSaPlan (cudpp_plan.h:289-305)
+    SaScratch sa;
+    ~SaPlan() override { sa_scratch_free(sa); }
+};
+struct BwtPlan : PlanBase {                      // CUDPPBwtPlan (cudpp_plan.h:343-356)
+    SaScratch sa;
+    ~BwtPlan() override { sa_scratch_free(sa); }
+};
+struct MtfPlan : PlanBase {                      // CUDPPMtfPlan (cudpp_plan.h:358-369)
+    MtfScratch mtf;
+    ~MtfPlan() override { mtf_scratch_free(mtf); }
+};
+struct CompressPlan : PlanBase {                 // CUDPPCompressPlan (cudpp_plan.h:307-341)
+    SaScratch sa;
+    MtfScratch mtf;
+    HuffScratch huff;
+    DecodeScratch dec;
+    uint8_t *d_bwt = nullptr, *d_mtf = nullptr;  // [rows][n]
+    ~CompressPlan() override
+    {
+        sa_scratch_free(sa); mtf_scratch_free(mtf); huff_scratch_free(huff); decode_scratch_free(dec);
+        if (d_bwt) (void)hipFree(d_bwt);
+        if (d_mtf) (void)hipFree(d_mtf);
+    }
+};
+
+template <class T> T *plan_from(CUDPPHandle h) { return reinterpret_cast<T *>(h); }
+
+CUDPPResult validate_options(const CUDPPConfiguration &c)
+{   // cudpp_plan.cpp:29-46
+    if ((c.options & CUDPP_OPTION_BACKWARD) && (c.options & CUDPP_OPTION_FORWARD))
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if ((c.options & CUDPP_OPTION_EXCLUSIVE) && (c.options & CUDPP_OPTION_INCLUSIVE))
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult hip_result(hipError_t e)
+{
+    if (e == hipSuccess) return CUDPP_SUCCESS;
+    if (e == hipErrorOutOfMemory) return CUDPP_ERROR_INSUFFICIENT_RESOURCES;
+    return CUDPP_ERROR_UNKNOWN;
+}
+
+struct StageTimer {
+    PlanBase *p;
+    explicit StageTimer(PlanBase *pl) : p(pl)
+    {
+        if (p->timing && !p->ev[0])
+            for (auto &e : p->ev) (void)hipEventCreate(&e);
+    }
+    void mark(int i) { if (p->timing) (void)hipEventRecord(p->ev[i], p->stream); }
+    void done() { if (p->timing) p->ev_valid = true; }
+};
+
+} // namespace
+
+extern "C" {
+
+CUDPPResult cudppCreate(CUDPPHandle *theCudpp)
+{
+    if (!theCudpp) return CUDPP_ERROR_INVALID_HANDLE;
+    Manager *m = new (std::nothrow) Manager();
+    if (!m) return CUDPP_ERROR_UNKNOWN;
+    if (hipGetDevice(&m->device) != hipSuccess) { delete m; *theCudpp = 0; return CUDPP_ERROR_UNKNOWN; }
+    *theCudpp = reinterpret_cast<CUDPPHandle>(m);
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult cudppDestroy(CUDPPHandle theCudpp)
+{
+    if (theCudpp == 0 || theCudpp == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    delete reinterpret_cast<Manager *>(theCudpp);
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult cudppPlan(const CUDPPHandle cudppHandle, CUDPPHandle *planHandle, CUDPPConfiguration config,
+                      size_t n, size_t rows, size_t /*rowPitch*/)
+{
+    if (!planHandle) return CUDPP_ERROR_INVALID_HANDLE;
+    *planHandle = CUDPP_INVALID_HANDLE;
+    if (cudppHandle == 0 || cudppHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    CUDPPResult r = validate_options(config);
+    if (r != CUDPP_SUCCESS) return r;
+    if (rows == 0) rows = 1;
+    if (n == 0 || rows > 65535) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+
+    PlanBase *plan = nullptr;
+    hipError_t e = hipSuccess;
+    switch (config.algorithm) {
+    case CUDPP_COMPRESS: {
+        if (n > MAX_BLOCK_ELEMS) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+        CompressPlan *p = new (std::nothrow) CompressPlan();
+        if (!p) return CUDPP_ERROR_UNKNOWN;
+        plan = p;
+        e = sa_scratch_alloc(p->sa, (uint32_t)n, (uint32_t)rows);
+        if (e == hipSuccess) e = mtf_scratch_alloc(p->mtf, (uint32_t)n, (uint32_t)rows);
+        if (e == hipSuccess) e = huff_scratch_alloc(p->huff, (uint32_t)n, (uint32_t)rows);
+        if (e == hipSuccess) e = hipMalloc((void **)&p->d_bwt, n * rows);
+        if (e == hipSuccess) e = hipMalloc((void **)&p->d_mtf, n * rows);
+        break;
+    }
+    case CUDPP_BWT: {
+        if (n > MAX_BLOCK_ELEMS) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+        BwtPlan *p = new (std::nothrow) BwtPlan();
+        if (!p) return CUDPP_ERROR_UNKNOWN;
+        plan = p;
+        e = sa_scratch_alloc(p->sa, (uint32_t)n, (uint32_t)rows);
+        break;
+    }
+    case CUDPP_SA: {
+        if (n > MAX_BLOCK_ELEMS) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+        SaPlan *p = new (std::nothrow) SaPlan();
+        if (!p) return CUDPP_ERROR_UNKNOWN;
+        plan = p;
+        e = sa_scratch_alloc(p->sa, (uint32_t)n, (uint32_t)rows);
+        break;
+    }
+    case CUDPP_MTF: {
+        if (n > (1u << 30)) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+        MtfPlan *p = new (std::nothrow) MtfPlan();
+        if (!p) return CUDPP_ERROR_UNKNOWN;
+        plan = p;
+        e = mtf_scratch_alloc(p->mtf, (uint32_t)n, (uint32_t)rows);
+        break;
+    }
+    default:
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;   // not on the compression path
+    }
+    if (e == hipSuccess) e = plan->init_common();
+    if (e != hipSuccess) { delete plan; (void)hipGetLastError(); return hip_result(e); }
+    plan->config = config;
+    plan->n = (uint32_t)n;
+    plan->rows = (uint32_t)rows;
+    *planHandle = reinterpret_cast<CUDPPHandle>(plan);
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult cudppDestroyPlan(CUDPPHandle planHandle)
+{
+    if (planHandle == CUDPP_INVALID_HANDLE || planHandle == 0) return CUDPP_ERROR_INVALID_HANDLE;
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    switch (p->config.algorithm) {
+    case CUDPP_COMPRESS: case CUDPP_BWT: case CUDPP_MTF: case CUDPP_SA:
+        (void)hipStreamSynchronize(p->stream);
+        delete p;
+        return CUDPP_SUCCESS;
+    default:
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    }
+}
+
+// --------------------------------------------------------------------------
+// batched entry points
+// --------------------------------------------------------------------------
+CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_uncompressed, int *d_bwtIndex,
+                             unsigned int *d_hist, unsigned int *d_encodeOffset, size_t offsetStride,
+                             unsigned int *d_compressedSize, unsigned int *d_compressed,
+                             size_t compressedStrideWords, size_t numElements, size_t numBlocks)
+{
+    CompressPlan *p = plan_from<CompressPlan>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm != CUDPP_COMPRESS) return CUDPP_ERROR_INVALID_PLAN;
+    if (p->config.datatype != CUDPP_UCHAR) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (numElements == 0 || numElements > p->n || numBlocks == 0 || numBlocks > p->rows)
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    const uint32_t n = (uint32_t)numElements, nb = (uint32_t)numBlocks;
+    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    if (offsetStride < nsub) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    hipStream_t st = p->stream;
+    StageTimer tm(p);
+    tm.mark(0);
+    hipError_t e = sa_build(st, d_uncompressed, n, n, nb, p->sa);
+    if (e == hipSuccess) e = bwt_gather(st, d_uncompressed, n, p->sa.sa, p->sa.nmax, n, nb, p->d_bwt, p->n, d_bwtIndex);
+    tm.mark(1);
+    if (e == hipSuccess) e = mtf_forward(st, p->d_bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
+    tm.mark(2);
+    if (e == hipSuccess) e = huff_build(st, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
+                                        compressedStrideWords, p->d_status);
+    if (e == hipSuccess) e = huff_pack(st, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
+                                       d_compressed, compressedStrideWords);
+    tm.mark(3);
+    tm.done();
+    return hip_result(e);
+}
+
+CUDPPResult glcBwtBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsigned char *d_out, int *d_index,
+                        size_t numElements, size_t numBlocks)
+{
+    BwtPlan *p = plan_from<BwtPlan>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm != CUDPP_BWT) return CUDPP_ERROR_INVALID_PLAN;
+    if (p->config.datatype != CUDPP_UCHAR) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (numElements == 0 || numElements > p->n || numBlocks == 0 || numBlocks > p->rows)
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    const uint32_t n = (uint32_t)numElements, nb = (uint32_t)numBlocks;
+    hipError_t e = sa_build(p->stream, d_in, n, n, nb, p->sa);
+    if (e == hipSuccess) e = bwt_gather(p->stream, d_in, n, p->sa.sa, p->sa.nmax, n, nb, d_out, n, d_index);
+    return hip_result(e);
+}
+
+CUDPPResult glcMtfBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsigned char *d_out,
+                        size_t numElements, size_t numBlocks)
+{
+    MtfPlan *p = plan_from<MtfPlan>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm != CUDPP_MTF) return CUDPP_ERROR_INVALID_PLAN;
+    if (p->config.datatype != CUDPP_UCHAR) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (numElements == 0 || numElements > p->n || numBlocks == 0 || numBlocks > p->rows)
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    const uint32_t n = (uint32_t)numElements, nb = (uint32_t)numBlocks;
+    return hip_result(mtf_forward(p->stream, d_in, n, n, nb, d_out, n, p->mtf, nullptr));
+}
+
+CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, const unsigned int *d_hist,
+                               const unsigned int *d_encodeOffset, size_t offsetStride,
+                               const unsigned int *d_compressed, size_t compressedStrideWords,
+                               unsigned char *d_out, size_t numElements, size_t numBlocks)
+{
+    CompressPlan *p = plan_from<CompressPlan>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm != CUDPP_COMPRESS) return CUDPP_ERROR_INVALID_PLAN;
+    if (numElements == 0 || numElements > p->n || numBlocks == 0 || numBlocks > p->rows)
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (!p->dec.lf) {
+        hipError_t e = decode_scratch_alloc(p->dec, p->n, p->rows);
+        if (e != hipSuccess) return hip_result(e);
+    }
+    return hip_result(decode_blocks(p->stream, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compressed,
+                                    compressedStrideWords, d_out, (uint32_t)numElements, (uint32_t)numBlocks,
+                                    p->dec, p->mtf, p->d_status));
+}
+
+// --------------------------------------------------------------------------
+// the reference's single-block entry points
+// --------------------------------------------------------------------------
+CUDPPResult cudppCompress(CUDPPHandle planHandle, unsigned char *d_uncompressed, int *d_bwtIndex,
+                          unsigned int * /*d_histSize: ignored, as compress_app.cu:507-526*/,
+                          unsigned int *d_hist, unsigned int *d_encodeOffset, unsigned int *d_compressedSize,
+                          unsigned int *d_compressed, size_t numElements)
+{
+    if (planHandle == 0) return CUDPP_ERROR_INVALID_HANDLE;
+    const size_t nsub = (numElements + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    return glcCompressBatch(planHandle, d_uncompressed, d_bwtIndex, d_hist, d_encodeOffset, nsub ? nsub : 1,
+                            d_compressedSize, d_compressed, (size_t)(HUFF_MAX_WORDS + 1) * (nsub ? nsub : 1),
+                            numElements, 1);
+}
+
+CUDPPResult cudppBurrowsWheelerTransform(CUDPPHandle planHandle, unsigned char *d_in, unsigned char *d_out,
+                                         int *d_index, size_t numElements)
+{
+    if (planHandle == 0) return CUDPP_ERROR_INVALID_HANDLE;
+    return glcBwtBatch(planHandle, d_in, d_out, d_index, numElements, 1);
+}
+
+CUDPPResult cudppMoveToFrontTransform(CUDPPHandle planHandle, unsigned char *d_in, unsigned char *d_out,
+                                      size_t numElements)
+{
+    if (planHandle == 0) return CUDPP_ERROR_INVALID_HANDLE;
+    return glcMtfBatch(planHandle, d_in, d_out, numElements, 1);
+}
+
+CUDPPResult cudppSuffixArray(CUDPPHandle planHandle, unsigned char *d_str, unsigned int *d_keys_sa,
+                             size_t numElements)
+{
+    SaPlan *p = plan_from<SaPlan>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm != CUDPP_SA) return CUDPP_ERROR_INVALID_PLAN;
+    if (p->config.datatype != CUDPP_UCHAR) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (numElements == 0 || numElements > p->n) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    const uint32_t n = (uint32_t)numElements;
+    hipError_t e = sa_build(p->stream, d_str, n, n, 1, p->sa);
+    if (e == hipSuccess) e = sa_export(p->stream, p->sa.sa, n, d_keys_sa);
+    return hip_result(e);
+}
+
+// --------------------------------------------------------------------------
+// plan utilities
+// --------------------------------------------------------------------------
+CUDPPResult glcPlanSetStream(CUDPPHandle planHandle, void *hipStream)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    p->stream = reinterpret_cast<hipStream_t>(hipStream);
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    hipError_t e = hipMemcpyAsync(p->h_status, p->d_status, 4, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d_status, 0, 4, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) return CUDPP_ERROR_UNKNOWN;
+    if (p->timing && p->ev_valid) {
+        (void)hipEventElapsedTime(&p->last_ms[0], p->ev[0], p->ev[1]);
+        (void)hipEventElapsedTime(&p->last_ms[1], p->ev[1], p->ev[2]);
+        (void)hipEventElapsedTime(&p->last_ms[2], p->ev[2], p->ev[3]);
+        (void)hipEventElapsedTime(&p->last_ms[3], p->ev[0], p->ev[3]);
+    }
+    return *p->h_status ? CUDPP_ERROR_UNKNOWN : CUDPP_SUCCESS;
+}
+
+CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    p->timing = enable != 0;
+    p->ev_valid = false;
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !ms4) return CUDPP_ERROR_INVALID_HANDLE;
+    for (int i = 0; i < 4; i++) ms4[i] = p->last_ms[i];
+    return CUDPP_SUCCESS;
+}
+
+} // extern "C"

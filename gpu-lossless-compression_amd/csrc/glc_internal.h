@@ -1,0 +1,111 @@
+// glc_internal.h -- host-side interfaces between the C-ABI layer (cudpp_api.cpp,
+// culzss_api.cpp) and the stage launchers (*.hip).  Plain pointers + sizes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace glc {
+
+constexpr uint32_t MAX_BLOCK_ELEMS = 1u << 20;   // cudppCompress/BWT limit (cudpp-inpar/README.md:96,99)
+constexpr uint32_t HUFF_BLOCK      = 4096;       // HUFF_THREADS_PER_BLOCK*HUFF_WORK_PER_THREAD (cudpp_globals.h:60-61)
+constexpr uint32_t HUFF_SYMS       = 257;        // HUFF_NUM_CHARS (cudpp_globals.h:62)
+constexpr uint32_t HUFF_MAX_WORDS  = 1536;       // HUFF_CODE_BYTES (cudpp_globals.h:66)
+constexpr uint32_t MTF_CHUNK       = 4096;       // bytes of BWT output per wave in the MTF kernels
+
+// status bits accumulated on the device (PlanBase::d_status)
+constexpr uint32_t ST_BLOCK_OVERFLOW = 1u;       // a 4096-symbol block needs > 1536 words
+constexpr uint32_t ST_CAPACITY       = 2u;       // compressed stream would not fit its stride
+
+// ---------------------------------------------------------------------------
+// suffix array scratch: everything for `rows` blocks of up to nmax elements
+// ---------------------------------------------------------------------------
+struct SaScratch {
+    uint32_t  nmax = 0, rows = 0, max_tiles = 0;
+    uint64_t *keyA = nullptr, *keyB = nullptr;   // [rows][nmax]
+    uint32_t *posA = nullptr, *posB = nullptr;   // [rows][nmax] SA slots of the unresolved list
+    uint32_t *isa = nullptr;                     // [rows][nmax] rank+1 of each suffix
+    uint32_t *sa = nullptr;                      // [rows][nmax]
+    uint32_t *tile_hist = nullptr;               // [rows][max_tiles][512]
+    uint32_t *digit_base = nullptr;              // [rows][512]
+    uint2    *tile_agg = nullptr;                // [rows][max_tiles]
+    uint32_t *cntA = nullptr, *cntB = nullptr;   // [rows] unresolved counts
+    uint32_t *d_max_cnt = nullptr;               // [1]
+    uint32_t *h_max_cnt = nullptr;               // pinned [1]
+    size_t    bytes = 0;
+};
+
+hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows);
+void       sa_scratch_free(SaScratch &s);
+
+// Suffix arrays of `nblk` blocks of n bytes (block b at text + b*text_stride).
+// Result in s.sa[b*nmax ..].  Synchronises the stream once per doubling round.
+hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                    SaScratch &s, int *rounds_out = nullptr);
+
+// L[i] = SA[i]==0 ? T[n-1] : T[SA[i]-1];  index[b] = i with SA[i]==0
+hipError_t bwt_gather(hipStream_t st, const uint8_t *text, size_t text_stride, const uint32_t *sa,
+                      size_t sa_stride, uint32_t n, uint32_t nblk, uint8_t *out, size_t out_stride,
+                      int *d_index);
+
+// copy SA to the cudppSuffixArray layout (out[0]=n, out[1..n]=SA)
+hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out);
+
+// ---------------------------------------------------------------------------
+// MTF
+// ---------------------------------------------------------------------------
+struct MtfScratch {
+    uint32_t nmax = 0, rows = 0, max_chunks = 0;
+    uint8_t  *lists = nullptr;       // [rows][max_chunks][256] chunk-local recency lists, then start lists
+    uint16_t *lens = nullptr;        // [rows][max_chunks]
+    size_t    bytes = 0;
+};
+hipError_t mtf_scratch_alloc(MtfScratch &s, uint32_t nmax, uint32_t rows);
+void       mtf_scratch_free(MtfScratch &s);
+
+// out = MTF(in) per block; if sub_hist != nullptr also writes the histogram of
+// each 4096-symbol chunk of the output: sub_hist[b][chunk][256].
+hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint32_t n, uint32_t nblk,
+                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist);
+
+// ---------------------------------------------------------------------------
+// Huffman
+// ---------------------------------------------------------------------------
+struct HuffScratch {
+    uint32_t nmax = 0, rows = 0, max_sub = 0;
+    uint32_t *sub_hist = nullptr;    // [rows][max_sub][256]
+    uint32_t *codes = nullptr;       // [rows][257]
+    uint32_t *lens = nullptr;        // [rows][257]  (one word each for aligned LDS staging)
+    size_t    bytes = 0;
+};
+hipError_t huff_scratch_alloc(HuffScratch &s, uint32_t nmax, uint32_t rows);
+void       huff_scratch_free(HuffScratch &s);
+
+// tree + codes + offsets (writes d_hist[b][256], d_offsets[b*offset_stride..], d_size[b])
+hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
+                      uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size,
+                      size_t capacity_words, uint32_t *d_status);
+// pack (reads mtf bytes, writes the stream)
+hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
+                     HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride,
+                     uint32_t *d_compressed, size_t comp_stride_words);
+
+// ---------------------------------------------------------------------------
+// decoder (round-trip parity only; the reference has no GPU decoder)
+// ---------------------------------------------------------------------------
+struct DecodeScratch {
+    uint32_t nmax = 0, rows = 0;
+    uint8_t  *mtf = nullptr, *bwt = nullptr;     // [rows][nmax]
+    uint32_t *lf = nullptr;                      // [rows][nmax+1]
+    uint32_t *tree = nullptr;                    // [rows][513*2]
+    uint32_t *cnt = nullptr;                     // [rows][max_tiles][257] / bases
+    size_t    bytes = 0;
+};
+hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows);
+void       decode_scratch_free(DecodeScratch &s);
+hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist,
+                         const uint32_t *d_offsets, size_t offset_stride, const uint32_t *d_comp,
+                         size_t comp_stride_words, uint8_t *d_out, uint32_t n, uint32_t nblk,
+                         DecodeScratch &s, MtfScratch &ms, uint32_t *d_status);
+
+} // namespace glc

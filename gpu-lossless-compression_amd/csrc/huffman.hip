@@ -1,0 +1,300 @@
+// huffman.hip -- histogram merge, Huffman tree + codes, block offsets and the
+// bit packer for the cudppCompress stream.  gfx950 / wave64.
+//
+// Bit-exact replacement of (cudpp-inpar/src/cudpp):
+//   huffman_build_histogram_kernel   kernel/compress_kernel.cuh:2037-2121
+//   huffman_build_tree_kernel        kernel/compress_kernel.cuh:2199-2512
+//     + FindMinimumCount             cta/compress_cta.cuh:550-571
+//   huffman_kernel_en                kernel/compress_kernel.cuh:2524-2708
+//   huffman_datapack_kernel          kernel/compress_kernel.cuh:2716-2750
+//   host glue huffmanEncoding        app/compress_app.cu:65-117
+//
+// What must be reproduced exactly is the TREE SHAPE: leaves are the present
+// symbols (+EOF with count 1) in ascending order in slots 0..n-1; repeatedly the
+// two minima by (count, level, slot) are merged, the first minimum is relocated
+// to the next free slot >= n and becomes the LEFT child, the second stays and is
+// the RIGHT child, the composite takes the first minimum's slot; codes are
+// root-to-leaf paths with left = 0.  The stream is, per 4096 symbols, the codes
+// concatenated MSB-first into 32-bit words, preceded by the word count.
+//
+// MI355X design differences: the per-4096-symbol histograms come out of the MTF
+// kernel (no separate histogram pass); the tree search is a wave64 arg-min over
+// packed (count,level,slot) keys instead of one thread scanning 257 slots; the
+// size of every block is known from (sub-histogram . code lengths) BEFORE packing,
+// so the packer writes straight into its final place -- no staging array, no
+// O(B^2) offset loop, no device->host copy in the middle of the pipeline
+// (compress_app.cu:106).
+#include "glc_device.h"
+#include "glc_internal.h"
+
+namespace glc {
+
+constexpr int HUFF_NODES = 2 * 257 - 1;          // 513
+constexpr uint64_t KEY_NONE = ~0ull;
+
+// wave-wide arg-min of 64-bit keys (KEY_NONE = not a candidate)
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t k)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)k, o, 64), hi = __shfl_xor((uint32_t)(k >> 32), o, 64);
+        uint64_t other = ((uint64_t)hi << 32) | lo;
+        k = other < k ? other : k;
+    }
+    return k;
+}
+
+// one 256-thread workgroup per 1 MiB block
+__global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__ sub_hist, uint32_t max_sub,
+                                                    uint32_t n, uint32_t *__restrict__ d_hist,
+                                                    uint32_t *__restrict__ codes_out,
+                                                    uint32_t *__restrict__ lens_out,
+                                                    uint32_t *__restrict__ d_offsets, size_t offset_stride,
+                                                    uint32_t *__restrict__ d_size, uint64_t capacity_words,
+                                                    uint32_t *__restrict__ d_status)
+{
+    __shared__ uint32_t s_hist[257];
+    __shared__ uint64_t s_key[320];
+    __shared__ uint32_t s_count[HUFF_NODES];
+    __shared__ int16_t  s_level[HUFF_NODES], s_value[HUFF_NODES];
+    __shared__ int16_t  s_left[HUFF_NODES], s_right[HUFF_NODES], s_parent[HUFF_NODES];
+    __shared__ uint32_t s_code[257], s_len[257];
+    __shared__ uint32_t s_words[256];
+    __shared__ uint32_t s_tmp[8];
+    __shared__ int s_nl, s_head;
+
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    const uint32_t *SH = sub_hist + (size_t)b * max_sub * 256;
+
+    // ---- total histogram (huffman_build_tree_kernel merges partial histograms,
+    //      compress_kernel.cuh:2284-2299; EOF gets count 1, :2250) ----
+    {
+        uint32_t c = 0;
+        for (uint32_t s = 0; s < nsub; s++) c += SH[(size_t)s * 256 + tid];
+        s_hist[tid] = c;
+        d_hist[(size_t)b * 256 + tid] = c;
+        s_code[tid] = 0; s_len[tid] = 0;
+        if (tid == 0) { s_hist[256] = 1; s_code[256] = 0; s_len[256] = 0; }
+    }
+    __syncthreads();
+
+    if (w == 0) {
+        // ---- leaves: present symbols in ascending order -> slots 0..nl-1 ----
+        uint32_t nl = 0;
+        for (int r = 0; r < 5; r++) {
+            const uint32_t sym = r * 64 + l;
+            const uint32_t c = sym < 257 ? s_hist[sym] : 0u;
+            const uint64_t bal = __ballot(c > 0);
+            if (c > 0) {
+                const uint32_t slot = nl + mbcnt(bal);
+                s_count[slot] = c; s_level[slot] = 0; s_value[slot] = (int16_t)sym;
+                s_left[slot] = -1; s_right[slot] = -1; s_parent[slot] = -1;
+                s_key[slot] = ((uint64_t)c << 32) | slot;              // level 0
+            }
+            nl += (uint32_t)__popcll(bal);
+        }
+        for (uint32_t s = nl + l; s < 320; s += 64) s_key[s] = KEY_NONE;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- merge loop (compress_kernel.cuh:2323-2392) ----
+        int head = -1;
+        for (uint32_t k = 0;; k++) {
+            uint64_t best = KEY_NONE;
+#pragma unroll
+            for (int r = 0; r < 5; r++) { const uint64_t x = s_key[r * 64 + l]; best = x < best ? x : best; }
+            best = wave_min_u64(best);
+            if (best == KEY_NONE) break;
+            const int min1 = (int)(best & 0xFFFF);
+            head = min1;
+            if (l == 0) s_key[min1] = KEY_NONE;
+            __builtin_amdgcn_wave_barrier();
+            uint64_t best2 = KEY_NONE;
+#pragma unroll
+            for (int r = 0; r < 5; r++) { const uint64_t x = s_key[r * 64 + l]; best2 = x < best2 ? x : best2; }
+            best2 = wave_min_u64(best2);
+            if (best2 == KEY_NONE) break;
+            const int min2 = (int)(best2 & 0xFFFF);
+            if (l == 0) {
+                const int i = (int)(nl + k);                            // next free slot >= nl
+                const uint32_t c1 = s_count[min1], c2 = s_count[min2];
+                const int l1 = s_level[min1], l2 = s_level[min2];
+                const int lf = s_left[min1], rt = s_right[min1];
+                s_count[i] = c1; s_level[i] = (int16_t)l1; s_value[i] = s_value[min1];
+                s_left[i] = (int16_t)lf; s_right[i] = (int16_t)rt; s_parent[i] = (int16_t)min1;
+                if (lf >= 0) s_parent[lf] = (int16_t)i;
+                if (rt >= 0) s_parent[rt] = (int16_t)i;
+                const int lv = (l1 > l2 ? l1 : l2) + 1;
+                s_left[min1] = (int16_t)i; s_right[min1] = (int16_t)min2; s_value[min1] = -1;
+                s_count[min1] = c1 + c2; s_level[min1] = (int16_t)lv; s_parent[min1] = -1;
+                s_parent[min2] = (int16_t)min1;
+                s_key[min1] = ((uint64_t)(c1 + c2) << 32) | ((uint64_t)lv << 16) | (uint32_t)min1;
+                s_key[min2] = KEY_NONE;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (l == 0) { s_nl = (int)nl; s_head = head; }
+    }
+    __syncthreads();
+
+    // ---- codes: every leaf walks to the root; the k-th step up supplies bit k
+    //      (left = 0, right = 1: compress_kernel.cuh:2416-2496) ----
+    {
+        const int nl = s_nl, used = 2 * nl - 1;
+        for (int s = (int)tid; s < used; s += 256) {
+            if (s_left[s] < 0) {
+                uint32_t code = 0, len = 0;
+                int node = s, p = s_parent[s];
+                while (p >= 0) {
+                    if (s_right[p] == node) code |= 1u << len;
+                    len++;
+                    node = p; p = s_parent[p];
+                }
+                const int sym = s_value[s];
+                s_code[sym] = code; s_len[sym] = len;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 257; i += 256) {
+        codes_out[(size_t)b * 257 + i] = s_code[i];
+        lens_out[(size_t)b * 257 + i] = s_len[i];
+    }
+
+    // ---- words per 4096-symbol block = ceil(sub_hist . len / 32) ----
+    for (uint32_t s = w; s < 256; s += 4) {
+        uint32_t bits = 0;
+        if (s < nsub) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) bits += SH[(size_t)s * 256 + r * 64 + l] * s_len[r * 64 + l];
+        }
+        bits = wave_sum(bits);
+        if (l == 0) s_words[s] = (s < nsub) ? (bits + 31) / 32 : 0u;
+    }
+    __syncthreads();
+    {
+        const uint32_t wd = s_words[tid];
+        const uint32_t item = (tid < nsub) ? 1 + wd : 0;
+        uint32_t total = 0;
+        const uint32_t off = block_excl_add<256>(item, s_tmp, &total);
+        if (tid < nsub) {
+            d_offsets[(size_t)b * offset_stride + tid] = off;
+            if (wd > HUFF_MAX_WORDS) atomicOr(d_status, ST_BLOCK_OVERFLOW);
+        }
+        if (tid == 0) {
+            d_size[b] = total;
+            if ((uint64_t)total > capacity_words) atomicOr(d_status, ST_CAPACITY);
+        }
+    }
+}
+
+// grid (sub-blocks, blocks); 256 threads x 16 symbols
+__global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ mtf, size_t mtf_stride, uint32_t n,
+                                                   const uint32_t *__restrict__ codes,
+                                                   const uint32_t *__restrict__ lens,
+                                                   const uint32_t *__restrict__ d_offsets, size_t offset_stride,
+                                                   uint32_t *__restrict__ d_comp, size_t comp_stride,
+                                                   uint64_t capacity_words)
+{
+    constexpr int SPT = HUFF_BLOCK / 256;                     // 16 symbols per thread
+    constexpr int MAXW = HUFF_BLOCK * 28 / 32 + 16;            // code length <= 28 for <= 2^20+1 total count
+    __shared__ uint32_t s_code[257], s_len[257];
+    __shared__ uint32_t s_words[MAXW];
+    __shared__ uint32_t s_tmp[8];
+    const uint32_t b = blockIdx.y, sub = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lo = sub * HUFF_BLOCK;
+    if (lo >= n) return;
+    const uint32_t cntb = min((uint32_t)HUFF_BLOCK, n - lo);
+    for (uint32_t i = tid; i < 257; i += 256) { s_code[i] = codes[(size_t)b * 257 + i]; s_len[i] = lens[(size_t)b * 257 + i]; }
+    for (uint32_t i = tid; i < MAXW; i += 256) s_words[i] = 0;
+    __syncthreads();
+
+    const uint8_t *src = mtf + (size_t)b * mtf_stride + lo;
+    uint8_t sym[SPT];
+    const uint32_t i0 = tid * SPT;
+    if (i0 + SPT <= cntb && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(src + i0);
+        const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < SPT; j++) sym[j] = (uint8_t)(qq[j >> 2] >> (8 * (j & 3)));
+    } else {
+#pragma unroll
+        for (int j = 0; j < SPT; j++) sym[j] = (i0 + j < cntb) ? src[i0 + j] : 0;
+    }
+    uint32_t mybits = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) if (i0 + j < cntb) mybits += s_len[sym[j]];
+    uint32_t total = 0;
+    const uint32_t start = block_excl_add<256>(mybits, s_tmp, &total);
+
+    // shift-merge: pending bits live in the low `na` bits of acc
+    uint32_t wi = start >> 5, na = start & 31;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        if (i0 + j < cntb) {
+            const uint32_t ln = s_len[sym[j]];
+            acc = (acc << ln) | s_code[sym[j]];
+            na += ln;
+            if (na >= 32) {
+                na -= 32;
+                atomicOr(&s_words[wi++], (uint32_t)(acc >> na));
+                acc &= (1ull << na) - 1ull;
+            }
+        }
+    }
+    if (na > 0 && mybits > 0) atomicOr(&s_words[wi], (uint32_t)(acc << (32 - na)));
+    __syncthreads();
+
+    const uint32_t nwords = (total + 31) / 32;
+    const uint32_t off = d_offsets[(size_t)b * offset_stride + sub];
+    if ((uint64_t)off + 1 + nwords > capacity_words) return;             // flagged by k_huff_build
+    uint32_t *dst = d_comp + (size_t)b * comp_stride + off;
+    if (tid == 0) dst[0] = nwords;
+    for (uint32_t i = tid; i < nwords; i += 256) dst[1 + i] = s_words[i];
+}
+
+// ---------------------------------------------------------------------------
+#define GLC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t huff_scratch_alloc(HuffScratch &s, uint32_t nmax, uint32_t rows)
+{
+    s.nmax = nmax; s.rows = rows; s.max_sub = (nmax + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    size_t a = (size_t)rows * s.max_sub * 256 * 4, c = (size_t)rows * 257 * 4;
+    GLC_TRY(hipMalloc((void **)&s.sub_hist, a));
+    GLC_TRY(hipMalloc((void **)&s.codes, c));
+    GLC_TRY(hipMalloc((void **)&s.lens, c));
+    s.bytes = a + 2 * c;
+    return hipSuccess;
+}
+
+void huff_scratch_free(HuffScratch &s)
+{
+    if (s.sub_hist) (void)hipFree(s.sub_hist);
+    if (s.codes) (void)hipFree(s.codes);
+    if (s.lens) (void)hipFree(s.lens);
+    s = HuffScratch();
+}
+
+hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
+                      uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size, size_t capacity_words,
+                      uint32_t *d_status)
+{
+    if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_huff_build, dim3(nblk), dim3(256), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
+                       s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status);
+    return hipGetLastError();
+}
+
+hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
+                     HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride, uint32_t *d_compressed,
+                     size_t comp_stride_words)
+{
+    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    hipLaunchKernelGGL(k_huff_pack, dim3(nsub, nblk), dim3(256), 0, st, mtf, mtf_stride, n, s.codes, s.lens,
+                       d_offsets, offset_stride, d_compressed, comp_stride_words, (uint64_t)comp_stride_words);
+    return hipGetLastError();
+}
+
+} // namespace glc

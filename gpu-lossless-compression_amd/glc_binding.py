@@ -1,0 +1,233 @@
+"""ctypes binding of libglc_amd.so -- the host-side mirror, in Python, of what a
+C caller of include/cudpp.h / include/culzss.h does.  Device memory comes from
+torch (plumbing only): every call passes raw device pointers and sizes.
+
+There is no CPU fallback: if the library is missing or a call fails, this
+raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libglc_amd.so")
+
+# enum values of include/cudpp.h (identical to the reference header)
+CUDPP_SUCCESS = 0
+CUDPP_ERROR_INVALID_HANDLE = 1
+CUDPP_ERROR_ILLEGAL_CONFIGURATION = 2
+CUDPP_ERROR_INVALID_PLAN = 3
+CUDPP_ERROR_INSUFFICIENT_RESOURCES = 4
+CUDPP_ERROR_UNKNOWN = 9999
+CUDPP_UCHAR = 1
+CUDPP_UINT = 5
+CUDPP_ADD = 0
+CUDPP_SCAN = 0
+CUDPP_COMPRESS = 10
+CUDPP_BWT = 12
+CUDPP_MTF = 13
+CUDPP_SA = 14
+CUDPP_INVALID_HANDLE = 0xC0DABAD1
+CUDPP_OPTION_FORWARD = 0x1
+CUDPP_OPTION_BACKWARD = 0x2
+
+HUFF_BLOCK = 4096
+HUFF_MAX_WORDS = 1536
+
+CUDPP_SYMBOLS = [
+    "cudppCreate", "cudppDestroy", "cudppPlan", "cudppDestroyPlan", "cudppCompress",
+    "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
+    "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
+    "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming",
+]
+CULZSS_SYMBOLS = [
+    "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
+    "onestream_finish_GPU", "initGPUmem", "initCPUmem", "deleteGPUmem", "deleteCPUmem", "initGPU",
+    "resetGPU", "streams_in_GPU", "deleteGPUStreams", "signalExitThreads", "deinitGPUmem",
+    "dedeleteGPUmem", "deinitGPU", "culzss_compress", "culzss_decompress",
+    "glcLzssEncodeDevice", "glcLzssDecodeDevice", "glcLzssLastKernelMs",
+]
+
+
+class CUDPPConfiguration(C.Structure):
+    _fields_ = [("algorithm", C.c_int), ("op", C.c_int), ("datatype", C.c_int),
+                ("options", C.c_uint), ("bucket_mapper", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libglc_amd.so is not built: run `python __graft_entry__.py` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u = C.c_void_p, C.c_size_t, C.c_uint
+    L.cudppCreate.argtypes = [C.POINTER(sz)]
+    L.cudppDestroy.argtypes = [sz]
+    L.cudppPlan.argtypes = [sz, C.POINTER(sz), CUDPPConfiguration, sz, sz, sz]
+    L.cudppDestroyPlan.argtypes = [sz]
+    L.cudppCompress.argtypes = [sz, vp, vp, vp, vp, vp, vp, vp, sz]
+    L.cudppBurrowsWheelerTransform.argtypes = [sz, vp, vp, vp, sz]
+    L.cudppMoveToFrontTransform.argtypes = [sz, vp, vp, sz]
+    L.cudppSuffixArray.argtypes = [sz, vp, vp, sz]
+    L.glcCompressBatch.argtypes = [sz, vp, vp, vp, vp, sz, vp, vp, sz, sz, sz]
+    L.glcBwtBatch.argtypes = [sz, vp, vp, vp, sz, sz]
+    L.glcMtfBatch.argtypes = [sz, vp, vp, sz, sz]
+    L.glcDecompressBatch.argtypes = [sz, vp, vp, vp, sz, vp, sz, vp, sz, sz]
+    L.glcPlanSetStream.argtypes = [sz, vp]
+    L.glcPlanSynchronize.argtypes = [sz]
+    L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
+    L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
+    for name in CUDPP_SYMBOLS:
+        getattr(L, name).restype = C.c_int
+    # CULZSS
+    if hasattr(L, "compression_kernel_wrapper"):
+        L.compression_kernel_wrapper.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, vp, vp]
+        L.compression_kernel_wrapper.restype = C.c_int
+        L.aftercompression_wrapper.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int)]
+        L.aftercompression_wrapper.restype = C.c_int
+        L.decompression_kernel_wrapper.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
+        L.decompression_kernel_wrapper.restype = C.c_int
+        L.onestream_finish_GPU.argtypes = [C.c_int]
+        L.onestream_finish_GPU.restype = C.c_int
+        for nm in ("initGPUmem", "initCPUmem", "deinitGPUmem"):
+            getattr(L, nm).argtypes = [C.c_int]
+            getattr(L, nm).restype = vp
+        for nm in ("deleteGPUmem", "deleteCPUmem", "dedeleteGPUmem"):
+            getattr(L, nm).argtypes = [vp]
+            getattr(L, nm).restype = None
+        for nm in ("initGPU", "resetGPU", "deleteGPUStreams", "signalExitThreads", "deinitGPU"):
+            getattr(L, nm).argtypes = []
+            getattr(L, nm).restype = None
+        L.streams_in_GPU.restype = C.c_int
+        L.culzss_compress.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int)]
+        L.culzss_compress.restype = C.c_int
+        L.culzss_decompress.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int)]
+        L.culzss_decompress.restype = C.c_int
+        L.glcLzssEncodeDevice.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        L.glcLzssEncodeDevice.restype = C.c_int
+        L.glcLzssDecodeDevice.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+        L.glcLzssDecodeDevice.restype = C.c_int
+        L.glcLzssLastKernelMs.argtypes = []
+        L.glcLzssLastKernelMs.restype = C.c_float
+    _lib = L
+    return L
+
+
+class CudppError(RuntimeError):
+    def __init__(self, fn, code):
+        super().__init__("%s returned CUDPPResult %d" % (fn, code))
+        self.code = code
+
+
+def _chk(fn, code):
+    if code != CUDPP_SUCCESS:
+        raise CudppError(fn, code)
+
+
+def config(algorithm, datatype=CUDPP_UCHAR, options=0, op=CUDPP_ADD):
+    return CUDPPConfiguration(algorithm, op, datatype, options, 0)
+
+
+class Cudpp:
+    """cudppCreate/cudppDestroy pair."""
+
+    def __init__(self):
+        h = C.c_size_t(0)
+        _chk("cudppCreate", lib().cudppCreate(C.byref(h)))
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            lib().cudppDestroy(self.handle)
+            self.handle = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Plan:
+    """cudppPlan/cudppDestroyPlan pair (rows = blocks per batched call)."""
+
+    def __init__(self, cudpp, algorithm, n, rows=1, datatype=CUDPP_UCHAR, options=0):
+        self.algorithm, self.n, self.rows = algorithm, n, rows
+        h = C.c_size_t(0)
+        rc = lib().cudppPlan(cudpp.handle, C.byref(h), config(algorithm, datatype, options), n, rows, 0)
+        _chk("cudppPlan", rc)
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            lib().cudppDestroyPlan(self.handle)
+            self.handle = 0
+
+    def set_stream(self, stream_ptr):
+        _chk("glcPlanSetStream", lib().glcPlanSetStream(self.handle, stream_ptr))
+
+    def synchronize(self):
+        _chk("glcPlanSynchronize", lib().glcPlanSynchronize(self.handle))
+
+    def enable_timing(self, on=True):
+        _chk("glcPlanEnableTiming", lib().glcPlanEnableTiming(self.handle, 1 if on else 0))
+
+    def last_timing(self):
+        a = (C.c_float * 4)()
+        _chk("glcPlanLastTiming", lib().glcPlanLastTiming(self.handle, a))
+        return list(a)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def compressed_stride_words(n):
+    return (HUFF_MAX_WORDS + 1) * ((n + HUFF_BLOCK - 1) // HUFF_BLOCK)
+
+
+# ---------------------------------------------------------------------------
+# torch-tensor conveniences (device pointers in, device tensors out)
+# ---------------------------------------------------------------------------
+def compress_batch(plan, d_in, n, nblk):
+    """d_in: uint8 cuda tensor of nblk*n bytes.  Returns dict of cuda tensors."""
+    import torch
+    dev = d_in.device
+    nsub = (n + HUFF_BLOCK - 1) // HUFF_BLOCK
+    stride = compressed_stride_words(n)
+    out = dict(
+        bwt_index=torch.empty(nblk, dtype=torch.int32, device=dev),
+        hist=torch.empty(nblk * 256, dtype=torch.int32, device=dev),
+        offsets=torch.empty(nblk * nsub, dtype=torch.int32, device=dev),
+        size=torch.empty(nblk, dtype=torch.int32, device=dev),
+        words=torch.empty(nblk * stride, dtype=torch.int32, device=dev),
+        stride=stride, nsub=nsub,
+    )
+    rc = lib().glcCompressBatch(plan.handle, d_in.data_ptr(), out["bwt_index"].data_ptr(),
+                                out["hist"].data_ptr(), out["offsets"].data_ptr(), nsub,
+                                out["size"].data_ptr(), out["words"].data_ptr(), stride, n, nblk)
+    _chk("glcCompressBatch", rc)
+    return out
+
+
+def compress_batch_into(plan, d_in, n, nblk, out):
+    rc = lib().glcCompressBatch(plan.handle, d_in.data_ptr(), out["bwt_index"].data_ptr(),
+                                out["hist"].data_ptr(), out["offsets"].data_ptr(), out["nsub"],
+                                out["size"].data_ptr(), out["words"].data_ptr(), out["stride"], n, nblk)
+    _chk("glcCompressBatch", rc)
+
+
+def decompress_batch(plan, comp, n, nblk):
+    import torch
+    d_out = torch.empty(nblk * n, dtype=torch.uint8, device=comp["words"].device)
+    rc = lib().glcDecompressBatch(plan.handle, comp["bwt_index"].data_ptr(), comp["hist"].data_ptr(),
+                                  comp["offsets"].data_ptr(), comp["nsub"], comp["words"].data_ptr(),
+                                  comp["stride"], d_out.data_ptr(), n, nblk)
+    _chk("glcDecompressBatch", rc)
+    return d_out

@@ -1,0 +1,196 @@
+/*
+ * cudpp.h -- C ABI of the MI355X-native cudppCompress path.
+ *
+ * Drop-in for the subset of the reference's public header
+ * (cudpp-inpar/include/cudpp.h) that is on the compression hot path:
+ *
+ *   cudppCreate / cudppDestroy                 cudpp.h:199-205, cudpp_manager.cpp:40-63
+ *   cudppPlan / cudppDestroyPlan               cudpp.h:209-217, cudpp_plan.cpp:81-292
+ *   cudppCompress                              cudpp.h:327-335, cudpp.cpp:764-806
+ *   cudppBurrowsWheelerTransform               cudpp.h:339-343, cudpp.cpp:829-864
+ *   cudppMoveToFrontTransform                  cudpp.h:347-350, cudpp.cpp:886-919
+ *   cudppSuffixArray                           cudpp.h:363-366, cudpp.cpp:1000-1034
+ *
+ * Enumerator VALUES, the CUDPPConfiguration layout, CUDPPHandle = size_t and
+ * CUDPP_INVALID_HANDLE are identical to the reference, so a caller compiled
+ * against the reference header links against this library unchanged.  All data
+ * pointers are DEVICE pointers (HIP) owned by the caller; a plan owns its
+ * scratch.  Algorithms the reference header lists but that are not on this
+ * path (scan, sort, rand, ...) keep their enumerators (values matter) but
+ * cudppPlan() answers CUDPP_ERROR_ILLEGAL_CONFIGURATION for them.
+ *
+ * Extensions (new, prefixed glc): batched entry points that run `rows`
+ * independent blocks per call -- see the end of this file.
+ */
+#ifndef GLC_CUDPP_H
+#define GLC_CUDPP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* result codes -- values as reference cudpp.h:32-49 */
+enum CUDPPResult
+{
+    CUDPP_SUCCESS = 0,
+    CUDPP_ERROR_INVALID_HANDLE,
+    CUDPP_ERROR_ILLEGAL_CONFIGURATION,
+    CUDPP_ERROR_INVALID_PLAN,
+    CUDPP_ERROR_INSUFFICIENT_RESOURCES,
+    CUDPP_ERROR_UNKNOWN = 9999
+};
+
+/* option bits -- reference cudpp.h:62-84 */
+enum CUDPPOption
+{
+    CUDPP_OPTION_FORWARD         = 0x1,
+    CUDPP_OPTION_BACKWARD        = 0x2,
+    CUDPP_OPTION_EXCLUSIVE       = 0x4,
+    CUDPP_OPTION_INCLUSIVE       = 0x8,
+    CUDPP_OPTION_CTA_LOCAL       = 0x10,
+    CUDPP_OPTION_KEYS_ONLY       = 0x20,
+    CUDPP_OPTION_KEY_VALUE_PAIRS = 0x40
+};
+
+/* datatypes -- reference cudpp.h:90-103 (CUDPP_UCHAR == 1) */
+enum CUDPPDatatype
+{
+    CUDPP_CHAR, CUDPP_UCHAR, CUDPP_SHORT, CUDPP_USHORT, CUDPP_INT, CUDPP_UINT,
+    CUDPP_FLOAT, CUDPP_DOUBLE, CUDPP_LONGLONG, CUDPP_ULONGLONG, CUDPP_DATATYPE_INVALID
+};
+
+/* operators -- reference cudpp.h:109-116 */
+enum CUDPPOperator
+{
+    CUDPP_ADD, CUDPP_MULTIPLY, CUDPP_MIN, CUDPP_MAX, CUDPP_OPERATOR_INVALID
+};
+
+/* algorithms -- reference cudpp.h:128-147 (COMPRESS=10, BWT=12, MTF=13, SA=14) */
+enum CUDPPAlgorithm
+{
+    CUDPP_SCAN, CUDPP_SEGMENTED_SCAN, CUDPP_COMPACT, CUDPP_REDUCE, CUDPP_SORT_RADIX,
+    CUDPP_SORT_MERGE, CUDPP_SORT_STRING, CUDPP_SPMVMULT, CUDPP_RAND_MD5, CUDPP_TRIDIAGONAL,
+    CUDPP_COMPRESS, CUDPP_LISTRANK, CUDPP_BWT, CUDPP_MTF, CUDPP_SA, CUDPP_MULTISPLIT,
+    CUDPP_ALGORITHM_INVALID
+};
+
+/* bucket mapper (multisplit only; kept for struct layout) -- cudpp.h:153-159 */
+enum CUDPPBucketMapper
+{
+    CUDPP_LSB_BUCKET_MAPPER, CUDPP_MSB_BUCKET_MAPPER, CUDPP_DEFAULT_BUCKET_MAPPER,
+    CUDPP_CUSTOM_BUCKET_MAPPER
+};
+
+/* plan configuration -- same five fields, same order: cudpp.h:171-178 */
+struct CUDPPConfiguration
+{
+    enum CUDPPAlgorithm    algorithm;
+    enum CUDPPOperator     op;
+    enum CUDPPDatatype     datatype;
+    unsigned int           options;
+    enum CUDPPBucketMapper bucket_mapper;
+};
+
+#ifndef __cplusplus
+typedef enum CUDPPResult CUDPPResult;
+typedef enum CUDPPOption CUDPPOption;
+typedef enum CUDPPDatatype CUDPPDatatype;
+typedef enum CUDPPOperator CUDPPOperator;
+typedef enum CUDPPAlgorithm CUDPPAlgorithm;
+typedef enum CUDPPBucketMapper CUDPPBucketMapper;
+typedef struct CUDPPConfiguration CUDPPConfiguration;
+#endif
+
+#define CUDPP_INVALID_HANDLE 0xC0DABAD1      /* cudpp.h:182 */
+typedef size_t CUDPPHandle;                   /* cudpp.h:183 */
+
+/* Library object.  One per host thread / device context by convention
+ * (cudpp_manager.cpp:30-34).  The device is whatever is current at the call. */
+CUDPPResult cudppCreate(CUDPPHandle *theCudpp);
+CUDPPResult cudppDestroy(CUDPPHandle theCudpp);
+
+/* Plan for `n` elements at most.  `rows` = how many independent blocks of up
+ * to n elements the plan can run per batched call (reference callers pass 1,
+ * test_compress.cpp:405); `rowPitch` is ignored as in the reference.
+ * Errors: ILLEGAL_CONFIGURATION (bad option combination, algorithm not on this
+ * path, n == 0 or n > 1048576 for COMPRESS/BWT), INSUFFICIENT_RESOURCES
+ * (device allocation failed), INVALID_HANDLE (library handle is 0). */
+CUDPPResult cudppPlan(const CUDPPHandle cudppHandle, CUDPPHandle *planHandle,
+                      CUDPPConfiguration config, size_t n, size_t rows, size_t rowPitch);
+CUDPPResult cudppDestroyPlan(CUDPPHandle plan);
+
+/* BWT -> MTF -> Huffman of one block (numElements <= plan n, <= 1 MiB).
+ *   d_bwtIndex[1], d_hist[256], d_encodeOffset[ceil(n/4096)] (256 at 1 MiB),
+ *   d_compressedSize[1] (words), d_compressed[>= (1536+1)*ceil(n/4096)] words,
+ *   d_histSize is ignored (may be NULL) exactly as in the reference.
+ * Stream layout: SURVEY.md App. A.  Errors: INVALID_HANDLE (plan 0),
+ * INVALID_PLAN (plan is not a COMPRESS plan), ILLEGAL_CONFIGURATION (datatype
+ * != UCHAR, numElements out of range), UNKNOWN (a HIP call failed; the
+ * reference exit()s instead, cuda_util.h:13-21). */
+CUDPPResult cudppCompress(CUDPPHandle planHandle, unsigned char *d_uncompressed,
+                          int *d_bwtIndex, unsigned int *d_histSize, unsigned int *d_hist,
+                          unsigned int *d_encodeOffset, unsigned int *d_compressedSize,
+                          unsigned int *d_compressed, size_t numElements);
+
+CUDPPResult cudppBurrowsWheelerTransform(CUDPPHandle planHandle, unsigned char *d_in,
+                                         unsigned char *d_out, int *d_index, size_t numElements);
+
+CUDPPResult cudppMoveToFrontTransform(CUDPPHandle planHandle, unsigned char *d_in,
+                                      unsigned char *d_out, size_t numElements);
+
+/* d_keys_sa must hold numElements+1 words; the suffix array (0-based, sentinel
+ * row dropped) is written at d_keys_sa[1..numElements] (test_sa.cpp:112-113,161);
+ * d_keys_sa[0] receives numElements (the position of the virtual sentinel). */
+CUDPPResult cudppSuffixArray(CUDPPHandle planHandle, unsigned char *d_str,
+                             unsigned int *d_keys_sa, size_t numElements);
+
+/* ------------------------------------------------------------------------ */
+/* Extensions (not in the reference): batched calls and stream control.     */
+/* A batched call runs `numBlocks` (<= plan rows) independent blocks of      */
+/* `numElements` each; block b reads d_uncompressed + b*numElements and      */
+/* writes d_bwtIndex[b], d_hist[b*256..], d_encodeOffset[b*offsetStride..],  */
+/* d_compressedSize[b], d_compressed + b*compressedStrideWords.  Each        */
+/* block's outputs are bit-identical to a single cudppCompress() call.       */
+/* ------------------------------------------------------------------------ */
+CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_uncompressed,
+                             int *d_bwtIndex, unsigned int *d_hist, unsigned int *d_encodeOffset,
+                             size_t offsetStride, unsigned int *d_compressedSize,
+                             unsigned int *d_compressed, size_t compressedStrideWords,
+                             size_t numElements, size_t numBlocks);
+
+CUDPPResult glcBwtBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsigned char *d_out,
+                        int *d_index, size_t numElements, size_t numBlocks);
+
+CUDPPResult glcMtfBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsigned char *d_out,
+                        size_t numElements, size_t numBlocks);
+
+/* Inverse of glcCompressBatch (the reference has no GPU decoder; semantics =
+ * the gold decoder of test_compress.cpp:192-311 with the sentinel-aware
+ * inverse BWT of SURVEY.md 8(f)1).  Plan must be a COMPRESS plan. */
+CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex,
+                               const unsigned int *d_hist, const unsigned int *d_encodeOffset,
+                               size_t offsetStride, const unsigned int *d_compressed,
+                               size_t compressedStrideWords, unsigned char *d_out,
+                               size_t numElements, size_t numBlocks);
+
+/* Run a plan's work on `hipStream` (a hipStream_t cast to void*; NULL = the
+ * default stream, which is what the reference uses). */
+CUDPPResult glcPlanSetStream(CUDPPHandle planHandle, void *hipStream);
+
+/* Blocks until everything queued by the plan has finished; returns
+ * CUDPP_ERROR_UNKNOWN if a kernel faulted or a block overflowed the 1536-word
+ * per-4096-symbol capacity of the reference format. */
+CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle);
+
+/* Per-stage device time of the plan's last batched compress, in milliseconds,
+ * measured with hipEvents on the plan's stream: [0]=BWT(suffix sort+gather),
+ * [1]=MTF, [2]=Huffman, [3]=total.  Enables timing when `enable` != 0. */
+CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable);
+CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLC_CUDPP_H */

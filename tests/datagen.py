@@ -1,0 +1,78 @@
+"""Seeded synthetic inputs shared by tests, smoke() and bench.py."""
+import numpy as np
+
+
+def zipf_bytes(n, seed=0x5eed0002, s=1.0):
+    """i.i.d. bytes, byte value = rank-th symbol of Zipf(s) over 256 symbols (config 2)."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    p = 1.0 / np.arange(1, 257) ** s
+    p /= p.sum()
+    cdf = np.cumsum(p)
+    u = rng.random(n)
+    return np.minimum(np.searchsorted(cdf, u), 255).astype(np.uint8)
+
+
+def float_bytes(n, seed=0x5eed0004):
+    """float32 ~ N(0,1) as little-endian bytes (config 4)."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    return rng.standard_normal((n + 3) // 4, dtype=np.float32).view(np.uint8)[:n].copy()
+
+
+_WORDS = None
+
+
+def text_bytes(n, seed=0x5eed0001):
+    """'enwik-style' text: order-1 word model over a fixed vocabulary with XML-ish tags (config 1)."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    global _WORDS
+    if _WORDS is None:
+        vr = np.random.Generator(np.random.Philox(key=12345))
+        letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+        lp = 1.0 / np.arange(1, 27)
+        lp /= lp.sum()
+        _WORDS = []
+        for _ in range(4096):
+            ln = int(vr.integers(2, 10))
+            _WORDS.append(bytes(vr.choice(letters, size=ln, p=lp)))
+    out = bytearray()
+    nw = len(_WORDS)
+    zp = 1.0 / np.arange(1, nw + 1)
+    zp /= zp.sum()
+    prev = 0
+    while len(out) < n:
+        picks = rng.choice(nw, size=4096, p=zp)
+        mix = rng.random(4096)
+        for k in range(4096):
+            w = (prev * 31 + 7) % nw if mix[k] < 0.35 else int(picks[k])   # order-1 dependence
+            prev = w
+            r = mix[k]
+            if r > 0.985:
+                out += b"<" + _WORDS[w] + b">"
+            elif r > 0.97:
+                out += b"</" + _WORDS[w] + b">\n"
+            elif r > 0.93:
+                out += _WORDS[w] + b". "
+            else:
+                out += _WORDS[w] + b" "
+        if len(out) >= n:
+            break
+    return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+
+
+def log_bytes(n, seed=0x5eed0003):
+    """log-style ASCII lines (config 3)."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    levels = [b"INFO", b"WARN", b"DEBUG", b"ERROR"]
+    svcs = [b"auth", b"db", b"cache", b"api", b"queue", b"sched"]
+    msgs = [b"request completed", b"connection reset by peer", b"cache miss for key", b"retrying operation",
+            b"user login ok", b"slow query detected", b"heartbeat", b"flushed buffers"]
+    out = bytearray()
+    t = 0
+    while len(out) < n:
+        r = rng.integers(0, 1 << 30, size=8)
+        t += int(r[0] % 997)
+        ms = t % 1000; s = (t // 1000) % 60; mi = (t // 60000) % 60; h = (t // 3600000) % 24
+        out += b"2026-09-%02dT%02d:%02d:%02d.%03dZ host-%02d svc-%s[%d]: %s %s k=%d v=%d\n" % (
+            1 + (t // 86400000) % 28, h, mi, s, ms, r[1] % 16, svcs[r[2] % 6], r[3] % 32768,
+            levels[r[4] % 4], msgs[r[5] % 8], r[6] % 1000, r[7] % 100000)
+    return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
