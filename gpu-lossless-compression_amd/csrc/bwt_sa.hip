@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512) void k_sa_aggscan(uint2 *__restrict__ tile_agg
     if (t < ntiles) tile_agg[(size_t)b * max_tiles + t] = make_uint2(carry, off);
     if (t == 0) {
         cnt_next[b] = total;
-        if (total) atomicMax(d_max_cnt, total);
+        if (total) { atomicMax(d_max_cnt, total); atomicAdd(d_max_cnt + 1, total); }
     }
 }
 
@@ -400,8 +400,8 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.tile_agg, (size_t)rows * s.max_tiles * sizeof(uint2)));
     GLC_TRY(A((void **)&s.cntA, (size_t)rows * 4)); GLC_TRY(A((void **)&s.cntB, (size_t)rows * 4));
-    GLC_TRY(A((void **)&s.d_max_cnt, 4));
-    GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 4, hipHostMallocDefault));
+    GLC_TRY(A((void **)&s.d_max_cnt, 8));
+    GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 8, hipHostMallocDefault));
     s.bytes = total;
     return hipSuccess;
 }
@@ -412,20 +412,44 @@ void sa_scratch_free(SaScratch &s)
                   s.cntA, s.cntB, s.d_max_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
+    for (auto &e : s.prof_ev) if (e) (void)hipEventDestroy(e);
     s = SaScratch();
+}
+
+// fold the finished event pairs into the running profile (stream must be idle)
+static void prof_collect(SaScratch &s)
+{
+    for (int i = 0; i < s.prof_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.prof_ev[2 * i], s.prof_ev[2 * i + 1]) == hipSuccess) {
+            s.prof_ms += ms; s.prof_launches++; s.prof_bytes += 16.0 * s.prof_live[i];
+        }
+    }
+    s.prof_used = 0;
 }
 
 template <int BITS>
 static hipError_t radix_pass(hipStream_t st, const uint64_t *in, uint64_t *out, const uint32_t *cnt,
-                             uint32_t nfixed, uint32_t shift, uint32_t tiles, uint32_t nblk, SaScratch &s)
+                             uint32_t nfixed, uint32_t shift, uint32_t tiles, uint32_t nblk, SaScratch &s,
+                             double live_total)
 {
     dim3 g(tiles, nblk);
+    const bool prof = s.prof && BITS == 8 && s.prof_used < 64;
+    if (prof) {
+        for (int k = 0; k < 2; k++)
+            if (!s.prof_ev[2 * s.prof_used + k]) GLC_TRY(hipEventCreate(&s.prof_ev[2 * s.prof_used + k]));
+    }
     hipLaunchKernelGGL(k_rs_hist<BITS>, g, dim3(SA_THREADS), 0, st, in, cnt, nfixed, shift, s.tile_hist,
                        s.nmax, s.max_tiles);
     hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(nblk), dim3(512), 0, st, s.tile_hist, cnt, nfixed,
                        s.digit_base, s.max_tiles);
+    if (prof) (void)hipEventRecord(s.prof_ev[2 * s.prof_used], st);
     hipLaunchKernelGGL(k_rs_scatter<BITS>, g, dim3(SA_THREADS), 0, st, in, out, cnt, nfixed, shift,
                        s.tile_hist, s.digit_base, s.nmax, s.max_tiles);
+    if (prof) {
+        (void)hipEventRecord(s.prof_ev[2 * s.prof_used + 1], st);
+        s.prof_live[s.prof_used++] = live_total;
+    }
     return hipGetLastError();
 }
 
@@ -435,14 +459,15 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     if (n == 0 || n > s.nmax || n > MAX_BLOCK_ELEMS || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     uint32_t tiles = (n + SA_TILE - 1) / SA_TILE;
     uint64_t *cur = s.keyA, *alt = s.keyB;
+    double live_total = (double)n * nblk;
     hipLaunchKernelGGL(k_sa_init_keys, dim3(tiles, nblk), dim3(SA_THREADS), 0, st, text, text_stride, n, cur,
                        s.nmax);
     // 41 key bits at [20, 61): 8+8+8+8+9
     for (int p = 0; p < 4; p++) {
-        GLC_TRY(radix_pass<8>(st, cur, alt, nullptr, n, VAL_BITS + 8 * p, tiles, nblk, s));
+        GLC_TRY(radix_pass<8>(st, cur, alt, nullptr, n, VAL_BITS + 8 * p, tiles, nblk, s, live_total));
         uint64_t *x = cur; cur = alt; alt = x;
     }
-    GLC_TRY(radix_pass<9>(st, cur, alt, nullptr, n, VAL_BITS + 32, tiles, nblk, s));
+    GLC_TRY(radix_pass<9>(st, cur, alt, nullptr, n, VAL_BITS + 32, tiles, nblk, s, live_total));
     { uint64_t *x = cur; cur = alt; alt = x; }
 
     uint32_t *cnt_cur = nullptr, *cnt_next = s.cntA, *cnt_spare = s.cntB;
@@ -451,7 +476,7 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     int rounds = 0;
     for (;;) {
         dim3 g(tiles, nblk);
-        GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 4, st));
+        GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 8, st));
         hipLaunchKernelGGL(k_sa_rank<false>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
                            s.tile_agg, s.isa, s.sa, alt, pos_next, s.nmax, s.max_tiles);
         hipLaunchKernelGGL(k_sa_aggscan, dim3(nblk), dim3(512), 0, st, s.tile_agg, cnt_cur, live, cnt_next,
@@ -459,10 +484,12 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         hipLaunchKernelGGL(k_sa_rank<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
                            s.tile_agg, s.isa, s.sa, alt, pos_next, s.nmax, s.max_tiles);
         GLC_TRY(hipGetLastError());
-        GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 4, hipMemcpyDeviceToHost, st));
+        GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 8, hipMemcpyDeviceToHost, st));
         GLC_TRY(hipStreamSynchronize(st));
+        if (s.prof) prof_collect(s);
         rounds++;
-        const uint32_t maxc = *s.h_max_cnt;
+        const uint32_t maxc = s.h_max_cnt[0];
+        live_total = (double)s.h_max_cnt[1];
         if (maxc == 0) break;
         if (h >= 2u * n + 10u) return hipErrorUnknown;           // cannot happen: h >= n resolves everything
         // next round works on the compacted list that k_sa_rank<true> wrote into `alt`
@@ -478,11 +505,11 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                            s.isa, n, h, s.nmax);
         // 42 key bits at [20, 62): 8+8+8+9+9
         for (int p = 0; p < 3; p++) {
-            GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 * p, tiles, nblk, s));
+            GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 * p, tiles, nblk, s, live_total));
             uint64_t *x = cur; cur = alt; alt = x;
         }
         for (int p = 0; p < 2; p++) {
-            GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 24 + 9 * p, tiles, nblk, s));
+            GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 24 + 9 * p, tiles, nblk, s, live_total));
             uint64_t *x = cur; cur = alt; alt = x;
         }
         h *= 2;

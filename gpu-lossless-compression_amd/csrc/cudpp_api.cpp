@@ -353,13 +353,50 @@ CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle)
     return *p->h_status ? CUDPP_ERROR_UNKNOWN : CUDPP_SUCCESS;
 }
 
+static SaScratch *sa_of(PlanBase *p)
+{
+    switch (p->config.algorithm) {
+    case CUDPP_COMPRESS: return &static_cast<CompressPlan *>(p)->sa;
+    case CUDPP_BWT: return &static_cast<BwtPlan *>(p)->sa;
+    case CUDPP_SA: return &static_cast<SaPlan *>(p)->sa;
+    default: return nullptr;
+    }
+}
+
 CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     p->timing = enable != 0;
     p->ev_valid = false;
+    if (SaScratch *s = sa_of(p)) {
+        s->prof = (enable & 2) != 0;
+        s->prof_ms = 0; s->prof_bytes = 0; s->prof_launches = 0; s->prof_used = 0;
+    }
     return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out3) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    out3[0] = s->prof_ms; out3[1] = (double)s->prof_launches; out3[2] = s->prof_bytes;
+    s->prof_ms = 0; s->prof_bytes = 0; s->prof_launches = 0;
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcCompactStreams(CUDPPHandle planHandle, const unsigned int *d_compressed,
+                              size_t compressedStrideWords, const unsigned int *d_compressedSize,
+                              size_t numBlocks, unsigned int *d_out, unsigned long long *d_outOffsets)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (!d_compressed || !d_compressedSize || !d_out || !d_outOffsets || numBlocks == 0)
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    return hip_result(compact_streams(p->stream, d_compressed, compressedStrideWords, d_compressedSize,
+                                      (uint32_t)numBlocks, d_out, d_outOffsets));
 }
 
 CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4)

@@ -30,9 +30,17 @@ struct SaScratch {
     uint32_t *digit_base = nullptr;              // [rows][512]
     uint2    *tile_agg = nullptr;                // [rows][max_tiles]
     uint32_t *cntA = nullptr, *cntB = nullptr;   // [rows] unresolved counts
-    uint32_t *d_max_cnt = nullptr;               // [1]
-    uint32_t *h_max_cnt = nullptr;               // pinned [1]
+    uint32_t *d_max_cnt = nullptr;               // [2] max and sum of the unresolved counts
+    uint32_t *h_max_cnt = nullptr;               // pinned [2]
     size_t    bytes = 0;
+    // optional live profile of the dominant kernel (k_rs_scatter<8>): HIP events on
+    // the launch stream around every launch, accumulated across sa_build calls
+    bool       prof = false;
+    hipEvent_t prof_ev[128] = {};
+    int        prof_used = 0;
+    double     prof_live[64] = {};               // live suffixes of the launch bracketed by event pair i
+    double     prof_ms = 0, prof_bytes = 0;
+    long       prof_launches = 0;
 };
 
 hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows);
@@ -89,6 +97,9 @@ hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s,
 hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
                      HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride,
                      uint32_t *d_compressed, size_t comp_stride_words);
+
+hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride, const uint32_t *d_sizes,
+                           uint32_t nblk, uint32_t *d_out, unsigned long long *d_off);
 
 // ---------------------------------------------------------------------------
 // decoder (round-trip parity only; the reference has no GPU decoder)

@@ -256,6 +256,51 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
 }
 
 // ---------------------------------------------------------------------------
+// stream compaction for result collection: block b's words move from the strided
+// layout to out[off[b] .. off[b]+size[b]); off has nblk+1 entries (last = total).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_compact_offsets(const uint32_t *__restrict__ sizes, uint32_t nblk,
+                                                          unsigned long long *__restrict__ off)
+{
+    __shared__ uint32_t s_tmp[20];
+    __shared__ unsigned long long s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t sz = i < nblk ? sizes[i] : 0;
+        uint32_t tot = 0;
+        const uint32_t ex = block_excl_add<1024>(sz, s_tmp, &tot);
+        const unsigned long long run = s_run;
+        if (i < nblk) off[i] = run + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nblk] = s_run;
+}
+
+__global__ __launch_bounds__(256) void k_compact_copy(const uint32_t *__restrict__ comp, size_t stride,
+                                                      const uint32_t *__restrict__ sizes,
+                                                      const unsigned long long *__restrict__ off,
+                                                      uint32_t *__restrict__ out)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t sz = sizes[b];
+    const uint32_t *src = comp + (size_t)b * stride;
+    uint32_t *dst = out + off[b];
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < sz; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride, const uint32_t *d_sizes,
+                           uint32_t nblk, uint32_t *d_out, unsigned long long *d_off)
+{
+    hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, d_sizes, nblk, d_off);
+    hipLaunchKernelGGL(k_compact_copy, dim3(32, nblk), dim3(256), 0, st, d_comp, stride, d_sizes, d_off, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 #define GLC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t huff_scratch_alloc(HuffScratch &s, uint32_t nmax, uint32_t rows)

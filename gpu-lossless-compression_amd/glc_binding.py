@@ -36,14 +36,16 @@ CUDPP_SYMBOLS = [
     "cudppCreate", "cudppDestroy", "cudppPlan", "cudppDestroyPlan", "cudppCompress",
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
-    "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming",
+    "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
+    "glcCompactStreams",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
     "onestream_finish_GPU", "initGPUmem", "initCPUmem", "deleteGPUmem", "deleteCPUmem", "initGPU",
     "resetGPU", "streams_in_GPU", "deleteGPUStreams", "signalExitThreads", "deinitGPUmem",
     "dedeleteGPUmem", "deinitGPU", "culzss_compress", "culzss_decompress",
-    "glcLzssEncodeDevice", "glcLzssDecodeDevice", "glcLzssLastKernelMs",
+    "glcLzssEncodeDevice", "glcLzssDecodeDevice", "glcLzssLastKernelMs", "glcLzssPackStride",
+    "glcLzssWorkBytes",
 ]
 
 
@@ -80,6 +82,8 @@ def lib():
     L.glcPlanSynchronize.argtypes = [sz]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
     L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
+    L.glcPlanKernelProfile.argtypes = [sz, C.POINTER(C.c_double)]
+    L.glcCompactStreams.argtypes = [sz, vp, sz, vp, sz, vp, vp]
     for name in CUDPP_SYMBOLS:
         getattr(L, name).restype = C.c_int
     # CULZSS
@@ -111,6 +115,10 @@ def lib():
         L.glcLzssEncodeDevice.restype = C.c_int
         L.glcLzssDecodeDevice.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.glcLzssDecodeDevice.restype = C.c_int
+        L.glcLzssPackStride.argtypes = [C.c_int]
+        L.glcLzssPackStride.restype = C.c_ulonglong
+        L.glcLzssWorkBytes.argtypes = [C.c_int, C.c_int]
+        L.glcLzssWorkBytes.restype = C.c_ulonglong
         L.glcLzssLastKernelMs.argtypes = []
         L.glcLzssLastKernelMs.restype = C.c_float
     _lib = L
@@ -173,8 +181,14 @@ class Plan:
     def synchronize(self):
         _chk("glcPlanSynchronize", lib().glcPlanSynchronize(self.handle))
 
-    def enable_timing(self, on=True):
-        _chk("glcPlanEnableTiming", lib().glcPlanEnableTiming(self.handle, 1 if on else 0))
+    def enable_timing(self, mode=1):
+        """0 off, 1 stage events, 3 stage events + dominant-kernel events"""
+        _chk("glcPlanEnableTiming", lib().glcPlanEnableTiming(self.handle, int(mode)))
+
+    def kernel_profile(self):
+        a = (C.c_double * 3)()
+        _chk("glcPlanKernelProfile", lib().glcPlanKernelProfile(self.handle, a))
+        return dict(ms=a[0], launches=int(a[1]), bytes=a[2])
 
     def last_timing(self):
         a = (C.c_float * 4)()

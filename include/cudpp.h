@@ -190,6 +190,20 @@ CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle);
 CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable);
 CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4);
 
+/* With glcPlanEnableTiming(plan, 3) the suffix sorter also brackets every launch
+ * of its dominant kernel (the 8-bit stable radix scatter) with hipEvents on the
+ * plan's stream.  out3 = {sum of launch durations in ms, number of launches,
+ * algorithmic bytes moved by those launches (8 B read + 8 B written per live
+ * suffix)}; reading resets the accumulators. */
+CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3);
+
+/* Result collection: packs the strided per-block streams of a batched compress
+ * back to back.  d_outOffsets has numBlocks+1 entries (word offsets; the last is
+ * the total).  d_out must hold sum(d_compressedSize) words. */
+CUDPPResult glcCompactStreams(CUDPPHandle planHandle, const unsigned int *d_compressed,
+                              size_t compressedStrideWords, const unsigned int *d_compressedSize,
+                              size_t numBlocks, unsigned int *d_out, unsigned long long *d_outOffsets);
+
 #ifdef __cplusplus
 }
 #endif
