@@ -64,6 +64,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libglc_amd.so is not built: run `python __graft_entry__.py` "
                            "(there is no CPU fallback)")
+    # torch bundles its own libamdhip64.so.7 (ROCm 7.0) while the library links the
+    # system one (ROCm 7.2) under the same soname: whichever is loaded first serves
+    # both.  A process that uses torch for device memory must load torch's first,
+    # or the two HIP runtimes disagree (hipGetDevice fails).  Pure C callers have
+    # no torch and are unaffected.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u = C.c_void_p, C.c_size_t, C.c_uint
     L.cudppCreate.argtypes = [C.POINTER(sz)]
