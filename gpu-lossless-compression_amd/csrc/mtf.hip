@@ -141,21 +141,21 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
             const uint32_t hzl = __builtin_amdgcn_readlane(hz, L);
             const uint32_t bidx = (uint32_t)__builtin_ctz(hzl) >> 3;          // byte within that lane
             const uint32_t pos = 4 * L + bidx;
-            if (l == j) outb = pos;
-            if (WITH_HIST) { if (l == 0) s_hist[w][pos] += 1; }
-            if (pos != 0) {
-                // entries [0, pos) move up by one, x goes to the front
-                uint32_t carry = __shfl_up(v >> 24, 1, 64);
-                if (l == 0) carry = x;
-                const uint32_t shifted = (v << 8) | carry;
-                if (l < L) v = shifted;
-                else if (l == L) {
-                    const uint32_t m2 = (bidx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (bidx + 1))) - 1u);
-                    v = (v & ~m2) | (shifted & m2);
-                }
-            }
+            outb = (l == j) ? pos : outb;
+            // entries [0, pos) move up by one, x goes to the front.  Branch-free: for
+            // pos == 0 the masked merge rewrites byte 0 of lane 0 with x itself.
+            // carry-in = top byte of the previous lane (DPP wave_shr:1, a VALU op -- no LDS
+            // round trip on the per-byte critical path); lane 0 keeps `old` = x.
+            const uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)(v >> 24), 0x138, 0xf, 0xf, false);
+            const uint32_t shifted = (v << 8) | carry;
+            const uint32_t m2 = (bidx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (bidx + 1))) - 1u);   // uniform
+            const uint32_t mask = (l < L) ? 0xFFFFFFFFu : ((l == L) ? m2 : 0u);
+            v = (v & ~mask) | (shifted & mask);
         }
-        if (p0 + l < hi) dst[p0 + l] = (uint8_t)outb;
+        if (p0 + l < hi) {
+            dst[p0 + l] = (uint8_t)outb;
+            if (WITH_HIST) atomicAdd(&s_hist[w][outb], 1u);     // once per 64 bytes, off the serial chain
+        }
     }
     if (WITH_HIST) {
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,239 @@
+"""CPU suite (-m "not gpu"): pins the oracle to the committed golden vectors that
+came from the reference's own gold routine, checks the domain's size-independent
+properties on the oracle, and checks the C-ABI library without touching a GPU."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import datagen
+import oracle_lib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def small():
+    return np.load(os.path.join(GOLD, "ref_gold_small.npz"))
+
+
+@pytest.fixture(scope="module")
+def kats():
+    return np.load(os.path.join(GOLD, "stream_kats.npz"))
+
+
+# ---------------------------------------------------------------- golden ----
+@pytest.mark.parametrize("n", [39, 128, 256, 512, 513, 1000, 1024, 1025, 32768, 45537, 65536])
+def test_suffix_array_matches_reference_gold(small, n):
+    assert np.array_equal(O.suffix_array(small["sa_in_%d" % n]), small["sa_out_%d" % n])
+
+
+@pytest.mark.parametrize("n", [39, 128, 1000, 1025, 45537, 65536])
+def test_bwt_and_mtf_match_reference_gold(small, n):
+    x = small["bwt_in_%d" % n]
+    b, idx = O.bwt(x)
+    assert idx == int(small["bwt_idx_%d" % n][0])
+    assert np.array_equal(b, small["bwt_out_%d" % n])
+    assert np.array_equal(O.mtf(x), small["mtf_of_in_%d" % n])
+
+
+def test_textbook_strings(small):
+    for name, s in (("mississippi", b"mississippi"), ("banana", b"banana")):
+        assert np.array_equal(O.suffix_array(s), small["str_%s_sa" % name])
+        b, idx = O.bwt(s)
+        assert np.array_equal(b, small["str_%s_bwt" % name]) and idx == int(small["str_%s_idx" % name][0])
+    assert bytes(O.bwt(b"mississippi")[0]) == b"pssmipissii"
+
+
+def test_reference_1m_vectors_known_answers():
+    """reference gold on the reference's own 1 MiB test inputs"""
+    j = json.load(open(os.path.join(GOLD, "ref_gold_1m.json")))
+    x = O.glibc_rand_bytes(1 << 20, 255)
+    assert "%08x" % O.crc32(x) == j["bwtTest"]["crc_in"] == "e8f0a761"
+    b, idx = O.bwt(x)
+    assert idx == j["bwtTest"]["bwt_index"] == 296638
+    assert "%08x" % O.crc32(b) == j["bwtTest"]["crc_bwt"] == "bd22be99"
+    assert "%08x" % O.crc32(O.mtf(b)) == j["bwtTest"]["crc_mtf"] == "1c647b66"
+    assert "%08x" % O.crc32(O.suffix_array(x).view(np.uint8)) == j["bwtTest"]["crc_sa"]
+    x[-1] = 0
+    r = O.compress(x)
+    s = j["compressTest_stream_restatement"]
+    assert r["bwt_index"] == j["compressTest"]["bwt_index"]
+    assert r["size"] == s["size_words"] == 262491
+    assert "%08x" % O.crc32(r["words"].view(np.uint8)) == s["crc_words"]
+    assert "%08x" % O.crc32(r["offsets"].view(np.uint8)) == s["crc_offsets"]
+    assert "%08x" % O.crc32(r["hist"].view(np.uint8)) == s["crc_hist"]
+    # gold decoder semantics (test_compress.cpp:240-311) give the input back
+    assert np.array_equal(O.decompress(r["bwt_index"], r["hist"], r["offsets"], r["words"], x.size), x)
+
+
+@pytest.mark.skipif(not O.have_ref_gold(), reason="oracle/_ref not built (no /root/reference on this box)")
+def test_oracle_vs_live_reference_gold():
+    for n, mod in ((1 << 20, 255), (500001, 128), (1048577, 255)):
+        x = O.glibc_rand_bytes(n, mod)
+        assert np.array_equal(O.suffix_array(x), O.ref_sa_gold(x))
+
+
+def test_stream_kats_do_not_drift(kats):
+    r = O.compress(kats["huff_in"])
+    assert r["bwt_index"] == int(kats["huff_idx"][0])
+    assert np.array_equal(r["words"], kats["huff_words"]) and np.array_equal(r["offsets"], kats["huff_offsets"])
+    assert np.array_equal(r["hist"], kats["huff_hist"])
+    c = O.lzss_candidates(kats["lz_in"])
+    assert np.array_equal(c, kats["lz_cand"])
+    assert np.array_equal(O.lzss_pack(c, kats["lz_in"].size), kats["lz_packed"])
+
+
+# ------------------------------------------------------------ properties ----
+def _naive_sa(x):
+    b = bytes(x)        # symbols are byte+1, the sentinel 0 ends every suffix (sa_kernel.cuh:55-58)
+    return np.array(sorted(range(len(b)), key=lambda i: [c + 1 for c in b[i:]] + [0]), dtype=np.uint32)
+
+
+@pytest.mark.parametrize("case", ["random", "zeros", "period2", "period3tail", "twosym", "text"])
+def test_suffix_array_against_naive_sort(case):
+    rng = np.random.default_rng(3)
+    x = {"random": rng.integers(0, 256, 700, dtype=np.uint8), "zeros": np.zeros(300, dtype=np.uint8),
+         "period2": np.tile(np.array([1, 2], dtype=np.uint8), 200),
+         "period3tail": np.concatenate([np.tile(np.array([9, 0, 0], dtype=np.uint8), 100), np.zeros(7, dtype=np.uint8)]),
+         "twosym": rng.integers(0, 2, 600, dtype=np.uint8), "text": datagen.text_bytes(800)}[case]
+    assert np.array_equal(O.suffix_array(x), _naive_sa(x))
+
+
+@pytest.mark.parametrize("gen,n", [("zipf", 70001), ("text", 131072), ("float", 65536), ("zeros", 5000), ("one", 1)])
+def test_bwt_mtf_inverses(gen, n):
+    x = {"zipf": datagen.zipf_bytes, "text": datagen.text_bytes, "float": datagen.float_bytes,
+         "zeros": lambda k: np.zeros(k, dtype=np.uint8), "one": lambda k: np.array([200], dtype=np.uint8)}[gen](n)
+    b, idx = O.bwt(x)
+    assert np.array_equal(np.sort(b), np.sort(x))                         # a permutation of the input
+    assert np.array_equal(O.ibwt(b, idx), x)
+    m = O.mtf(b)
+    assert np.array_equal(O.imtf(m), b)
+
+
+def test_mtf_definition_small():
+    assert O.mtf(np.array([0, 0, 1, 1, 0, 255], dtype=np.uint8)).tolist() == [0, 0, 1, 0, 1, 255]
+    assert O.mtf(np.array([3, 3, 3, 2, 3], dtype=np.uint8)).tolist() == [3, 0, 0, 3, 1]
+
+
+def test_huffman_codes_are_a_prefix_code_with_reference_tie_breaks():
+    # two symbols + EOF: counts 5, 5, EOF=1 -> first merge takes (EOF, then the lower-index of the 5s)
+    hist = np.zeros(256, dtype=np.uint32); hist[10] = 5; hist[20] = 5
+    codes, lens, n = O.huff_codes(hist)
+    assert n == 3
+    # min1 = EOF(count 1, slot 2) -> left, min2 = slot 0 (sym 10) -> right; then composite(6) vs sym 20 (5):
+    # min1 = sym20 (count 5) left, min2 = composite right  => sym20 = '0', EOF = '10', sym10 = '11'
+    assert (lens[20], codes[20]) == (1, 0) and (lens[256], codes[256]) == (2, 0b10) and (lens[10], codes[10]) == (2, 0b11)
+    # Kraft equality for a full binary tree
+    rng = np.random.default_rng(5)
+    hist = rng.integers(0, 1000, 256).astype(np.uint32)
+    codes, lens, n = O.huff_codes(hist)
+    present = [s for s in range(257) if (hist[s] if s < 256 else 1) > 0]
+    assert abs(sum(2.0 ** -int(lens[s]) for s in present) - 1.0) < 1e-12
+    as_str = sorted(format(int(codes[s]), "0%db" % lens[s]) for s in present)
+    assert all(not b.startswith(a) for a, b in zip(as_str, as_str[1:]))
+
+
+@pytest.mark.parametrize("n", [1, 39, 4095, 4096, 4097, 65536, 100001])
+def test_compress_round_trip_and_layout(n):
+    x = datagen.zipf_bytes(n, seed=n)
+    r = O.compress(x)
+    nblk = (n + 4095) // 4096
+    assert r["offsets"].size == nblk and r["offsets"][0] == 0
+    # offset table is the running sum of (1 + block words)  (huffman_datapack_kernel)
+    sizes = np.array([int(r["words"][o]) for o in r["offsets"]])
+    assert np.array_equal(r["offsets"], np.concatenate([[0], np.cumsum(1 + sizes)[:-1]]))
+    assert r["size"] == int((1 + sizes).sum()) == r["words"].size
+    assert int(r["hist"].sum()) == n
+    assert np.array_equal(O.decompress(r["bwt_index"], r["hist"], r["offsets"], r["words"], n), x)
+
+
+@pytest.mark.parametrize("gen", ["log", "text", "zeros", "float"])
+def test_lzss_round_trip_and_format(gen):
+    n = 65536
+    x = {"log": datagen.log_bytes, "text": datagen.text_bytes, "float": datagen.float_bytes,
+         "zeros": lambda k: np.zeros(k, dtype=np.uint8)}[gen](n)
+    c = O.lzss_candidates(x)
+    assert c.size == 2 * n
+    lens = c[0::2]
+    assert lens.min() >= 1 and lens.max() <= 127 and not np.any(lens == 2)       # 1 = literal, else 3..127
+    lit = lens == 1
+    assert np.array_equal(c[1::2][lit], x[lit])
+    p = O.lzss_pack(c, n)
+    if p is None:
+        assert gen == "float"                                                    # incompressible: store raw
+        return
+    assert int.from_bytes(bytes(p[-6:-2]), "big") == n and bytes(p[-2:]) == b"\x00\x00"
+    npk = n // 4096
+    sizes = np.frombuffer(bytes(p[-6 - 2 * npk:-6]), dtype=">u2")
+    assert int(sizes.sum()) == p.size - 6 - 2 * npk
+    assert np.array_equal(O.lzss_decode(p), x)
+
+
+def test_lzss_last_chunk_quirks():
+    """the last 128-byte chunk of a packet: matches are clamped to the packet end"""
+    x = np.tile(np.frombuffer(b"abcdefgh", dtype=np.uint8), 512)
+    c = O.lzss_candidates(x)
+    lens = c[0::2].astype(int)
+    pos = np.arange(4096)
+    tail = pos >= 3968
+    assert np.all(pos[tail] + np.where(lens[tail] == 1, 1, lens[tail]) <= 4096)
+    assert np.array_equal(O.lzss_decode(O.lzss_pack(c, 4096)), x)
+
+
+# ---------------------------------------------------------------- C ABI -----
+def test_library_exports_every_declared_symbol(glc):
+    L = glc.lib()
+    missing = [s for s in glc.CUDPP_SYMBOLS + glc.CULZSS_SYMBOLS if not hasattr(L, s)]
+    assert not missing, missing
+    # every function declared in the two headers is in the binding's symbol lists
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for hdr, syms in (("cudpp.h", glc.CUDPP_SYMBOLS), ("culzss.h", glc.CULZSS_SYMBOLS)):
+        text = open(os.path.join(root, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)) - {"defined", "sizeof"}
+        declared = {d for d in declared if not d.isupper()}
+        assert declared <= set(syms), (hdr, declared - set(syms))
+
+
+def test_host_side_argument_validation_without_gpu(glc):
+    """validation that happens before any device work (cudpp_plan.cpp:29-46,147-190)"""
+    L = glc.lib()
+    h = C.c_size_t(0)
+    assert L.cudppPlan(0, C.byref(h), glc.config(glc.CUDPP_COMPRESS), 1 << 20, 1, 0) == glc.CUDPP_ERROR_INVALID_HANDLE
+    fake = 0x1000      # never dereferenced for these paths
+    both = glc.CUDPP_OPTION_FORWARD | glc.CUDPP_OPTION_BACKWARD
+    assert L.cudppPlan(fake, C.byref(h), glc.config(glc.CUDPP_COMPRESS, options=both), 1 << 20, 1, 0) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
+    assert h.value == glc.CUDPP_INVALID_HANDLE
+    assert L.cudppPlan(fake, C.byref(h), glc.config(glc.CUDPP_SCAN), 1024, 1, 0) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
+    assert L.cudppPlan(fake, C.byref(h), glc.config(glc.CUDPP_BWT), (1 << 20) + 1, 1, 0) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
+    assert L.cudppPlan(fake, C.byref(h), glc.config(glc.CUDPP_COMPRESS), 0, 1, 0) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
+    assert L.cudppCompress(0, None, None, None, None, None, None, None, 4096) == glc.CUDPP_ERROR_INVALID_HANDLE
+    assert L.cudppDestroyPlan(glc.CUDPP_INVALID_HANDLE) == glc.CUDPP_ERROR_INVALID_HANDLE
+    assert L.cudppDestroy(0) == glc.CUDPP_ERROR_INVALID_HANDLE
+    # CULZSS wrappers reject malformed arguments before touching the device
+    n = C.c_int(0)
+    assert L.culzss_compress(None, 4096, None, C.byref(n)) == 0
+    buf = (C.c_uint8 * 8192)()
+    assert L.culzss_compress(buf, 5000, buf, C.byref(n)) == 0               # not whole packets
+    assert L.decompression_kernel_wrapper(buf, 4, C.byref(n), 0, 1, 1) == 0  # shorter than a trailer
+    assert L.glcLzssPackStride(1 << 20) >= (1 << 20) + 2 * 256 + 6
+    assert L.glcLzssWorkBytes(1 << 20, 4) > 4 * (2 << 20)
+
+
+def test_product_does_not_reference_the_oracle():
+    """the oracle is a checker: nothing under the package or include/ may mention it"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for base in ("gpu-lossless-compression_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(root, base)):
+            for f in fs:
+                if f.endswith((".so", ".pyc")):
+                    continue
+                t = open(os.path.join(dp, f), errors="ignore").read()
+                if "oracle_lib" in t or "glc_oracle" in t or "libglc_oracle" in t or "/root/reference" in t:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
