@@ -518,6 +518,15 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     return hipSuccess;
 }
 
+// per-block exclusive scan of [tile][512] histograms (used by the decoder's LF construction)
+hipError_t tile_hist_scan9(hipStream_t st, uint32_t *tile_hist, uint32_t count, uint32_t *digit_base,
+                           uint32_t max_tiles, uint32_t nblk)
+{
+    hipLaunchKernelGGL(k_rs_scan<9>, dim3(nblk), dim3(512), 0, st, tile_hist, (const uint32_t *)nullptr, count,
+                       digit_base, max_tiles);
+    return hipGetLastError();
+}
+
 hipError_t bwt_gather(hipStream_t st, const uint8_t *text, size_t text_stride, const uint32_t *sa,
                       size_t sa_stride, uint32_t n, uint32_t nblk, uint8_t *out, size_t out_stride,
                       int *d_index)

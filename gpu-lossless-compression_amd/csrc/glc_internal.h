@@ -105,13 +105,18 @@ hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride
 // decoder (round-trip parity only; the reference has no GPU decoder)
 // ---------------------------------------------------------------------------
 struct DecodeScratch {
-    uint32_t nmax = 0, rows = 0;
+    uint32_t nmax = 0, rows = 0, max_tiles = 0, max_split = 0;
     uint8_t  *mtf = nullptr, *bwt = nullptr;     // [rows][nmax]
-    uint32_t *lf = nullptr;                      // [rows][nmax+1]
-    uint32_t *tree = nullptr;                    // [rows][513*2]
-    uint32_t *cnt = nullptr;                     // [rows][max_tiles][257] / bases
+    uint32_t *lf = nullptr;                      // [rows][nmax+1]  (symbol << 21) | LF(row)
+    uint32_t *lut = nullptr;                     // [rows][4096] 12-bit Huffman decode table
+    uint32_t *nodes = nullptr;                   // [rows][513]  tree for codes longer than 12 bits
+    uint32_t *tile_hist = nullptr;               // [rows][max_tiles][512]
+    uint32_t *digit_base = nullptr;              // [rows][512]
+    uint32_t *seg = nullptr;                     // [rows][max_split][4] len, next, pos, -
     size_t    bytes = 0;
 };
+hipError_t tile_hist_scan9(hipStream_t st, uint32_t *tile_hist, uint32_t count, uint32_t *digit_base,
+                           uint32_t max_tiles, uint32_t nblk);
 hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows);
 void       decode_scratch_free(DecodeScratch &s);
 hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist,

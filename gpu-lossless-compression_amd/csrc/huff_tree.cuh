@@ -1,0 +1,96 @@
+// huff_tree.cuh -- the reference's Huffman tree shape, built by one wave64.
+// Shared by the encoder (huffman.hip) and the decoder (decode.hip): both must
+// derive the identical tree from the 256-bin histogram (+EOF with count 1).
+//
+// Restates huffman_build_tree_kernel's merge loop (cudpp-inpar/src/cudpp/kernel/
+// compress_kernel.cuh:2306-2392) with FindMinimumCount's order (cta/compress_cta.cuh:
+// 550-571: lowest count, then lowest level, then lowest slot) as a wave-wide arg-min
+// over packed 64-bit keys  count<<32 | level<<16 | slot.
+#pragma once
+#include "glc_device.h"
+
+namespace glc {
+
+constexpr int      HUFF_NODES = 2 * 257 - 1;          // 513
+constexpr uint64_t HUFF_KEY_NONE = ~0ull;
+
+struct HuffTreeLds {
+    uint64_t key[320];                                 // candidates live in slots < nl (<= 257)
+    uint32_t count[HUFF_NODES];
+    int16_t  level[HUFF_NODES], value[HUFF_NODES];     // value = symbol, -1 for a composite node
+    int16_t  left[HUFF_NODES], right[HUFF_NODES], parent[HUFF_NODES];
+    int      nl, head;
+};
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t k)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)k, o, 64), hi = __shfl_xor((uint32_t)(k >> 32), o, 64);
+        uint64_t other = ((uint64_t)hi << 32) | lo;
+        k = other < k ? other : k;
+    }
+    return k;
+}
+
+// Called by ONE full wave (l = lane).  hist257[256] must already hold the EOF count 1.
+__device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *hist257, unsigned l)
+{
+    // leaves: present symbols in ascending order -> slots 0..nl-1 (compress_kernel.cuh:2310-2321)
+    uint32_t nl = 0;
+    for (int r = 0; r < 5; r++) {
+        const uint32_t sym = r * 64 + l;
+        const uint32_t c = sym < 257 ? hist257[sym] : 0u;
+        const uint64_t bal = __ballot(c > 0);
+        if (c > 0) {
+            const uint32_t slot = nl + mbcnt(bal);
+            T.count[slot] = c; T.level[slot] = 0; T.value[slot] = (int16_t)sym;
+            T.left[slot] = -1; T.right[slot] = -1; T.parent[slot] = -1;
+            T.key[slot] = ((uint64_t)c << 32) | slot;
+        }
+        nl += (uint32_t)__popcll(bal);
+    }
+    for (uint32_t s = nl + l; s < 320; s += 64) T.key[s] = HUFF_KEY_NONE;
+    __builtin_amdgcn_wave_barrier();
+
+    int head = -1;
+    for (uint32_t k = 0;; k++) {
+        uint64_t best = HUFF_KEY_NONE;
+#pragma unroll
+        for (int r = 0; r < 5; r++) { const uint64_t x = T.key[r * 64 + l]; best = x < best ? x : best; }
+        best = wave_min_u64(best);
+        if (best == HUFF_KEY_NONE) break;
+        const int min1 = (int)(best & 0xFFFF);
+        head = min1;
+        if (l == 0) T.key[min1] = HUFF_KEY_NONE;
+        __builtin_amdgcn_wave_barrier();
+        uint64_t best2 = HUFF_KEY_NONE;
+#pragma unroll
+        for (int r = 0; r < 5; r++) { const uint64_t x = T.key[r * 64 + l]; best2 = x < best2 ? x : best2; }
+        best2 = wave_min_u64(best2);
+        if (best2 == HUFF_KEY_NONE) break;
+        const int min2 = (int)(best2 & 0xFFFF);
+        if (l == 0) {
+            // min1 moves to the next free slot >= nl and becomes the LEFT child; min2 stays and
+            // is the RIGHT child; the composite takes min1's slot (compress_kernel.cuh:2344-2385)
+            const int i = (int)(nl + k);
+            const uint32_t c1 = T.count[min1], c2 = T.count[min2];
+            const int l1 = T.level[min1], l2 = T.level[min2];
+            const int lf = T.left[min1], rt = T.right[min1];
+            T.count[i] = c1; T.level[i] = (int16_t)l1; T.value[i] = T.value[min1];
+            T.left[i] = (int16_t)lf; T.right[i] = (int16_t)rt; T.parent[i] = (int16_t)min1;
+            if (lf >= 0) T.parent[lf] = (int16_t)i;
+            if (rt >= 0) T.parent[rt] = (int16_t)i;
+            const int lv = (l1 > l2 ? l1 : l2) + 1;
+            T.left[min1] = (int16_t)i; T.right[min1] = (int16_t)min2; T.value[min1] = -1;
+            T.count[min1] = c1 + c2; T.level[min1] = (int16_t)lv; T.parent[min1] = -1;
+            T.parent[min2] = (int16_t)min1;
+            T.key[min1] = ((uint64_t)(c1 + c2) << 32) | ((uint64_t)lv << 16) | (uint32_t)min1;
+            T.key[min2] = HUFF_KEY_NONE;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (l == 0) { T.nl = (int)nl; T.head = head; }
+}
+
+} // namespace glc

@@ -26,23 +26,9 @@
 // (compress_app.cu:106).
 #include "glc_device.h"
 #include "glc_internal.h"
+#include "huff_tree.cuh"
 
 namespace glc {
-
-constexpr int HUFF_NODES = 2 * 257 - 1;          // 513
-constexpr uint64_t KEY_NONE = ~0ull;
-
-// wave-wide arg-min of 64-bit keys (KEY_NONE = not a candidate)
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t k)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)k, o, 64), hi = __shfl_xor((uint32_t)(k >> 32), o, 64);
-        uint64_t other = ((uint64_t)hi << 32) | lo;
-        k = other < k ? other : k;
-    }
-    return k;
-}
 
 // one 256-thread workgroup per 1 MiB block
 __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__ sub_hist, uint32_t max_sub,
@@ -54,14 +40,10 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ d_status)
 {
     __shared__ uint32_t s_hist[257];
-    __shared__ uint64_t s_key[320];
-    __shared__ uint32_t s_count[HUFF_NODES];
-    __shared__ int16_t  s_level[HUFF_NODES], s_value[HUFF_NODES];
-    __shared__ int16_t  s_left[HUFF_NODES], s_right[HUFF_NODES], s_parent[HUFF_NODES];
+    __shared__ HuffTreeLds T;
     __shared__ uint32_t s_code[257], s_len[257];
     __shared__ uint32_t s_words[256];
     __shared__ uint32_t s_tmp[8];
-    __shared__ int s_nl, s_head;
 
     const uint32_t b = blockIdx.x, tid = threadIdx.x, l = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,78 +62,23 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
     }
     __syncthreads();
 
-    if (w == 0) {
-        // ---- leaves: present symbols in ascending order -> slots 0..nl-1 ----
-        uint32_t nl = 0;
-        for (int r = 0; r < 5; r++) {
-            const uint32_t sym = r * 64 + l;
-            const uint32_t c = sym < 257 ? s_hist[sym] : 0u;
-            const uint64_t bal = __ballot(c > 0);
-            if (c > 0) {
-                const uint32_t slot = nl + mbcnt(bal);
-                s_count[slot] = c; s_level[slot] = 0; s_value[slot] = (int16_t)sym;
-                s_left[slot] = -1; s_right[slot] = -1; s_parent[slot] = -1;
-                s_key[slot] = ((uint64_t)c << 32) | slot;              // level 0
-            }
-            nl += (uint32_t)__popcll(bal);
-        }
-        for (uint32_t s = nl + l; s < 320; s += 64) s_key[s] = KEY_NONE;
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- merge loop (compress_kernel.cuh:2323-2392) ----
-        int head = -1;
-        for (uint32_t k = 0;; k++) {
-            uint64_t best = KEY_NONE;
-#pragma unroll
-            for (int r = 0; r < 5; r++) { const uint64_t x = s_key[r * 64 + l]; best = x < best ? x : best; }
-            best = wave_min_u64(best);
-            if (best == KEY_NONE) break;
-            const int min1 = (int)(best & 0xFFFF);
-            head = min1;
-            if (l == 0) s_key[min1] = KEY_NONE;
-            __builtin_amdgcn_wave_barrier();
-            uint64_t best2 = KEY_NONE;
-#pragma unroll
-            for (int r = 0; r < 5; r++) { const uint64_t x = s_key[r * 64 + l]; best2 = x < best2 ? x : best2; }
-            best2 = wave_min_u64(best2);
-            if (best2 == KEY_NONE) break;
-            const int min2 = (int)(best2 & 0xFFFF);
-            if (l == 0) {
-                const int i = (int)(nl + k);                            // next free slot >= nl
-                const uint32_t c1 = s_count[min1], c2 = s_count[min2];
-                const int l1 = s_level[min1], l2 = s_level[min2];
-                const int lf = s_left[min1], rt = s_right[min1];
-                s_count[i] = c1; s_level[i] = (int16_t)l1; s_value[i] = s_value[min1];
-                s_left[i] = (int16_t)lf; s_right[i] = (int16_t)rt; s_parent[i] = (int16_t)min1;
-                if (lf >= 0) s_parent[lf] = (int16_t)i;
-                if (rt >= 0) s_parent[rt] = (int16_t)i;
-                const int lv = (l1 > l2 ? l1 : l2) + 1;
-                s_left[min1] = (int16_t)i; s_right[min1] = (int16_t)min2; s_value[min1] = -1;
-                s_count[min1] = c1 + c2; s_level[min1] = (int16_t)lv; s_parent[min1] = -1;
-                s_parent[min2] = (int16_t)min1;
-                s_key[min1] = ((uint64_t)(c1 + c2) << 32) | ((uint64_t)lv << 16) | (uint32_t)min1;
-                s_key[min2] = KEY_NONE;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (l == 0) { s_nl = (int)nl; s_head = head; }
-    }
+    if (w == 0) huff_tree_build(T, s_hist, l);
     __syncthreads();
 
     // ---- codes: every leaf walks to the root; the k-th step up supplies bit k
     //      (left = 0, right = 1: compress_kernel.cuh:2416-2496) ----
     {
-        const int nl = s_nl, used = 2 * nl - 1;
+        const int nl = T.nl, used = 2 * nl - 1;
         for (int s = (int)tid; s < used; s += 256) {
-            if (s_left[s] < 0) {
+            if (T.left[s] < 0) {
                 uint32_t code = 0, len = 0;
-                int node = s, p = s_parent[s];
+                int node = s, p = T.parent[s];
                 while (p >= 0) {
-                    if (s_right[p] == node) code |= 1u << len;
+                    if (T.right[p] == node) code |= 1u << len;
                     len++;
-                    node = p; p = s_parent[p];
+                    node = p; p = T.parent[p];
                 }
-                const int sym = s_value[s];
+                const int sym = T.value[s];
                 s_code[sym] = code; s_len[sym] = len;
             }
         }

@@ -1,0 +1,65 @@
+"""GPU decoder for the cudppCompress stream.  The reference has
+no GPU decoder; parity = round trip through the HIP encoder + HIP decoder, and
+HIP decoder == oracle decoder (the gold decoder semantics of
+test_compress.cpp:192-311) on streams produced by the ORACLE encoder."""
+import numpy as np
+import pytest
+
+import datagen
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(17)
+    return {
+        "zipf_1m": datagen.zipf_bytes(1 << 20),
+        "text_1m": datagen.text_bytes(1 << 20),
+        "float_1m": datagen.float_bytes(1 << 20),
+        "ref_vector_1m": O.glibc_rand_bytes(1 << 20, 255),
+        "zeros_1m": np.zeros(1 << 20, dtype=np.uint8),
+        "log_300001": datagen.log_bytes(300001),
+        "one": np.array([9], dtype=np.uint8),
+        "n_4097": rng.integers(0, 256, 4097, dtype=np.uint8),
+        "two_symbols": rng.integers(0, 2, 70000, dtype=np.uint8),
+        "ends_without_unique_min": np.frombuffer(b"abracadabra" * 3000, dtype=np.uint8),   # gold LF walk fails here
+    }
+
+
+@pytest.mark.parametrize("name", list(_cases().keys()))
+def test_round_trip_and_oracle_stream(glc, cuda, name):
+    import torch
+    x = _cases()[name]
+    n = x.size
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, max(n, 64), rows=1) as plan:
+        d_in = torch.from_numpy(x.copy()).cuda()
+        comp = glc.compress_batch(plan, d_in, n, 1)
+        back = glc.decompress_batch(plan, comp, n, 1)
+        plan.synchronize()
+        assert np.array_equal(back.cpu().numpy(), x), name + ": HIP encode -> HIP decode"
+        # decode a stream made by the oracle encoder
+        r = O.compress(x)
+        nsub, stride = comp["nsub"], comp["stride"]
+        words = np.zeros(stride, dtype=np.uint32); words[: r["size"]] = r["words"]
+        oc = dict(bwt_index=torch.tensor([r["bwt_index"]], dtype=torch.int32, device=cuda),
+                  hist=torch.from_numpy(r["hist"].view(np.int32).copy()).cuda(),
+                  offsets=torch.from_numpy(r["offsets"].view(np.int32).copy()).cuda(),
+                  words=torch.from_numpy(words.view(np.int32)).cuda(), nsub=nsub, stride=stride)
+        back2 = glc.decompress_batch(plan, oc, n, 1)
+        plan.synchronize()
+        assert np.array_equal(back2.cpu().numpy(), x), name + ": oracle encode -> HIP decode"
+
+
+def test_batch_round_trip(glc, cuda):
+    import torch
+    n, nb = 1 << 19, 8
+    blocks = [datagen.zipf_bytes(n, seed=i) for i in range(4)] + [datagen.text_bytes(n, seed=9), datagen.float_bytes(n),
+                                                                 np.zeros(n, dtype=np.uint8), datagen.log_bytes(n)]
+    x = np.concatenate(blocks)
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=nb) as plan:
+        d_in = torch.from_numpy(x).cuda()
+        comp = glc.compress_batch(plan, d_in, n, nb)
+        back = glc.decompress_batch(plan, comp, n, nb)
+        plan.synchronize()
+        assert torch.equal(back, d_in)
