@@ -550,6 +550,47 @@ ORC_API int orc_lzss_decode(const uint8_t *buf, int buf_length, uint8_t *out, in
 }
 
 /* ========================================================================= */
+/* 7b. all-core CPU baseline driver (bench.py cpu_baseline only): compresses  */
+/*     nblocks blocks of n bytes with `nthreads` pthreads, block i on thread  */
+/*     i % nthreads; returns total compressed words through *total_words.     */
+/* ========================================================================= */
+#include <pthread.h>
+typedef struct { const uint8_t *in; uint32_t n, nblocks, tid, nthreads; uint64_t words; } orc_job;
+
+static void *orc_worker(void *p)
+{
+    orc_job *j = (orc_job *)p;
+    uint32_t nsub = (j->n + HUFF_BLOCK_SYMS - 1) / HUFF_BLOCK_SYMS;
+    uint32_t cap = (nsub ? nsub : 1) * (HUFF_BLOCK_WORDS + 1) * 2;
+    uint32_t *comp = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    uint32_t *off = (uint32_t *)malloc(sizeof(uint32_t) * (nsub ? nsub : 1));
+    uint32_t hist[256], size; int32_t idx;
+    for (uint32_t b = j->tid; b < j->nblocks; b += j->nthreads) {
+        orc_compress(j->in + (size_t)b * j->n, j->n, &idx, hist, off, &size, comp, cap);
+        j->words += size;
+    }
+    free(comp); free(off);
+    return 0;
+}
+
+ORC_API int orc_compress_many(const uint8_t *in, uint32_t n, uint32_t nblocks, uint32_t nthreads,
+                              uint64_t *total_words)
+{
+    if (nthreads == 0) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    orc_job *jobs = (orc_job *)calloc(nthreads, sizeof(orc_job));
+    for (uint32_t t = 0; t < nthreads; t++) {
+        jobs[t].in = in; jobs[t].n = n; jobs[t].nblocks = nblocks; jobs[t].tid = t; jobs[t].nthreads = nthreads;
+        pthread_create(&th[t], 0, orc_worker, &jobs[t]);
+    }
+    uint64_t tot = 0;
+    for (uint32_t t = 0; t < nthreads; t++) { pthread_join(th[t], 0); tot += jobs[t].words; }
+    *total_words = tot;
+    free(th); free(jobs);
+    return 0;
+}
+
+/* ========================================================================= */
 /* 8. helpers for tests                                                      */
 /* ========================================================================= */
 ORC_API uint32_t orc_crc32(const uint8_t *p, size_t n)

@@ -48,6 +48,8 @@ def _load():
     lib.orc_lzss_pack.restype = C.c_int
     lib.orc_lzss_decode.argtypes = [_u8p, C.c_int, _u8p, C.POINTER(C.c_int)]
     lib.orc_lzss_decode.restype = C.c_int
+    lib.orc_compress_many.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.orc_compress_many.restype = C.c_int
     lib.orc_crc32.argtypes = [_u8p, C.c_size_t]
     lib.orc_crc32.restype = C.c_uint32
     return lib
@@ -155,6 +157,14 @@ def compress(data):
     rc = lib().orc_compress(_p8(a), a.size, C.byref(idx), _p32(hist), _p32(off), C.byref(size), _p32(comp), cap)
     return dict(rc=rc, bwt_index=idx.value, hist=hist, offsets=off[:nblk], size=size.value,
                 words=comp[: size.value])
+
+
+def compress_many(blocks, n, nthreads):
+    """bench.py cpu_baseline: len(blocks)//n blocks through orc_compress on `nthreads` pthreads."""
+    a = _as_u8(blocks)
+    tot = C.c_uint64(0)
+    lib().orc_compress_many(_p8(a), n, a.size // n, nthreads, C.byref(tot))
+    return tot.value
 
 
 def decompress(bwt_index, hist, offsets, words, n):
