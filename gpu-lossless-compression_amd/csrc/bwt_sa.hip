@@ -226,21 +226,35 @@ __global__ __launch_bounds__(SA_THREADS) void k_rs_scatter(const uint64_t *__res
 
 // ---------------------------------------------------------------------------
 // After a sort: group heads, ranks, write-back, compaction of unresolved.
-// APPLY=false: per-tile aggregates (last head index, #unresolved).
-// APPLY=true : uses the scanned aggregates and writes ISA / SA / next list.
+// APPLY=false: per-tile aggregates (last head index, #unresolved, #unresolved heads).
+// APPLY=true : uses the scanned aggregates and writes SA (+ISA) and the next list.
 // A suffix is resolved when its group (equal sort key) is a singleton.
+//
+// Two refinement modes for the NEXT round's words:
+//   MODE_TEXT  [dense group number:19 | code of symbols d..d+2 (base 257):25 | i:20]
+//              -- no rank array at all: the next 3 symbols come straight from the
+//              text.  Shallow-LCP data (i.i.d. bytes, float mantissas) is finished by
+//              1-2 such rounds and never pays the random ISA scatter.
+//   MODE_ISA   [rank(i):21 | rank(i+h):21 | i:20]  classic prefix doubling; ISA is
+//              scattered for every suffix of the list.
 // ---------------------------------------------------------------------------
+constexpr int MODE_ISA = 0, MODE_TEXT = 1;
+constexpr uint32_t TXT_GRP_SHIFT = 45, TXT_CODE_SHIFT = 20;
+
 template <bool APPLY>
 __global__ __launch_bounds__(SA_THREADS) void k_sa_rank(const uint64_t *__restrict__ key,
                                                         const uint32_t *__restrict__ pos,
                                                         const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                        uint2 *__restrict__ tile_agg,
+                                                        uint4 *__restrict__ tile_agg,
                                                         uint32_t *__restrict__ isa, uint32_t *__restrict__ sa,
                                                         uint64_t *__restrict__ key_next,
                                                         uint32_t *__restrict__ pos_next,
-                                                        uint32_t nmax, uint32_t max_tiles)
+                                                        uint32_t *__restrict__ hd_next,
+                                                        uint32_t nmax, uint32_t max_tiles, int mode,
+                                                        const uint8_t *__restrict__ text, size_t text_stride,
+                                                        uint32_t n, uint32_t depth)
 {
-    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_tmp[12];
     const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
     if (base >= m) return;
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank(const uint64_t *__restri
         const int64_t g = (int64_t)e0 - 1 + i;
         kk[i] = (g >= 0 && g < (int64_t)m) ? (K[g] >> VAL_BITS) : 0ull;
     }
-    uint32_t headm = 0, unresm = 0, lh = 0, uc = 0;
+    uint32_t headm = 0, unresm = 0, lh = 0, uc = 0, uh = 0;
 #pragma unroll
     for (int i = 0; i < SA_ITEMS; i++) {
         const uint32_t e = e0 + i;
@@ -263,42 +277,62 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank(const uint64_t *__restri
             const bool head = (e == 0) || (kk[i + 1] != kk[i]);
             const bool nhead = (e + 1 >= m) || (kk[i + 2] != kk[i + 1]);
             if (head) { headm |= 1u << i; lh = e; }
-            if (!(head && nhead)) { unresm |= 1u << i; uc++; }
+            if (!(head && nhead)) { unresm |= 1u << i; uc++; if (head) uh++; }
         }
     }
     if (!APPLY) {
-        uint32_t mx = wave_max(lh), sm = wave_sum(uc);
-        if ((tid & 63) == 0) { s_tmp[tid >> 6] = mx; s_tmp[4 + (tid >> 6)] = sm; }
+        uint32_t mx = wave_max(lh), sm = wave_sum(uc), sh = wave_sum(uh);
+        if ((tid & 63) == 0) { s_tmp[tid >> 6] = mx; s_tmp[4 + (tid >> 6)] = sm; s_tmp[8 + (tid >> 6)] = sh; }
         __syncthreads();
         if (tid == 0) {
             uint32_t a = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
             uint32_t c = s_tmp[4] + s_tmp[5] + s_tmp[6] + s_tmp[7];
-            tile_agg[(size_t)b * max_tiles + t] = make_uint2(a, c);
+            uint32_t h = s_tmp[8] + s_tmp[9] + s_tmp[10] + s_tmp[11];
+            tile_agg[(size_t)b * max_tiles + t] = make_uint4(a, c, h, 0);
         }
         return;
     } else {
-        const uint2 agg = tile_agg[(size_t)b * max_tiles + t];     // (carry head, unresolved offset)
+        const uint4 agg = tile_agg[(size_t)b * max_tiles + t];   // (carry head, unresolved offset, group offset)
         uint32_t carry = block_excl_max<SA_THREADS>(lh, s_tmp);
         carry = max(carry, agg.x);
         uint32_t off = agg.y + block_excl_add<SA_THREADS>(uc, s_tmp);
+        uint32_t gcount = (mode == MODE_TEXT) ? agg.z + block_excl_add<SA_THREADS>(uh, s_tmp) : 0u;
         uint32_t *ISA = isa + (size_t)b * nmax, *SAo = sa + (size_t)b * nmax;
         uint64_t *KN = key_next + (size_t)b * nmax;
         uint32_t *PN = pos_next + (size_t)b * nmax;
+        uint32_t *HN = hd_next + (size_t)b * nmax;
+        const uint8_t *T = text + (size_t)b * text_stride;
         uint32_t running = carry;
 #pragma unroll
         for (int i = 0; i < SA_ITEMS; i++) {
             const uint32_t e = e0 + i;
             if (e < m) {
-                if (headm & (1u << i)) running = e;
+                const bool head = headm & (1u << i), unres = unresm & (1u << i);
+                if (head) running = e;
                 const uint32_t grp = P ? P[running] : running;    // SA slot of the group head
                 const uint32_t v = (uint32_t)(K[e] & VAL_MASK);
                 const uint32_t slot = P ? P[e] : e;
-                ISA[v] = grp + 1;
                 SAo[slot] = v;
-                if (unresm & (1u << i)) {
-                    PN[off] = slot;
-                    KN[off] = ((uint64_t)(grp + 1) << R1_SHIFT) | v;
-                    off++;
+                if (mode == MODE_ISA) {
+                    ISA[v] = grp + 1;
+                    if (unres) {
+                        PN[off] = slot;
+                        KN[off] = ((uint64_t)(grp + 1) << R1_SHIFT) | v;
+                        off++;
+                    }
+                } else {
+                    if (head && unres) gcount++;
+                    if (unres) {
+                        const uint32_t p0 = v + depth;
+                        const uint32_t c0 = p0 < n ? (uint32_t)T[p0] + 1 : 0u;
+                        const uint32_t c1 = p0 + 1 < n ? (uint32_t)T[p0 + 1] + 1 : 0u;
+                        const uint32_t c2 = p0 + 2 < n ? (uint32_t)T[p0 + 2] + 1 : 0u;
+                        const uint64_t code = ((uint64_t)c0 * 257 + c1) * 257 + c2;
+                        PN[off] = slot;
+                        HN[off] = grp;
+                        KN[off] = ((uint64_t)(gcount - 1) << TXT_GRP_SHIFT) | (code << TXT_CODE_SHIFT) | v;
+                        off++;
+                    }
                 }
             }
         }
@@ -306,7 +340,7 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank(const uint64_t *__restri
 }
 
 // scan of the per-tile aggregates; one 512-thread workgroup per block
-__global__ __launch_bounds__(512) void k_sa_aggscan(uint2 *__restrict__ tile_agg,
+__global__ __launch_bounds__(512) void k_sa_aggscan(uint4 *__restrict__ tile_agg,
                                                     const uint32_t *__restrict__ cnt, uint32_t nfixed,
                                                     uint32_t *__restrict__ cnt_next,
                                                     uint32_t *__restrict__ d_max_cnt, uint32_t max_tiles)
@@ -315,15 +349,44 @@ __global__ __launch_bounds__(512) void k_sa_aggscan(uint2 *__restrict__ tile_agg
     const uint32_t b = blockIdx.x, t = threadIdx.x;
     const uint32_t m = live_count(cnt, nfixed, b);
     const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
-    uint2 a = make_uint2(0, 0);
+    uint4 a = make_uint4(0, 0, 0, 0);
     if (t < ntiles) a = tile_agg[(size_t)b * max_tiles + t];
     uint32_t carry = block_excl_max<512>(a.x, s_tmp);
     uint32_t total = 0;
     uint32_t off = block_excl_add<512>(a.y, s_tmp, &total);
-    if (t < ntiles) tile_agg[(size_t)b * max_tiles + t] = make_uint2(carry, off);
+    uint32_t goff = block_excl_add<512>(a.z, s_tmp);
+    if (t < ntiles) tile_agg[(size_t)b * max_tiles + t] = make_uint4(carry, off, goff, 0);
     if (t == 0) {
         cnt_next[b] = total;
         if (total) { atomicMax(d_max_cnt, total); atomicAdd(d_max_cnt + 1, total); }
+    }
+}
+
+// switch from text refinement to prefix doubling: ranks of every suffix in the order
+// established so far.  Resolved suffixes: rank = own SA slot + 1 ...
+__global__ __launch_bounds__(256) void k_isa_init(const uint32_t *__restrict__ sa, uint32_t *__restrict__ isa,
+                                                  uint32_t n, uint32_t nmax)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) isa[(size_t)b * nmax + sa[(size_t)b * nmax + j]] = j + 1;
+}
+
+// ... unresolved suffixes: rank = SA slot of their group head + 1; also rewrite their words
+// into the doubling format [rank(i):21 | (rank(i+h) filled by k_sa_fill_rank2) | i:20]
+__global__ __launch_bounds__(SA_THREADS) void k_isa_fix(uint64_t *__restrict__ key, const uint32_t *__restrict__ cnt,
+                                                        const uint32_t *__restrict__ hd, uint32_t *__restrict__ isa,
+                                                        uint32_t nmax)
+{
+    const uint32_t b = blockIdx.y, m = cnt[b];
+    uint64_t *K = key + (size_t)b * nmax;
+    const uint32_t *H = hd + (size_t)b * nmax;
+    uint32_t *ISA = isa + (size_t)b * nmax;
+    for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
+        const uint32_t v = (uint32_t)(K[i] & VAL_MASK);
+        const uint32_t r1 = H[i] + 1;
+        ISA[v] = r1;
+        K[i] = ((uint64_t)r1 << R1_SHIFT) | v;
     }
 }
 
@@ -398,7 +461,8 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.isa, ne * 4));  GLC_TRY(A((void **)&s.sa, ne * 4));
     GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.max_tiles * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * SA_MAXRADIX * 4));
-    GLC_TRY(A((void **)&s.tile_agg, (size_t)rows * s.max_tiles * sizeof(uint2)));
+    GLC_TRY(A((void **)&s.tile_agg, (size_t)rows * s.max_tiles * sizeof(uint4)));
+    GLC_TRY(A((void **)&s.hdA, ne * 4)); GLC_TRY(A((void **)&s.hdB, ne * 4));
     GLC_TRY(A((void **)&s.cntA, (size_t)rows * 4)); GLC_TRY(A((void **)&s.cntB, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.d_max_cnt, 8));
     GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 8, hipHostMallocDefault));
@@ -408,8 +472,8 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.isa, s.sa, s.tile_hist, s.digit_base, s.tile_agg,
-                  s.cntA, s.cntB, s.d_max_cnt};
+    void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base,
+                  s.tile_agg, s.cntA, s.cntB, s.d_max_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
     for (auto &e : s.prof_ev) if (e) (void)hipEventDestroy(e);
@@ -472,17 +536,25 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 
     uint32_t *cnt_cur = nullptr, *cnt_next = s.cntA, *cnt_spare = s.cntB;
     uint32_t *pos_cur = nullptr, *pos_next = s.posA, *pos_spare = s.posB;
-    uint32_t h = 5, live = n;
+    uint32_t *hd_cur = nullptr, *hd_next = s.hdA, *hd_spare = s.hdB;
+    // `depth` = symbols the current order is exact for; text refinement adds 3 per round,
+    // prefix doubling doubles it.  Text refinement first: data whose suffixes separate
+    // within ~11 symbols (i.i.d. bytes, float mantissas) never builds the rank array.
+    int mode = s.force_isa ? MODE_ISA : MODE_TEXT;
+    uint32_t depth = 5, live = n, text_rounds = 0;
     int rounds = 0;
+    if (mode == MODE_ISA) {
+        // ranks are needed from the first refinement on: k_sa_rank<true> writes them in MODE_ISA
+    }
     for (;;) {
         dim3 g(tiles, nblk);
         GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 8, st));
-        hipLaunchKernelGGL(k_sa_rank<false>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
-                           s.tile_agg, s.isa, s.sa, alt, pos_next, s.nmax, s.max_tiles);
+        hipLaunchKernelGGL(k_sa_rank<false>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live, s.tile_agg,
+                           s.isa, s.sa, alt, pos_next, hd_next, s.nmax, s.max_tiles, mode, text, text_stride, n, depth);
         hipLaunchKernelGGL(k_sa_aggscan, dim3(nblk), dim3(512), 0, st, s.tile_agg, cnt_cur, live, cnt_next,
                            s.d_max_cnt, s.max_tiles);
-        hipLaunchKernelGGL(k_sa_rank<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
-                           s.tile_agg, s.isa, s.sa, alt, pos_next, s.nmax, s.max_tiles);
+        hipLaunchKernelGGL(k_sa_rank<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live, s.tile_agg,
+                           s.isa, s.sa, alt, pos_next, hd_next, s.nmax, s.max_tiles, mode, text, text_stride, n, depth);
         GLC_TRY(hipGetLastError());
         GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 8, hipMemcpyDeviceToHost, st));
         GLC_TRY(hipStreamSynchronize(st));
@@ -491,28 +563,52 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         const uint32_t maxc = s.h_max_cnt[0];
         live_total = (double)s.h_max_cnt[1];
         if (maxc == 0) break;
-        if (h >= 2u * n + 10u) return hipErrorUnknown;           // cannot happen: h >= n resolves everything
+        if (depth >= 2u * n + 16u) return hipErrorUnknown;        // cannot happen: depth >= n resolves everything
         // next round works on the compacted list that k_sa_rank<true> wrote into `alt`
         { uint64_t *x = cur; cur = alt; alt = x; }
         if (cnt_cur == nullptr) { cnt_cur = cnt_next; cnt_next = cnt_spare; }
         else { uint32_t *x = cnt_cur; cnt_cur = cnt_next; cnt_next = x; }
         if (pos_cur == nullptr) { pos_cur = pos_next; pos_next = pos_spare; }
         else { uint32_t *x = pos_cur; pos_cur = pos_next; pos_next = x; }
+        if (hd_cur == nullptr) { hd_cur = hd_next; hd_next = hd_spare; }
+        else { uint32_t *x = hd_cur; hd_cur = hd_next; hd_next = x; }
         live = maxc;
         tiles = (maxc + SA_TILE - 1) / SA_TILE;
-        uint32_t fill_blocks = (maxc + SA_THREADS * 4 - 1) / (SA_THREADS * 4);
-        hipLaunchKernelGGL(k_sa_fill_rank2, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur,
-                           s.isa, n, h, s.nmax);
-        // 42 key bits at [20, 62): 8+8+8+9+9
-        for (int p = 0; p < 3; p++) {
-            GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 * p, tiles, nblk, s, live_total));
-            uint64_t *x = cur; cur = alt; alt = x;
+        const uint32_t fill_blocks = (maxc + SA_THREADS * 4 - 1) / (SA_THREADS * 4);
+        if (mode == MODE_TEXT) {
+            // deep data (text, long repeats): 3 symbols per round is too slow -> prefix doubling
+            const bool deep = (rounds == 1 && live_total > 0.25 * (double)n * nblk) || text_rounds >= 3;
+            if (deep) {
+                hipLaunchKernelGGL(k_isa_init, dim3((n + 255) / 256, nblk), dim3(256), 0, st, s.sa, s.isa, n, s.nmax);
+                hipLaunchKernelGGL(k_isa_fix, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur, hd_cur,
+                                   s.isa, s.nmax);
+                mode = MODE_ISA;
+            }
         }
-        for (int p = 0; p < 2; p++) {
-            GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 24 + 9 * p, tiles, nblk, s, live_total));
-            uint64_t *x = cur; cur = alt; alt = x;
+        if (mode == MODE_TEXT) {
+            // 44 key bits at [20, 64): 8+9+9+9+9
+            GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS, tiles, nblk, s, live_total));
+            { uint64_t *x = cur; cur = alt; alt = x; }
+            for (int p = 0; p < 4; p++) {
+                GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 + 9 * p, tiles, nblk, s, live_total));
+                uint64_t *x = cur; cur = alt; alt = x;
+            }
+            depth += 3;
+            text_rounds++;
+        } else {
+            hipLaunchKernelGGL(k_sa_fill_rank2, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur, s.isa,
+                               n, depth, s.nmax);
+            // 42 key bits at [20, 62): 8+8+8+9+9
+            for (int p = 0; p < 3; p++) {
+                GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 * p, tiles, nblk, s, live_total));
+                uint64_t *x = cur; cur = alt; alt = x;
+            }
+            for (int p = 0; p < 2; p++) {
+                GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 24 + 9 * p, tiles, nblk, s, live_total));
+                uint64_t *x = cur; cur = alt; alt = x;
+            }
+            depth *= 2;
         }
-        h *= 2;
     }
     if (rounds_out) *rounds_out = rounds;
     return hipSuccess;

@@ -28,11 +28,13 @@ struct SaScratch {
     uint32_t *sa = nullptr;                      // [rows][nmax]
     uint32_t *tile_hist = nullptr;               // [rows][max_tiles][512]
     uint32_t *digit_base = nullptr;              // [rows][512]
-    uint2    *tile_agg = nullptr;                // [rows][max_tiles]
+    uint4    *tile_agg = nullptr;                // [rows][max_tiles]
+    uint32_t *hdA = nullptr, *hdB = nullptr;     // [rows][nmax] SA slot of the group head of each unresolved entry
     uint32_t *cntA = nullptr, *cntB = nullptr;   // [rows] unresolved counts
     uint32_t *d_max_cnt = nullptr;               // [2] max and sum of the unresolved counts
     uint32_t *h_max_cnt = nullptr;               // pinned [2]
     size_t    bytes = 0;
+    bool      force_isa = false;                 // tests: skip text refinement, prefix doubling from round 1
     // optional live profile of the dominant kernel (k_rs_scatter<8>): HIP events on
     // the launch stream around every launch, accumulated across sa_build calls
     bool       prof = false;

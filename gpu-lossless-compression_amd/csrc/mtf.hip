@@ -105,7 +105,21 @@ __global__ __launch_bounds__(64) void k_mtf_scan_lists(uint8_t *__restrict__ lis
 }
 
 // --- 3. encode ---------------------------------------------------------------
-// list entry e lives in lane e/4, byte e%4 of `v`.
+// MTF as dominance counting.  Give every position i of the chunk the index
+// P[i] of the previous occurrence of its symbol (virtual times -256..-1 for the
+// symbols of the start list: the symbol at list position q "occurred" at -1-q).
+// The P values are distinct, and
+//     mtf[i] = #{ j in (P[i], i) : P[j] < P[i] }
+// (the symbols whose first occurrence after P[i] lies before i).  A wave evaluates
+// 64 positions at once:
+//   * j in earlier batches:  P[j] marks a "killed" timestamp; a 4352-bit bitmap of
+//     killed timestamps + per-word prefix counts in LDS answers
+//     #{j < base : P[j] < P[i]} with two LDS reads and a popcount; the j <= P[i]
+//     part of it is exactly P[i]+1.
+//   * j in the same batch:   T = #{k < lane : P[k] < P[lane]} by a 64-step
+//     readlane / compare / add-with-carry loop (3 VALU per step for 64 outputs).
+// No per-byte serial dependency chain and almost no scalar-unit work: the previous
+// kernel (one list rotation per input byte) was bound by instruction issue.
 template <bool WITH_HIST>
 __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__restrict__ in,
                                                               size_t in_stride, uint32_t n,
@@ -114,48 +128,89 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
                                                               uint8_t *__restrict__ out, size_t out_stride,
                                                               uint32_t *__restrict__ sub_hist)
 {
+    constexpr int NW = (MTF_CHUNK + 256) / 64;                 // 68 bitmap words
     __shared__ uint32_t s_hist[WITH_HIST ? MTF_WAVES : 1][256];
+    __shared__ int s_last[MTF_WAVES][256];
+    __shared__ unsigned long long s_bm[MTF_WAVES][NW + 4];
+    __shared__ uint32_t s_cum[MTF_WAVES][NW + 4];
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const uint32_t chunk = blockIdx.x * MTF_WAVES + w;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
     if (chunk >= nchunks) return;
-    const uint32_t lo = chunk * MTF_CHUNK, hi = min(n, lo + MTF_CHUNK);
-    const uint8_t *src = in + (size_t)b * in_stride;
-    uint8_t *dst = out + (size_t)b * out_stride;
-    uint32_t v = reinterpret_cast<const uint32_t *>(lists + ((size_t)b * max_chunks + chunk) * 256)[l];
-    if (WITH_HIST) {
-        for (int i = l; i < 256; i += 64) s_hist[w][i] = 0;
+    const uint32_t lo = chunk * MTF_CHUNK, C = min(n, lo + MTF_CHUNK) - lo;
+    const uint8_t *src = in + (size_t)b * in_stride + lo;
+    uint8_t *dst = out + (size_t)b * out_stride + lo;
+    int *last = s_last[w];
+    unsigned long long *bm = s_bm[w];
+    uint32_t *cum = s_cum[w];
+    {
+        const uint32_t lw = reinterpret_cast<const uint32_t *>(lists + ((size_t)b * max_chunks + chunk) * 256)[l];
+#pragma unroll
+        for (int j = 0; j < 4; j++) last[(lw >> (8 * j)) & 0xFF] = -1 - (int)(4 * l + j);
+        bm[l] = 0; cum[l] = 0;
+        if (l < NW + 4 - 64) { bm[64 + l] = 0; cum[64 + l] = 0; }
+        if (WITH_HIST) for (int i = l; i < 256; i += 64) s_hist[w][i] = 0;
         __builtin_amdgcn_wave_barrier();
     }
-    for (uint32_t p0 = lo; p0 < hi; p0 += 64) {
-        const uint32_t cntv = min(64u, hi - p0);
-        const uint32_t inb = (p0 + l < hi) ? src[p0 + l] : 0u;
-        uint32_t outb = 0;
-        for (uint32_t j = 0; j < cntv; j++) {
-            const uint32_t x = __builtin_amdgcn_readlane(inb, j);            // uniform
-            const uint32_t z = v ^ (x * 0x01010101u);
-            const uint32_t hz = (z - 0x01010101u) & ~z & 0x80808080u;         // 0x80 in every zero byte
-            const uint64_t bal = __ballot(hz != 0);
-            const uint32_t L = (uint32_t)__builtin_ctzll(bal);                // lane holding x
-            const uint32_t hzl = __builtin_amdgcn_readlane(hz, L);
-            const uint32_t bidx = (uint32_t)__builtin_ctz(hzl) >> 3;          // byte within that lane
-            const uint32_t pos = 4 * L + bidx;
-            outb = (l == j) ? pos : outb;
-            // entries [0, pos) move up by one, x goes to the front.  Branch-free: for
-            // pos == 0 the masked merge rewrites byte 0 of lane 0 with x itself.
-            // carry-in = top byte of the previous lane (DPP wave_shr:1, a VALU op -- no LDS
-            // round trip on the per-byte critical path); lane 0 keeps `old` = x.
-            const uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)(v >> 24), 0x138, 0xf, 0xf, false);
-            const uint32_t shifted = (v << 8) | carry;
-            const uint32_t m2 = (bidx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (bidx + 1))) - 1u);   // uniform
-            const uint32_t mask = (l < L) ? 0xFFFFFFFFu : ((l == L) ? m2 : 0u);
-            v = (v & ~mask) | (shifted & mask);
+    const uint64_t lt_mask = (1ull << l) - 1ull;
+    for (uint32_t base = 0; base < C; base += 64) {
+        const uint32_t i = base + l;
+        const bool valid = i < C;
+        const uint32_t sym = valid ? src[i] : 0u;
+        // lanes of this batch holding the same symbol
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            const bool set = (sym >> bit) & 1u;
+            const uint64_t bal = __ballot(set);
+            peers &= set ? bal : ~bal;
         }
-        if (p0 + l < hi) {
-            dst[p0 + l] = (uint8_t)outb;
-            if (WITH_HIST) atomicAdd(&s_hist[w][outb], 1u);     // once per 64 bytes, off the serial chain
+        const uint64_t before = peers & lt_mask;
+        const bool hasprev = before != 0;
+        const int p = 63 - __builtin_clzll(before | 1ull);                       // previous lane with my symbol
+        const bool last_in_batch = (peers >> l) == 1ull;
+        const int P = hasprev ? (int)base + p : last[sym];
+        // T = #{k < l : P[k] < P[l]}
+        // the (biased, strictly positive) P values slide up one lane per step (DPP wave_shr:1,
+        // lanes with no source read 0), so lane l meets P[l-1], P[l-2], ... P[0]; counting the
+        // LARGER ones lets the zero fill drop out: T = #{k < l : P[k] < P[l]} = l - G
+        const uint32_t Pb = (uint32_t)(P + 257);
+        uint32_t G = 0, slide = Pb;
+#pragma unroll
+        for (int k = 0; k < 63; k++) {
+            slide = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)slide, 0x138, 0xf, 0xf, true);
+            G += (slide > Pb) ? 1u : 0u;
         }
+        const uint32_t T = l - G;
+        uint32_t o;
+        if (hasprev) o = T - (uint32_t)(p + 1);
+        else {
+            const uint32_t bitx = (uint32_t)(P + 256), wd = bitx >> 6, r = bitx & 63;
+            const uint32_t kb = cum[wd] + (uint32_t)__popcll(bm[wd] & ((1ull << r) - 1ull));
+            o = T + kb - (uint32_t)(P + 1);           // signed: virtual P adds the -1-P start-list symbols ahead of x
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            dst[i] = (uint8_t)o;
+            if (WITH_HIST) atomicAdd(&s_hist[w][o], 1u);
+            const uint32_t bitx = (uint32_t)(P + 256);
+            atomicOr(&bm[bitx >> 6], 1ull << (bitx & 63));                       // timestamp P is killed by i
+            if (last_in_batch) last[sym] = (int)i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // prefix counts of the killed-timestamp bitmap
+        {
+            const uint32_t c = (uint32_t)__popcll(bm[l]);
+            const uint32_t inc = wave_incl_add(c);
+            cum[l] = inc - c;
+            const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
+            if (l == 0) {
+                uint32_t run = tot;
+                for (int q = 64; q < NW; q++) { cum[q] = run; run += (uint32_t)__popcll(bm[q]); }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (WITH_HIST) {
         __builtin_amdgcn_wave_barrier();

@@ -39,6 +39,15 @@ def rand_1m():
     return O.glibc_rand_bytes(1 << 20, 255)          # test_compress.cpp:552-556
 
 
+def _planted():
+    x = datagen.zipf_bytes(200000, seed=77)
+    motif = datagen.zipf_bytes(300, seed=78)
+    for p in (1000, 50000, 50400, 120000, 199000):
+        x[p:p + 300] = motif
+    x[150000:150700] = 7
+    return x
+
+
 def edge_inputs():
     rng = np.random.default_rng(7)
     return {
@@ -56,6 +65,9 @@ def edge_inputs():
                                              rng.integers(0, 256, 30000, dtype=np.uint8)]),
         "two_symbols": rng.integers(0, 2, 50000, dtype=np.uint8),
         "text_64k": datagen.text_bytes(65536),
+        # mostly shallow (text-refinement rounds) with a few long planted repeats, so the sorter
+        # runs its 3 text rounds and THEN has to switch to prefix doubling for the leftovers
+        "zipf_planted_repeats": _planted(),
     }
 
 
