@@ -36,7 +36,8 @@ constexpr int      DEC_LUT_BITS = 12;
 constexpr uint32_t DEC_FLAG     = 0x80000000u;
 constexpr int      LF_TILE      = 2048;
 constexpr uint32_t LF_MASK      = (1u << 21) - 1;
-constexpr uint32_t SPLIT        = 1024;                  // LF-cycle rows between splitters
+constexpr uint32_t SPLIT        = 128;                   // LF-cycle rows between splitters
+constexpr uint32_t MAX_SPLITS   = (1u << 20) / SPLIT + 8;
 
 // ---------------------------------------------------------------------------
 // 1. tree -> 12-bit LUT + node table.  One workgroup per block.
@@ -304,8 +305,8 @@ __global__ __launch_bounds__(256) void k_ibwt_walk1(const uint32_t *__restrict__
 // text positions pos, pos-1, ...  One wave per block; the chase runs in LDS.
 __global__ __launch_bounds__(64) void k_ibwt_order(uint32_t *__restrict__ seg, uint32_t n, uint32_t max_split)
 {
-    __shared__ uint32_t s_len[1040], s_next[1040];
-    __shared__ int s_pos[1040];
+    __shared__ uint32_t s_len[MAX_SPLITS], s_next[MAX_SPLITS];
+    __shared__ int s_pos[MAX_SPLITS];
     const uint32_t b = blockIdx.x, l = threadIdx.x;
     const uint32_t rows = n + 1, nsplit = (rows + SPLIT - 1) / SPLIT;
     uint32_t *S = seg + (size_t)b * max_split * 4;
@@ -397,7 +398,7 @@ hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t 
     const size_t lf_stride = (size_t)s.nmax + 4;
     hipLaunchKernelGGL(k_ibwt_hist, dim3(tiles, nblk), dim3(256), 0, st, s.bwt, (size_t)s.nmax, d_bwt_index, n,
                        s.tile_hist, s.max_tiles);
-    GLC_TRY(tile_hist_scan9(st, s.tile_hist, rows, s.digit_base, s.max_tiles, nblk));
+    GLC_TRY(tile_hist_scan9(st, s.tile_hist, rows, s.digit_base, s.max_tiles, nblk, LF_TILE));
     hipLaunchKernelGGL(k_ibwt_lf, dim3(tiles, nblk), dim3(256), 0, st, s.bwt, (size_t)s.nmax, d_bwt_index, n,
                        s.tile_hist, s.digit_base, s.max_tiles, s.lf, lf_stride);
     hipLaunchKernelGGL(k_ibwt_walk1, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,

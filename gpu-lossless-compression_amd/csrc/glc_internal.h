@@ -118,7 +118,7 @@ struct DecodeScratch {
     size_t    bytes = 0;
 };
 hipError_t tile_hist_scan9(hipStream_t st, uint32_t *tile_hist, uint32_t count, uint32_t *digit_base,
-                           uint32_t max_tiles, uint32_t nblk);
+                           uint32_t max_tiles, uint32_t nblk, uint32_t tile_elems);
 hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows);
 void       decode_scratch_free(DecodeScratch &s);
 hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist,
