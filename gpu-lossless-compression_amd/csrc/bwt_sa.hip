@@ -363,6 +363,210 @@ __global__ __launch_bounds__(512) void k_sa_aggscan(uint4 *__restrict__ tile_agg
     }
 }
 
+// ---------------------------------------------------------------------------
+// Single-pass version of the step above: one kernel per round instead of
+// mark + scan + apply.  Tiles of a block take tickets in arrival order and chain
+// their (last head, #unresolved, #unresolved groups) prefix through 8-byte
+// {flag, value} granules with a wave-parallel decoupled look-back (agent-scope
+// relaxed atomics: the granule IS the flag, so no fence is needed).  The sorted
+// words are staged through LDS once; the BWT byte T[SA-1] is gathered here, so
+// there is no separate gather kernel and (unless the caller wants it) no second
+// pass over the suffix array.
+// ---------------------------------------------------------------------------
+constexpr uint64_t LB_AGG = 1ull << 62, LB_PFX = 2ull << 62, LB_FLAGS = 3ull << 62;
+
+__device__ __forceinline__ uint64_t lb_pack(uint32_t head, uint32_t uc, uint32_t uh)
+{
+    return ((uint64_t)head << 41) | ((uint64_t)uc << 20) | (uint64_t)uh;
+}
+__device__ __forceinline__ uint64_t lb_combine(uint64_t earlier, uint64_t later)
+{   // flags stripped; head = max, counts add (fields cannot overflow: uc <= 2^20, uh <= 2^19)
+    const uint64_t he = earlier >> 41, hl = later >> 41;
+    const uint64_t cnts = (earlier & ((1ull << 41) - 1)) + (later & ((1ull << 41) - 1));
+    return ((he > hl ? he : hl) << 41) | cnts;
+}
+
+__global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restrict__ key,
+                                                         const uint32_t *__restrict__ pos,
+                                                         const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                         unsigned long long *__restrict__ tile_state,
+                                                         uint32_t *__restrict__ ticket,
+                                                         uint32_t *__restrict__ isa, uint32_t *__restrict__ sa,
+                                                         uint64_t *__restrict__ key_next,
+                                                         uint32_t *__restrict__ pos_next,
+                                                         uint32_t *__restrict__ hd_next,
+                                                         uint32_t *__restrict__ cnt_next,
+                                                         uint32_t *__restrict__ d_max_cnt,
+                                                         uint32_t nmax, uint32_t max_tiles, int mode,
+                                                         const uint8_t *__restrict__ text, size_t text_stride,
+                                                         uint32_t n, uint32_t depth,
+                                                         uint8_t *__restrict__ bwt_out, size_t bwt_stride,
+                                                         int *__restrict__ d_index, uint32_t *__restrict__ d_err)
+{
+    // LK(1 + i) = word of tile element i; one pad slot per 8 words so the blocked (8 per thread) reads
+    // are bank-conflict free (lane stride 72 B instead of 64 B = 16-way conflict on ds_read_b64)
+#define LK(j) s_k[(j) + ((j) >> 3)]
+    __shared__ uint64_t s_k[SA_TILE + 2 + (SA_TILE + 2) / 8 + 1];
+    __shared__ uint32_t s_tmp[12];
+    __shared__ uint32_t s_tile;
+    __shared__ uint64_t s_excl;
+    const uint32_t tid = threadIdx.x;
+    // (an XCD-aware remap -- all tiles of a block on one XCD so its text stays in that L2 -- was
+    //  measured slower on MI355X: 17.5 vs 16.3 ms per 256 blocks; plain dispatch order is kept)
+    const uint32_t b = blockIdx.y;
+    const uint32_t m = live_count(cnt, nfixed, b);
+    if (tid == 0) s_tile = atomicAdd(&ticket[b], 1u);
+    __syncthreads();
+    const uint32_t t = s_tile, base = t * SA_TILE;
+    if (base >= m) return;
+    const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
+    const uint64_t *K = key + (size_t)b * nmax;
+    const uint32_t *P = pos ? pos + (size_t)b * nmax : nullptr;
+    for (uint32_t i = tid; i < SA_TILE + 2; i += SA_THREADS) {
+        const int64_t g = (int64_t)base - 1 + i;
+        LK(i) = (g >= 0 && g < (int64_t)m) ? K[g] : 0ull;
+    }
+    __syncthreads();
+    const uint32_t l0 = tid * SA_ITEMS, e0 = base + l0;
+    uint32_t headm = 0, unresm = 0, lh = 0, uc = 0, uh = 0;
+#pragma unroll
+    for (int i = 0; i < SA_ITEMS; i++) {
+        const uint32_t e = e0 + i;
+        if (e < m) {
+            const uint64_t kp = LK(l0 + i) >> VAL_BITS, kc = LK(l0 + i + 1) >> VAL_BITS, kn = LK(l0 + i + 2) >> VAL_BITS;
+            const bool head = (e == 0) || (kc != kp);
+            const bool nhead = (e + 1 >= m) || (kn != kc);
+            if (head) { headm |= 1u << i; lh = e; }
+            if (!(head && nhead)) { unresm |= 1u << i; uc++; if (head) uh++; }
+        }
+    }
+    // thread-exclusive prefixes within the tile + tile aggregate
+    const uint32_t carry_t = block_excl_max<SA_THREADS>(lh, s_tmp);
+    uint32_t tile_uc = 0, tile_uh = 0;
+    const uint32_t off_t = block_excl_add<SA_THREADS>(uc, s_tmp, &tile_uc);
+    const uint32_t goff_t = block_excl_add<SA_THREADS>(uh, s_tmp, &tile_uh);
+    uint32_t mx = wave_max(lh);
+    __syncthreads();
+    if ((tid & 63) == 0) s_tmp[tid >> 6] = mx;
+    __syncthreads();
+    const uint32_t tile_lh = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
+
+    // ---- decoupled look-back over the tiles of this block (wave 0) ----
+    unsigned long long *ST = tile_state + (size_t)b * max_tiles;
+    if (tid < 64) {
+        const uint64_t agg = lb_pack(tile_lh, tile_uc, tile_uh);
+        uint64_t excl = 0;
+        if (t == 0) {
+            if (tid == 0) __hip_atomic_store(&ST[0], LB_PFX | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (tid == 0) __hip_atomic_store(&ST[t], LB_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = (int)t - 1;
+            uint32_t spins = 0;
+            bool bad = false;
+            for (;;) {
+                const int idx = look - (int)tid;
+                uint64_t g = LB_PFX;                                      // lanes past tile 0: identity prefix
+                if (idx >= 0) g = __hip_atomic_load(&ST[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any((g & LB_FLAGS) == 0)) {                         // a predecessor has not published yet
+                    if (++spins > (1u << 24)) { bad = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                const uint64_t pm = __ballot((g & LB_FLAGS) == LB_PFX);
+                const uint32_t first = pm ? (uint32_t)__builtin_ctzll(pm) : 63u;   // nearest lane holding a full prefix
+                uint64_t val = (tid <= first) ? (g & ~LB_FLAGS) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t lo = __shfl_xor((uint32_t)val, o, 64), hi = __shfl_xor((uint32_t)(val >> 32), o, 64);
+                    val = lb_combine(val, ((uint64_t)hi << 32) | lo);
+                }
+                excl = lb_combine(val, excl);
+                if (pm) break;
+                look -= 64;
+            }
+            if (bad && tid == 0) atomicOr(d_err, 4u);
+            if (tid == 0)
+                __hip_atomic_store(&ST[t], LB_PFX | lb_combine(excl, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) {
+            s_excl = excl;
+            if (t + 1 == ntiles) {                                        // inclusive total of the block
+                const uint32_t total = (uint32_t)((lb_combine(excl, agg) >> 20) & 0x1FFFFF);
+                cnt_next[b] = total;
+                if (total) { atomicMax(d_max_cnt, total); atomicAdd(d_max_cnt + 1, total); }
+            }
+        }
+    }
+    __syncthreads();
+    const uint64_t excl = s_excl;
+    const uint32_t carry = max(carry_t, (uint32_t)(excl >> 41));
+    uint32_t off = (uint32_t)((excl >> 20) & 0x1FFFFF) + off_t;
+    uint32_t gcount = (uint32_t)(excl & 0xFFFFF) + goff_t;
+
+    uint32_t *ISA = isa + (size_t)b * nmax, *SAo = sa + (size_t)b * nmax;
+    uint64_t *KN = key_next + (size_t)b * nmax;
+    uint32_t *PN = pos_next + (size_t)b * nmax;
+    uint32_t *HN = hd_next + (size_t)b * nmax;
+    const uint8_t *T = text + (size_t)b * text_stride;
+    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride : nullptr;
+    uint32_t running = carry;
+    uint32_t packed[SA_ITEMS / 4] = {};
+#pragma unroll
+    for (int i = 0; i < SA_ITEMS; i++) {
+        const uint32_t e = e0 + i;
+        if (e < m) {
+            const bool head = headm & (1u << i), unres = unresm & (1u << i);
+            if (head) running = e;
+            const uint32_t grp = P ? P[running] : running;    // SA slot of the group head
+            const uint32_t v = (uint32_t)(LK(l0 + i + 1) & VAL_MASK);
+            const uint32_t slot = P ? P[e] : e;
+            if (P) SAo[slot] = v;                             // round 0 (slot == e) goes out coalesced below
+            if (O) {
+                uint8_t c;
+                if (v == 0) { c = T[n - 1]; d_index[b] = (int)slot; }
+                else c = T[v - 1];
+                if (P) O[slot] = c;
+                else packed[i >> 2] |= (uint32_t)c << (8 * (i & 3));
+            }
+            if (mode == MODE_ISA) {
+                ISA[v] = grp + 1;
+                if (unres) {
+                    PN[off] = slot;
+                    KN[off] = ((uint64_t)(grp + 1) << R1_SHIFT) | v;
+                    off++;
+                }
+            } else {
+                if (head && unres) gcount++;
+                if (unres) {
+                    const uint32_t p0 = v + depth;
+                    const uint32_t c0 = p0 < n ? (uint32_t)T[p0] + 1 : 0u;
+                    const uint32_t c1 = p0 + 1 < n ? (uint32_t)T[p0 + 1] + 1 : 0u;
+                    const uint32_t c2 = p0 + 2 < n ? (uint32_t)T[p0 + 2] + 1 : 0u;
+                    const uint64_t code = ((uint64_t)c0 * 257 + c1) * 257 + c2;
+                    PN[off] = slot;
+                    HN[off] = grp;
+                    KN[off] = ((uint64_t)(gcount - 1) << TXT_GRP_SHIFT) | (code << TXT_CODE_SHIFT) | v;
+                    off++;
+                }
+            }
+        }
+    }
+    if (!P) {                                                 // round 0: SA[e] = v, transposed through LDS
+        __syncthreads();                                      // everyone is done reading the words
+        for (uint32_t i = tid; i < SA_TILE; i += SA_THREADS)
+            if (base + i < m) SAo[base + i] = (uint32_t)(LK(i + 1) & VAL_MASK);
+    }
+    if (O && !P) {                                            // round 0: slot == e, 8 consecutive bytes per thread
+        const bool al = ((reinterpret_cast<uintptr_t>(O) & 3) == 0);
+#pragma unroll
+        for (int q = 0; q < SA_ITEMS / 4; q++) {
+            const uint32_t e = e0 + 4 * q;
+            if (e + 3 < m && al) *reinterpret_cast<uint32_t *>(O + e) = packed[q];
+            else for (int j = 0; j < 4; j++) if (e + j < m) O[e + j] = (uint8_t)(packed[q] >> (8 * j));
+        }
+    }
+}
+
 // switch from text refinement to prefix doubling: ranks of every suffix in the order
 // established so far.  Resolved suffixes: rank = own SA slot + 1 ...
 __global__ __launch_bounds__(256) void k_isa_init(const uint32_t *__restrict__ sa, uint32_t *__restrict__ isa,
@@ -463,10 +667,12 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.max_tiles * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.tile_agg, (size_t)rows * s.max_tiles * sizeof(uint4)));
+    GLC_TRY(A((void **)&s.tile_state, (size_t)rows * s.max_tiles * 8));
+    GLC_TRY(A((void **)&s.ticket, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.hdA, ne * 4)); GLC_TRY(A((void **)&s.hdB, ne * 4));
     GLC_TRY(A((void **)&s.cntA, (size_t)rows * 4)); GLC_TRY(A((void **)&s.cntB, (size_t)rows * 4));
-    GLC_TRY(A((void **)&s.d_max_cnt, 8));
-    GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 8, hipHostMallocDefault));
+    GLC_TRY(A((void **)&s.d_max_cnt, 16));
+    GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 16, hipHostMallocDefault));
     s.bytes = total;
     return hipSuccess;
 }
@@ -474,7 +680,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 void sa_scratch_free(SaScratch &s)
 {
     void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base,
-                  s.tile_agg, s.cntA, s.cntB, s.d_max_cnt};
+                  s.tile_agg, s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
     for (auto &e : s.prof_ev) if (e) (void)hipEventDestroy(e);
@@ -519,7 +725,7 @@ static hipError_t radix_pass(hipStream_t st, const uint64_t *in, uint64_t *out, 
 }
 
 hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
-                    SaScratch &s, int *rounds_out)
+                    SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out)
 {
     if (n == 0 || n > s.nmax || n > MAX_BLOCK_ELEMS || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     uint32_t tiles = (n + SA_TILE - 1) / SA_TILE;
@@ -549,20 +755,22 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     }
     for (;;) {
         dim3 g(tiles, nblk);
-        GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 8, st));
-        hipLaunchKernelGGL(k_sa_rank<false>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live, s.tile_agg,
-                           s.isa, s.sa, alt, pos_next, hd_next, s.nmax, s.max_tiles, mode, text, text_stride, n, depth);
-        hipLaunchKernelGGL(k_sa_aggscan, dim3(nblk), dim3(512), 0, st, s.tile_agg, cnt_cur, live, cnt_next,
-                           s.d_max_cnt, s.max_tiles);
-        hipLaunchKernelGGL(k_sa_rank<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live, s.tile_agg,
-                           s.isa, s.sa, alt, pos_next, hd_next, s.nmax, s.max_tiles, mode, text, text_stride, n, depth);
+        GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 16, st));
+        GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
+        GLC_TRY(hipMemsetAsync(cnt_next, 0, (size_t)nblk * 4, st));   // blocks with nothing left launch no tile
+        GLC_TRY(hipMemsetAsync(s.tile_state, 0, (size_t)nblk * s.max_tiles * 8, st));
+        hipLaunchKernelGGL(k_sa_rank1, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
+                           (unsigned long long *)s.tile_state, s.ticket, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
+                           s.d_max_cnt, s.nmax, s.max_tiles, mode, text, text_stride, n, depth, bwt_out, bwt_stride,
+                           d_index, s.d_max_cnt + 2);
         GLC_TRY(hipGetLastError());
-        GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 8, hipMemcpyDeviceToHost, st));
+        GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 16, hipMemcpyDeviceToHost, st));
         GLC_TRY(hipStreamSynchronize(st));
         if (s.prof) prof_collect(s);
         rounds++;
         const uint32_t maxc = s.h_max_cnt[0];
         live_total = (double)s.h_max_cnt[1];
+        if (s.h_max_cnt[2]) return hipErrorUnknown;               // a look-back spin hit its bound
         if (maxc == 0) break;
         if (depth >= 2u * n + 16u) return hipErrorUnknown;        // cannot happen: depth >= n resolves everything
         // next round works on the compacted list that k_sa_rank<true> wrote into `alt`

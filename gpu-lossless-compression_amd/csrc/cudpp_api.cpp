@@ -221,8 +221,7 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     hipStream_t st = p->stream;
     StageTimer tm(p);
     tm.mark(0);
-    hipError_t e = sa_build(st, d_uncompressed, n, n, nb, p->sa);
-    if (e == hipSuccess) e = bwt_gather(st, d_uncompressed, n, p->sa.sa, p->sa.nmax, n, nb, p->d_bwt, p->n, d_bwtIndex);
+    hipError_t e = sa_build(st, d_uncompressed, n, n, nb, p->sa, p->d_bwt, p->n, d_bwtIndex);
     tm.mark(1);
     if (e == hipSuccess) e = mtf_forward(st, p->d_bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
     tm.mark(2);
@@ -245,8 +244,7 @@ CUDPPResult glcBwtBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsig
     if (numElements == 0 || numElements > p->n || numBlocks == 0 || numBlocks > p->rows)
         return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     const uint32_t n = (uint32_t)numElements, nb = (uint32_t)numBlocks;
-    hipError_t e = sa_build(p->stream, d_in, n, n, nb, p->sa);
-    if (e == hipSuccess) e = bwt_gather(p->stream, d_in, n, p->sa.sa, p->sa.nmax, n, nb, d_out, n, d_index);
+    hipError_t e = sa_build(p->stream, d_in, n, n, nb, p->sa, d_out, n, d_index);
     return hip_result(e);
 }
 

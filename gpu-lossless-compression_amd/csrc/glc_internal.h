@@ -29,6 +29,8 @@ struct SaScratch {
     uint32_t *tile_hist = nullptr;               // [rows][max_tiles][512]
     uint32_t *digit_base = nullptr;              // [rows][512]
     uint4    *tile_agg = nullptr;                // [rows][max_tiles]
+    uint64_t *tile_state = nullptr;              // [rows][max_tiles] look-back granules {flag:2, head:21, unres:21, groups:20}
+    uint32_t *ticket = nullptr;                  // [rows] tile tickets of the single-pass rank kernel
     uint32_t *hdA = nullptr, *hdB = nullptr;     // [rows][nmax] SA slot of the group head of each unresolved entry
     uint32_t *cntA = nullptr, *cntB = nullptr;   // [rows] unresolved counts
     uint32_t *d_max_cnt = nullptr;               // [2] max and sum of the unresolved counts
@@ -50,8 +52,11 @@ void       sa_scratch_free(SaScratch &s);
 
 // Suffix arrays of `nblk` blocks of n bytes (block b at text + b*text_stride).
 // Result in s.sa[b*nmax ..].  Synchronises the stream once per doubling round.
+// If bwt_out != nullptr the BWT bytes (L[i] = SA[i]==0 ? T[n-1] : T[SA[i]-1]) and d_index[b] are
+// produced on the way (bwt_compute_final_kernel, compress_kernel.cuh:55-74) -- no separate gather.
 hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
-                    SaScratch &s, int *rounds_out = nullptr);
+                    SaScratch &s, uint8_t *bwt_out = nullptr, size_t bwt_stride = 0, int *d_index = nullptr,
+                    int *rounds_out = nullptr);
 
 // L[i] = SA[i]==0 ? T[n-1] : T[SA[i]-1];  index[b] = i with SA[i]==0
 hipError_t bwt_gather(hipStream_t st, const uint8_t *text, size_t text_stride, const uint32_t *sa,
