@@ -71,30 +71,41 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_init_keys(const uint8_t *__re
 
 // ---------------------------------------------------------------------------
 // radix pass 1/3: per-tile digit histogram (LDS, one sub-histogram per wave)
+// The radix kernels use their own tile: RS_NT threads x 8 words.
 // ---------------------------------------------------------------------------
+constexpr int RS_NT    = 512;                    // threads per radix workgroup
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE  = RS_NT * RS_ITEMS;       // words per radix tile (longer per-digit write runs than 2048)
+constexpr int RS_WAVES = RS_NT / 64;
+
 template <int BITS>
-__global__ __launch_bounds__(SA_THREADS) void k_rs_hist(const uint64_t *__restrict__ key,
-                                                        const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                        uint32_t shift, uint32_t *__restrict__ tile_hist,
-                                                        uint32_t nmax, uint32_t max_tiles)
+__global__ __launch_bounds__(RS_NT) void k_rs_hist(const uint64_t *__restrict__ key,
+                                                   const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                   uint32_t shift, uint32_t *__restrict__ tile_hist,
+                                                   uint32_t nmax, uint32_t max_tiles)
 {
     constexpr int RADIX = 1 << BITS;
-    __shared__ uint32_t s_h[4][RADIX];
+    __shared__ uint32_t s_h[RS_WAVES][RADIX];
     const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
-    const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
+    const uint32_t m = live_count(cnt, nfixed, b), base = t * RS_TILE;
     if (base >= m) return;
-    const uint32_t tile_n = min((uint32_t)SA_TILE, m - base);
-    for (uint32_t i = tid; i < 4 * RADIX; i += SA_THREADS) (&s_h[0][0])[i] = 0;
+    const uint32_t tile_n = min((uint32_t)RS_TILE, m - base);
+    for (uint32_t i = tid; i < RS_WAVES * RADIX; i += RS_NT) (&s_h[0][0])[i] = 0;
     __syncthreads();
     const uint64_t *K = key + (size_t)b * nmax + base;
 #pragma unroll
-    for (int r = 0; r < SA_ITEMS; r++) {
-        uint32_t i = r * SA_THREADS + tid;
+    for (int r = 0; r < RS_ITEMS; r++) {
+        uint32_t i = r * RS_NT + tid;
         if (i < tile_n) atomicAdd(&s_h[w][(uint32_t)(K[i] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
     uint32_t *H = tile_hist + ((size_t)b * max_tiles + t) * SA_MAXRADIX;
-    for (uint32_t d = tid; d < RADIX; d += SA_THREADS) H[d] = s_h[0][d] + s_h[1][d] + s_h[2][d] + s_h[3][d];
+    for (uint32_t d = tid; d < RADIX; d += RS_NT) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < RS_WAVES; q++) c += s_h[q][d];
+        H[d] = c;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -134,35 +145,35 @@ __global__ __launch_bounds__(512) void k_rs_scan(uint32_t *__restrict__ tile_his
 // global writes are runs of consecutive addresses per digit.
 // ---------------------------------------------------------------------------
 template <int BITS>
-__global__ __launch_bounds__(SA_THREADS) void k_rs_scatter(const uint64_t *__restrict__ key_in,
-                                                           uint64_t *__restrict__ key_out,
-                                                           const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                           uint32_t shift,
-                                                           const uint32_t *__restrict__ tile_hist,
-                                                           const uint32_t *__restrict__ digit_base,
-                                                           uint32_t nmax, uint32_t max_tiles)
+__global__ __launch_bounds__(RS_NT) void k_rs_scatter(const uint64_t *__restrict__ key_in,
+                                                      uint64_t *__restrict__ key_out,
+                                                      const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                      uint32_t shift,
+                                                      const uint32_t *__restrict__ tile_hist,
+                                                      const uint32_t *__restrict__ digit_base,
+                                                      uint32_t nmax, uint32_t max_tiles)
 {
     constexpr int RADIX = 1 << BITS;
-    constexpr int DPT = RADIX / SA_THREADS;                 // digits per thread in the prefix step
-    __shared__ uint32_t s_wc[4][RADIX];
+    static_assert(RADIX <= RS_NT, "one digit per thread in the prefix step");
+    __shared__ uint32_t s_wc[RS_WAVES][RADIX];
     __shared__ uint32_t s_gbase[RADIX];
-    __shared__ uint64_t s_key[SA_TILE];
-    __shared__ uint32_t s_tmp[8];
+    __shared__ uint64_t s_key[RS_TILE];
+    __shared__ uint32_t s_tmp[RS_WAVES + 1];
     const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
+    const uint32_t m = live_count(cnt, nfixed, b), base = t * RS_TILE;
     if (base >= m) return;
-    const uint32_t tile_n = min((uint32_t)SA_TILE, m - base);
+    const uint32_t tile_n = min((uint32_t)RS_TILE, m - base);
     const uint64_t *K = key_in + (size_t)b * nmax + base;
     uint64_t *KO = key_out + (size_t)b * nmax;
 
-    for (uint32_t i = tid; i < 4 * RADIX; i += SA_THREADS) (&s_wc[0][0])[i] = 0;
+    for (uint32_t i = tid; i < RS_WAVES * RADIX; i += RS_NT) (&s_wc[0][0])[i] = 0;
     __syncthreads();
 
-    uint64_t k[SA_ITEMS];
-    uint32_t rk[SA_ITEMS];
+    uint64_t k[RS_ITEMS];
+    uint32_t rk[RS_ITEMS];
 #pragma unroll
-    for (int r = 0; r < SA_ITEMS; r++) {
-        const uint32_t i = w * (SA_TILE / 4) + r * 64 + l;
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
         const bool valid = i < tile_n;
         k[r] = valid ? K[i] : 0ull;
         const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
@@ -183,31 +194,23 @@ __global__ __launch_bounds__(SA_THREADS) void k_rs_scatter(const uint64_t *__res
     __syncthreads();
 
     // tile-local bucket starts (exclusive scan over digits), per-wave starts, global bases
-    uint32_t c[DPT][4], tot[DPT], tsum = 0;
+    uint32_t c[RS_WAVES], tot = 0;
+    if (tid < RADIX) {
 #pragma unroll
-    for (int q = 0; q < DPT; q++) {
-        const uint32_t d = tid * DPT + q;
-        c[q][0] = s_wc[0][d]; c[q][1] = s_wc[1][d]; c[q][2] = s_wc[2][d]; c[q][3] = s_wc[3][d];
-        tot[q] = c[q][0] + c[q][1] + c[q][2] + c[q][3];
-        tsum += tot[q];
+        for (int q = 0; q < RS_WAVES; q++) { c[q] = s_wc[q][tid]; tot += c[q]; }
     }
-    uint32_t run = block_excl_add<SA_THREADS>(tsum, s_tmp);
-    const uint32_t *TH = tile_hist + ((size_t)b * max_tiles + t) * SA_MAXRADIX;
-    const uint32_t *DB = digit_base + (size_t)b * SA_MAXRADIX;
+    uint32_t run = block_excl_add<RS_NT>(tot, s_tmp);
+    if (tid < RADIX) {
+        const uint32_t *TH = tile_hist + ((size_t)b * max_tiles + t) * SA_MAXRADIX;
+        const uint32_t *DB = digit_base + (size_t)b * SA_MAXRADIX;
+        s_gbase[tid] = DB[tid] + TH[tid] - run;
 #pragma unroll
-    for (int q = 0; q < DPT; q++) {
-        const uint32_t d = tid * DPT + q;
-        s_wc[0][d] = run;
-        s_wc[1][d] = run + c[q][0];
-        s_wc[2][d] = run + c[q][0] + c[q][1];
-        s_wc[3][d] = run + c[q][0] + c[q][1] + c[q][2];
-        s_gbase[d] = DB[d] + TH[d] - run;
-        run += tot[q];
+        for (int q = 0; q < RS_WAVES; q++) { s_wc[q][tid] = run; run += c[q]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SA_ITEMS; r++) {
-        const uint32_t i = w * (SA_TILE / 4) + r * 64 + l;
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
         if (i < tile_n) {
             const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
             s_key[s_wc[w][d] + rk[r]] = k[r];
@@ -215,8 +218,174 @@ __global__ __launch_bounds__(SA_THREADS) void k_rs_scatter(const uint64_t *__res
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SA_ITEMS; r++) {
-        const uint32_t p = r * SA_THREADS + tid;
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t p = r * RS_NT + tid;
+        if (p < tile_n) {
+            const uint64_t kk = s_key[p];
+            const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
+            KO[s_gbase[d] + p] = kk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Onesweep form of the radix pass: no per-pass histogram/scan kernels.
+//   k_rs_prehist   ONE read of the words gives the per-block digit totals of every pass
+//                  of the sort (LSD totals do not depend on the order of the words).
+//   k_rs_digitbase exclusive scan of those totals.
+//   k_rs_onesweep  the stable scatter above, but the tile's per-digit offset comes from a
+//                  decoupled look-back over the earlier tiles of the block: thread d owns
+//                  digit d and chains 4-byte granules {epoch:8 | flag:2 | count:22}
+//                  (agent-scope relaxed atomics; the granule is its own flag).  Tiles take
+//                  tickets in arrival order, so a tile only ever waits for tiles that are
+//                  already running.  The epoch tag makes stale granules of earlier launches
+//                  invisible, so the state array is cleared only once per 255 launches.
+// ---------------------------------------------------------------------------
+struct PassPlan { uint32_t npass; uint32_t shift[5]; uint32_t bits[5]; };
+constexpr int RS_MAXPASS = 5;
+
+__global__ __launch_bounds__(RS_NT) void k_rs_prehist(const uint64_t *__restrict__ key,
+                                                      const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                      PassPlan pp, uint32_t *__restrict__ ghist, uint32_t nmax)
+{
+    __shared__ uint32_t s_h[RS_MAXPASS][SA_MAXRADIX];
+    const uint32_t b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t m = live_count(cnt, nfixed, b);
+    if (blockIdx.x * RS_TILE >= m) return;
+    for (uint32_t i = tid; i < RS_MAXPASS * SA_MAXRADIX; i += RS_NT) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t *K = key + (size_t)b * nmax;
+    for (uint32_t base = blockIdx.x * RS_TILE; base < m; base += gridDim.x * RS_TILE) {
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const uint32_t i = base + r * RS_NT + tid;
+            if (i < m) {
+                const uint64_t k = K[i];
+                for (uint32_t p = 0; p < pp.npass; p++)
+                    atomicAdd(&s_h[p][(uint32_t)(k >> pp.shift[p]) & ((1u << pp.bits[p]) - 1u)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *G = ghist + (size_t)b * RS_MAXPASS * SA_MAXRADIX;
+    for (uint32_t i = tid; i < pp.npass * SA_MAXRADIX; i += RS_NT) {
+        const uint32_t c = (&s_h[0][0])[i];
+        if (c) atomicAdd(&G[i], c);
+    }
+}
+
+__global__ __launch_bounds__(512) void k_rs_digitbase(const uint32_t *__restrict__ ghist,
+                                                      uint32_t *__restrict__ digit_base)
+{
+    __shared__ uint32_t s_tmp[16];
+    const size_t o = ((size_t)blockIdx.x * RS_MAXPASS + blockIdx.y) * SA_MAXRADIX + threadIdx.x;
+    const uint32_t c = ghist[o];
+    digit_base[o] = block_excl_add<512>(c, s_tmp);
+}
+
+constexpr uint32_t OS_AGG = 1u << 22, OS_PFX = 2u << 22, OS_FLAGS = 3u << 22, OS_CNT = (1u << 22) - 1;
+
+template <int BITS>
+__global__ __launch_bounds__(RS_NT) void k_rs_onesweep(const uint64_t *__restrict__ key_in,
+                                                       uint64_t *__restrict__ key_out,
+                                                       const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                       uint32_t shift, uint32_t *__restrict__ state,
+                                                       uint32_t *__restrict__ ticket, uint32_t epoch,
+                                                       const uint32_t *__restrict__ digit_base, uint32_t db_stride,
+                                                       uint32_t nmax, uint32_t max_tiles,
+                                                       uint32_t *__restrict__ d_err)
+{
+    constexpr int RADIX = 1 << BITS;
+    static_assert(RADIX <= RS_NT, "one digit per thread in the look-back");
+    __shared__ uint32_t s_wc[RS_WAVES][RADIX];
+    __shared__ uint32_t s_gbase[RADIX];
+    __shared__ uint64_t s_key[RS_TILE];
+    __shared__ uint32_t s_tmp[RS_WAVES + 1];
+    __shared__ uint32_t s_tile;
+    const uint32_t b = blockIdx.y, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const uint32_t m = live_count(cnt, nfixed, b);
+    if (tid == 0) s_tile = atomicAdd(&ticket[b], 1u);
+    for (uint32_t i = tid; i < RS_WAVES * RADIX; i += RS_NT) (&s_wc[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t t = s_tile, base = t * RS_TILE;
+    if (base >= m) return;
+    const uint32_t tile_n = min((uint32_t)RS_TILE, m - base);
+    const uint64_t *K = key_in + (size_t)b * nmax + base;
+    uint64_t *KO = key_out + (size_t)b * nmax;
+
+    uint64_t k[RS_ITEMS];
+    uint32_t rk[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
+        const bool valid = i < tile_n;
+        k[r] = valid ? K[i] : 0ull;
+        const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < BITS; bit++) {
+            const bool set = (d >> bit) & 1u;
+            const uint64_t bal = __ballot(set);
+            peers &= set ? bal : ~bal;
+        }
+        const uint32_t pre = mbcnt(peers), tot = (uint32_t)__popcll(peers);
+        const uint32_t old = s_wc[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && pre == 0) s_wc[w][d] = old + tot;
+        __builtin_amdgcn_wave_barrier();
+        rk[r] = old + pre;
+    }
+    __syncthreads();
+
+    uint32_t c[RS_WAVES], tot = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int q = 0; q < RS_WAVES; q++) { c[q] = s_wc[q][tid]; tot += c[q]; }
+    }
+    // publish this tile's count of digit `tid` as soon as it is known, then look back
+    uint32_t excl = 0;
+    if (tid < RADIX) {
+        uint32_t *ST = state + ((size_t)b * max_tiles) * SA_MAXRADIX + tid;
+        const uint32_t tag = epoch << 24;
+        if (t == 0) {
+            __hip_atomic_store(&ST[0], tag | OS_PFX | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&ST[(size_t)t * SA_MAXRADIX], tag | OS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = (int)t - 1;
+            uint32_t spins = 0;
+            for (;;) {
+                const uint32_t g = __hip_atomic_load(&ST[(size_t)look * SA_MAXRADIX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((g >> 24) != epoch || (g & OS_FLAGS) == 0) {          // not published in this launch yet
+                    if (++spins > (1u << 22)) { atomicOr(d_err, 8u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                excl += g & OS_CNT;
+                if ((g & OS_FLAGS) == OS_PFX) break;
+                look--;
+            }
+            __hip_atomic_store(&ST[(size_t)t * SA_MAXRADIX], tag | OS_PFX | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    uint32_t run = block_excl_add<RS_NT>(tot, s_tmp);
+    if (tid < RADIX) {
+        s_gbase[tid] = digit_base[(size_t)b * db_stride + tid] + excl - run;
+#pragma unroll
+        for (int q = 0; q < RS_WAVES; q++) { s_wc[q][tid] = run; run += c[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
+        if (i < tile_n) {
+            const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
+            s_key[s_wc[w][d] + rk[r]] = k[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t p = r * RS_NT + tid;
         if (p < tile_n) {
             const uint64_t kk = s_key[p];
             const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
@@ -658,14 +827,16 @@ __global__ void k_sa_export(const uint32_t *__restrict__ sa, uint32_t n, uint32_
 hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 {
     s.nmax = nmax; s.rows = rows; s.max_tiles = (nmax + SA_TILE - 1) / SA_TILE;
+    s.rs_tiles = (nmax + RS_TILE - 1) / RS_TILE;
     const size_t ne = (size_t)nmax * rows;
     size_t total = 0;
     auto A = [&](void **p, size_t bytes) -> hipError_t { total += bytes; return hipMalloc(p, bytes); };
     GLC_TRY(A((void **)&s.keyA, ne * 8)); GLC_TRY(A((void **)&s.keyB, ne * 8));
     GLC_TRY(A((void **)&s.posA, ne * 4)); GLC_TRY(A((void **)&s.posB, ne * 4));
     GLC_TRY(A((void **)&s.isa, ne * 4));  GLC_TRY(A((void **)&s.sa, ne * 4));
-    GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.max_tiles * SA_MAXRADIX * 4));
-    GLC_TRY(A((void **)&s.digit_base, (size_t)rows * SA_MAXRADIX * 4));
+    GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.rs_tiles * SA_MAXRADIX * 4));
+    GLC_TRY(A((void **)&s.digit_base, (size_t)rows * RS_MAXPASS * SA_MAXRADIX * 4));
+    GLC_TRY(A((void **)&s.ghist, (size_t)rows * RS_MAXPASS * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.tile_agg, (size_t)rows * s.max_tiles * sizeof(uint4)));
     GLC_TRY(A((void **)&s.tile_state, (size_t)rows * s.max_tiles * 8));
     GLC_TRY(A((void **)&s.ticket, (size_t)rows * 4));
@@ -679,7 +850,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base,
+    void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_agg, s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
@@ -699,27 +870,42 @@ static void prof_collect(SaScratch &s)
     s.prof_used = 0;
 }
 
-template <int BITS>
-static hipError_t radix_pass(hipStream_t st, const uint64_t *in, uint64_t *out, const uint32_t *cnt,
-                             uint32_t nfixed, uint32_t shift, uint32_t tiles, uint32_t nblk, SaScratch &s,
-                             double live_total)
+// one LSD sort = prehist + digitbase + npass onesweep launches; result ends in `*cur`
+static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, const uint32_t *cnt, uint32_t nfixed,
+                             const PassPlan &pp, uint32_t tiles, uint32_t nblk, SaScratch &s, double live_total)
 {
-    dim3 g(tiles, nblk);
-    const bool prof = s.prof && BITS == 8 && s.prof_used < 64;
-    if (prof) {
-        for (int k = 0; k < 2; k++)
-            if (!s.prof_ev[2 * s.prof_used + k]) GLC_TRY(hipEventCreate(&s.prof_ev[2 * s.prof_used + k]));
-    }
-    hipLaunchKernelGGL(k_rs_hist<BITS>, g, dim3(SA_THREADS), 0, st, in, cnt, nfixed, shift, s.tile_hist,
-                       s.nmax, s.max_tiles);
-    hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(nblk), dim3(512), 0, st, s.tile_hist, cnt, nfixed,
-                       s.digit_base, s.max_tiles, (uint32_t)SA_TILE);
-    if (prof) (void)hipEventRecord(s.prof_ev[2 * s.prof_used], st);
-    hipLaunchKernelGGL(k_rs_scatter<BITS>, g, dim3(SA_THREADS), 0, st, in, out, cnt, nfixed, shift,
-                       s.tile_hist, s.digit_base, s.nmax, s.max_tiles);
-    if (prof) {
-        (void)hipEventRecord(s.prof_ev[2 * s.prof_used + 1], st);
-        s.prof_live[s.prof_used++] = live_total;
+    // `tiles` counts SA_TILE-word tiles (rank kernel); the radix kernels use RS_TILE
+    const uint32_t rs_tiles = (tiles * (uint32_t)SA_TILE + RS_TILE - 1) / RS_TILE;
+    GLC_TRY(hipMemsetAsync(s.ghist, 0, (size_t)nblk * RS_MAXPASS * SA_MAXRADIX * 4, st));
+    hipLaunchKernelGGL(k_rs_prehist, dim3(rs_tiles < 32 ? rs_tiles : 32, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed, pp,
+                       s.ghist, s.nmax);
+    hipLaunchKernelGGL(k_rs_digitbase, dim3(nblk, pp.npass), dim3(512), 0, st, s.ghist, s.digit_base);
+    for (uint32_t p = 0; p < pp.npass; p++) {
+        if (++s.epoch > 255) {                              // epoch tags wrapped: clear stale granules once
+            GLC_TRY(hipMemsetAsync(s.tile_hist, 0, (size_t)s.rows * s.rs_tiles * SA_MAXRADIX * 4, st));
+            s.epoch = 1;
+        }
+        GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
+        const bool prof = s.prof && pp.bits[p] == 8 && s.prof_used < 64;
+        if (prof) {
+            for (int k = 0; k < 2; k++)
+                if (!s.prof_ev[2 * s.prof_used + k]) GLC_TRY(hipEventCreate(&s.prof_ev[2 * s.prof_used + k]));
+            (void)hipEventRecord(s.prof_ev[2 * s.prof_used], st);
+        }
+        dim3 g(rs_tiles, nblk);
+        if (pp.bits[p] == 8)
+            hipLaunchKernelGGL(k_rs_onesweep<8>, g, dim3(RS_NT), 0, st, cur, alt, cnt, nfixed, pp.shift[p], s.tile_hist,
+                               s.ticket, s.epoch, s.digit_base + p * SA_MAXRADIX, (uint32_t)(RS_MAXPASS * SA_MAXRADIX),
+                               s.nmax, s.rs_tiles, s.d_max_cnt + 2);
+        else
+            hipLaunchKernelGGL(k_rs_onesweep<9>, g, dim3(RS_NT), 0, st, cur, alt, cnt, nfixed, pp.shift[p], s.tile_hist,
+                               s.ticket, s.epoch, s.digit_base + p * SA_MAXRADIX, (uint32_t)(RS_MAXPASS * SA_MAXRADIX),
+                               s.nmax, s.rs_tiles, s.d_max_cnt + 2);
+        if (prof) {
+            (void)hipEventRecord(s.prof_ev[2 * s.prof_used + 1], st);
+            s.prof_live[s.prof_used++] = live_total;
+        }
+        uint64_t *x = cur; cur = alt; alt = x;
     }
     return hipGetLastError();
 }
@@ -733,13 +919,11 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     double live_total = (double)n * nblk;
     hipLaunchKernelGGL(k_sa_init_keys, dim3(tiles, nblk), dim3(SA_THREADS), 0, st, text, text_stride, n, cur,
                        s.nmax);
-    // 41 key bits at [20, 61): 8+8+8+8+9
-    for (int p = 0; p < 4; p++) {
-        GLC_TRY(radix_pass<8>(st, cur, alt, nullptr, n, VAL_BITS + 8 * p, tiles, nblk, s, live_total));
-        uint64_t *x = cur; cur = alt; alt = x;
+    GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 16, st));          // [2] doubles as the device error word of the sort
+    {   // 41 key bits at [20, 61): 8+8+8+8+9
+        PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 16, VAL_BITS + 24, VAL_BITS + 32}, {8, 8, 8, 8, 9}};
+        GLC_TRY(radix_sort(st, cur, alt, nullptr, n, pp, tiles, nblk, s, live_total));
     }
-    GLC_TRY(radix_pass<9>(st, cur, alt, nullptr, n, VAL_BITS + 32, tiles, nblk, s, live_total));
-    { uint64_t *x = cur; cur = alt; alt = x; }
 
     uint32_t *cnt_cur = nullptr, *cnt_next = s.cntA, *cnt_spare = s.cntB;
     uint32_t *pos_cur = nullptr, *pos_next = s.posA, *pos_spare = s.posB;
@@ -755,7 +939,7 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     }
     for (;;) {
         dim3 g(tiles, nblk);
-        GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 16, st));
+        GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 8, st));
         GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
         GLC_TRY(hipMemsetAsync(cnt_next, 0, (size_t)nblk * 4, st));   // blocks with nothing left launch no tile
         GLC_TRY(hipMemsetAsync(s.tile_state, 0, (size_t)nblk * s.max_tiles * 8, st));
@@ -796,26 +980,16 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         }
         if (mode == MODE_TEXT) {
             // 44 key bits at [20, 64): 8+9+9+9+9
-            GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS, tiles, nblk, s, live_total));
-            { uint64_t *x = cur; cur = alt; alt = x; }
-            for (int p = 0; p < 4; p++) {
-                GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 + 9 * p, tiles, nblk, s, live_total));
-                uint64_t *x = cur; cur = alt; alt = x;
-            }
+            PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 17, VAL_BITS + 26, VAL_BITS + 35}, {8, 9, 9, 9, 9}};
+            GLC_TRY(radix_sort(st, cur, alt, cnt_cur, 0, pp, tiles, nblk, s, live_total));
             depth += 3;
             text_rounds++;
         } else {
             hipLaunchKernelGGL(k_sa_fill_rank2, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur, s.isa,
                                n, depth, s.nmax);
             // 42 key bits at [20, 62): 8+8+8+9+9
-            for (int p = 0; p < 3; p++) {
-                GLC_TRY(radix_pass<8>(st, cur, alt, cnt_cur, 0, VAL_BITS + 8 * p, tiles, nblk, s, live_total));
-                uint64_t *x = cur; cur = alt; alt = x;
-            }
-            for (int p = 0; p < 2; p++) {
-                GLC_TRY(radix_pass<9>(st, cur, alt, cnt_cur, 0, VAL_BITS + 24 + 9 * p, tiles, nblk, s, live_total));
-                uint64_t *x = cur; cur = alt; alt = x;
-            }
+            PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 16, VAL_BITS + 24, VAL_BITS + 33}, {8, 8, 8, 9, 9}};
+            GLC_TRY(radix_sort(st, cur, alt, cnt_cur, 0, pp, tiles, nblk, s, live_total));
             depth *= 2;
         }
     }

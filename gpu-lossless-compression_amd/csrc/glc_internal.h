@@ -21,13 +21,15 @@ constexpr uint32_t ST_CAPACITY       = 2u;       // compressed stream would not 
 // suffix array scratch: everything for `rows` blocks of up to nmax elements
 // ---------------------------------------------------------------------------
 struct SaScratch {
-    uint32_t  nmax = 0, rows = 0, max_tiles = 0;
+    uint32_t  nmax = 0, rows = 0, max_tiles = 0, rs_tiles = 0;
     uint64_t *keyA = nullptr, *keyB = nullptr;   // [rows][nmax]
     uint32_t *posA = nullptr, *posB = nullptr;   // [rows][nmax] SA slots of the unresolved list
     uint32_t *isa = nullptr;                     // [rows][nmax] rank+1 of each suffix
     uint32_t *sa = nullptr;                      // [rows][nmax]
-    uint32_t *tile_hist = nullptr;               // [rows][max_tiles][512]
-    uint32_t *digit_base = nullptr;              // [rows][512]
+    uint32_t *tile_hist = nullptr;               // [rows][rs_tiles][512] look-back granules of the radix passes
+    uint32_t *digit_base = nullptr;              // [rows][5][512] exclusive digit offsets, one table per pass
+    uint32_t *ghist = nullptr;                   // [rows][5][512] digit totals
+    uint32_t  epoch = 255;                       // launch tag of the look-back granules (forces a clear first)
     uint4    *tile_agg = nullptr;                // [rows][max_tiles]
     uint64_t *tile_state = nullptr;              // [rows][max_tiles] look-back granules {flag:2, head:21, unres:21, groups:20}
     uint32_t *ticket = nullptr;                  // [rows] tile tickets of the single-pass rank kernel
