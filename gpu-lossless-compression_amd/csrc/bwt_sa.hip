@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void k_rs_digitbase(const uint32_t *__restrict
 constexpr uint32_t OS_AGG = 1u << 22, OS_PFX = 2u << 22, OS_FLAGS = 3u << 22, OS_CNT = (1u << 22) - 1;
 
 template <int BITS>
-__global__ __launch_bounds__(RS_NT) void k_rs_onesweep(const uint64_t *__restrict__ key_in,
+__global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__restrict__ key_in,
                                                        uint64_t *__restrict__ key_out,
                                                        const uint32_t *__restrict__ cnt, uint32_t nfixed,
                                                        uint32_t shift, uint32_t *__restrict__ state,
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_onesweep(const uint64_t *__restric
 {
     constexpr int RADIX = 1 << BITS;
     static_assert(RADIX <= RS_NT, "one digit per thread in the look-back");
-    __shared__ uint32_t s_wc[RS_WAVES][RADIX];
+    __shared__ uint16_t s_wc[RS_WAVES][RADIX];         // 16-bit: counts <= 512 per wave, starts < RS_TILE (4 workgroups / CU)
     __shared__ uint32_t s_gbase[RADIX];
     __shared__ uint64_t s_key[RS_TILE];
     __shared__ uint32_t s_tmp[RS_WAVES + 1];
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_onesweep(const uint64_t *__restric
     const uint32_t b = blockIdx.y, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const uint32_t m = live_count(cnt, nfixed, b);
     if (tid == 0) s_tile = atomicAdd(&ticket[b], 1u);
-    for (uint32_t i = tid; i < RS_WAVES * RADIX; i += RS_NT) (&s_wc[0][0])[i] = 0;
+    for (uint32_t i = tid; i < RS_WAVES * RADIX / 2; i += RS_NT) reinterpret_cast<uint32_t *>(&s_wc[0][0])[i] = 0;
     __syncthreads();
     const uint32_t t = s_tile, base = t * RS_TILE;
     if (base >= m) return;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_onesweep(const uint64_t *__restric
         const uint32_t pre = mbcnt(peers), tot = (uint32_t)__popcll(peers);
         const uint32_t old = s_wc[w][d];
         __builtin_amdgcn_wave_barrier();
-        if (valid && pre == 0) s_wc[w][d] = old + tot;
+        if (valid && pre == 0) s_wc[w][d] = (uint16_t)(old + tot);
         __builtin_amdgcn_wave_barrier();
         rk[r] = old + pre;
     }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(RS_NT) void k_rs_onesweep(const uint64_t *__restric
     if (tid < RADIX) {
         s_gbase[tid] = digit_base[(size_t)b * db_stride + tid] + excl - run;
 #pragma unroll
-        for (int q = 0; q < RS_WAVES; q++) { s_wc[q][tid] = run; run += c[q]; }
+        for (int q = 0; q < RS_WAVES; q++) { s_wc[q][tid] = (uint16_t)run; run += c[q]; }
     }
     __syncthreads();
 #pragma unroll

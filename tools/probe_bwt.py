@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Timing probe (no verification): glcBwtBatch / glcCompressBatch on Zipf blocks.
+usage: probe_bwt.py [rows] [iters]   -- prints ms per batch.  Used for kernel A/B experiments."""
+import importlib.util, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+import torch
+glc = bench._load("glc_binding", os.path.join(ROOT, "gpu-lossless-compression_amd", "glc_binding.py"))
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+n = 1 << 20
+d_in = bench.zipf_blocks_on_device(torch, dev, rows, 0, 1)
+d_out = torch.empty_like(d_in); d_idx = torch.empty(rows, dtype=torch.int32, device=dev)
+L = glc.lib()
+with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_BWT, n, rows=rows) as plan:
+    for it in range(iters + 1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        assert L.glcBwtBatch(plan.handle, d_in.data_ptr(), d_out.data_ptr(), d_idx.data_ptr(), n, rows) == 0
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        if it: print("bwt batch of %d: %.3f ms" % (rows, (t1 - t0) * 1e3))
