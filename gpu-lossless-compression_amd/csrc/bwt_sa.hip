@@ -12,10 +12,13 @@
 //   round 0 : one 64-bit word per suffix = [41-bit mixed-radix code of the first
 //             5 symbols (symbol = byte+1, 0 past the end) | 20-bit suffix index],
 //             LSD radix sort on the 41 key bits, LDS-staged digit buckets.
-//   round r : prefix doubling on the *unresolved* suffixes only (Larsson-Sadakane
-//             style): word = [rank(i):21 | rank(i+h):21 | i:20], same radix sort,
-//             results scattered back to their SA slots, ranks refined, singletons
-//             dropped.  h = 5, 10, 20, ...
+//   round r : refinement of the *unresolved* suffixes only, results scattered back to
+//             their SA slots, singletons dropped.  First by the next 3 text symbols
+//             (word = [group:19 | code:25 | i:20], no rank array: enough for i.i.d.
+//             bytes / float data), then, for deep-LCP data, by prefix doubling
+//             (Larsson-Sadakane: word = [rank(i):21 | rank(i+h):21 | i:20]).
+//   Every sort is Onesweep-style: one histogram read for all digits, then one
+//   stable scatter per digit with a decoupled look-back across tiles.
 //
 // One array of 8-byte words is the only thing the sort moves (key and payload are
 // the same word), so a radix pass costs 8 B read (histogram) + 8 B read + 8 B
@@ -70,7 +73,6 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_init_keys(const uint8_t *__re
 }
 
 // ---------------------------------------------------------------------------
-// radix pass 1/3: per-tile digit histogram (LDS, one sub-histogram per wave)
 // The radix kernels use their own tile: RS_NT threads x 8 words.
 // ---------------------------------------------------------------------------
 constexpr int RS_NT    = 512;                    // threads per radix workgroup
@@ -78,39 +80,10 @@ constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE  = RS_NT * RS_ITEMS;       // words per radix tile (longer per-digit write runs than 2048)
 constexpr int RS_WAVES = RS_NT / 64;
 
-template <int BITS>
-__global__ __launch_bounds__(RS_NT) void k_rs_hist(const uint64_t *__restrict__ key,
-                                                   const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                   uint32_t shift, uint32_t *__restrict__ tile_hist,
-                                                   uint32_t nmax, uint32_t max_tiles)
-{
-    constexpr int RADIX = 1 << BITS;
-    __shared__ uint32_t s_h[RS_WAVES][RADIX];
-    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
-    const uint32_t m = live_count(cnt, nfixed, b), base = t * RS_TILE;
-    if (base >= m) return;
-    const uint32_t tile_n = min((uint32_t)RS_TILE, m - base);
-    for (uint32_t i = tid; i < RS_WAVES * RADIX; i += RS_NT) (&s_h[0][0])[i] = 0;
-    __syncthreads();
-    const uint64_t *K = key + (size_t)b * nmax + base;
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        uint32_t i = r * RS_NT + tid;
-        if (i < tile_n) atomicAdd(&s_h[w][(uint32_t)(K[i] >> shift) & (RADIX - 1)], 1u);
-    }
-    __syncthreads();
-    uint32_t *H = tile_hist + ((size_t)b * max_tiles + t) * SA_MAXRADIX;
-    for (uint32_t d = tid; d < RADIX; d += RS_NT) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int q = 0; q < RS_WAVES; q++) c += s_h[q][d];
-        H[d] = c;
-    }
-}
-
 // ---------------------------------------------------------------------------
-// radix pass 2/3: per block, turn tile histograms into per-(tile,digit)
-// exclusive prefixes and the per-digit base.  One 512-thread workgroup / block.
+// per block, turn [tile][digit] histograms into per-(tile,digit) exclusive prefixes and the
+// per-digit base.  One 512-thread workgroup / block.  (Used by the decoder's LF construction;
+// the suffix sorter's own passes are the Onesweep kernels below.)
 // ---------------------------------------------------------------------------
 template <int BITS>
 __global__ __launch_bounds__(512) void k_rs_scan(uint32_t *__restrict__ tile_hist,
@@ -137,95 +110,6 @@ __global__ __launch_bounds__(512) void k_rs_scan(uint32_t *__restrict__ tile_his
     }
     uint32_t ex = block_excl_add<512>(run, s_tmp);
     if (d < RADIX) digit_base[(size_t)b * SA_MAXRADIX + d] = ex;
-}
-
-// ---------------------------------------------------------------------------
-// radix pass 3/3: stable scatter.  Each wave ranks its 512 words 64 at a time
-// with a ballot match on the digit (wave64), buckets are staged in LDS so the
-// global writes are runs of consecutive addresses per digit.
-// ---------------------------------------------------------------------------
-template <int BITS>
-__global__ __launch_bounds__(RS_NT) void k_rs_scatter(const uint64_t *__restrict__ key_in,
-                                                      uint64_t *__restrict__ key_out,
-                                                      const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                      uint32_t shift,
-                                                      const uint32_t *__restrict__ tile_hist,
-                                                      const uint32_t *__restrict__ digit_base,
-                                                      uint32_t nmax, uint32_t max_tiles)
-{
-    constexpr int RADIX = 1 << BITS;
-    static_assert(RADIX <= RS_NT, "one digit per thread in the prefix step");
-    __shared__ uint32_t s_wc[RS_WAVES][RADIX];
-    __shared__ uint32_t s_gbase[RADIX];
-    __shared__ uint64_t s_key[RS_TILE];
-    __shared__ uint32_t s_tmp[RS_WAVES + 1];
-    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const uint32_t m = live_count(cnt, nfixed, b), base = t * RS_TILE;
-    if (base >= m) return;
-    const uint32_t tile_n = min((uint32_t)RS_TILE, m - base);
-    const uint64_t *K = key_in + (size_t)b * nmax + base;
-    uint64_t *KO = key_out + (size_t)b * nmax;
-
-    for (uint32_t i = tid; i < RS_WAVES * RADIX; i += RS_NT) (&s_wc[0][0])[i] = 0;
-    __syncthreads();
-
-    uint64_t k[RS_ITEMS];
-    uint32_t rk[RS_ITEMS];
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
-        const bool valid = i < tile_n;
-        k[r] = valid ? K[i] : 0ull;
-        const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < BITS; bit++) {
-            const bool set = (d >> bit) & 1u;
-            const uint64_t bal = __ballot(set);
-            peers &= set ? bal : ~bal;
-        }
-        const uint32_t pre = mbcnt(peers), tot = (uint32_t)__popcll(peers);
-        const uint32_t old = s_wc[w][d];
-        __builtin_amdgcn_wave_barrier();
-        if (valid && pre == 0) s_wc[w][d] = old + tot;
-        __builtin_amdgcn_wave_barrier();
-        rk[r] = old + pre;
-    }
-    __syncthreads();
-
-    // tile-local bucket starts (exclusive scan over digits), per-wave starts, global bases
-    uint32_t c[RS_WAVES], tot = 0;
-    if (tid < RADIX) {
-#pragma unroll
-        for (int q = 0; q < RS_WAVES; q++) { c[q] = s_wc[q][tid]; tot += c[q]; }
-    }
-    uint32_t run = block_excl_add<RS_NT>(tot, s_tmp);
-    if (tid < RADIX) {
-        const uint32_t *TH = tile_hist + ((size_t)b * max_tiles + t) * SA_MAXRADIX;
-        const uint32_t *DB = digit_base + (size_t)b * SA_MAXRADIX;
-        s_gbase[tid] = DB[tid] + TH[tid] - run;
-#pragma unroll
-        for (int q = 0; q < RS_WAVES; q++) { s_wc[q][tid] = run; run += c[q]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
-        if (i < tile_n) {
-            const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
-            s_key[s_wc[w][d] + rk[r]] = k[r];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const uint32_t p = r * RS_NT + tid;
-        if (p < tile_n) {
-            const uint64_t kk = s_key[p];
-            const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
-            KO[s_gbase[d] + p] = kk;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -396,8 +280,6 @@ __global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__rest
 
 // ---------------------------------------------------------------------------
 // After a sort: group heads, ranks, write-back, compaction of unresolved.
-// APPLY=false: per-tile aggregates (last head index, #unresolved, #unresolved heads).
-// APPLY=true : uses the scanned aggregates and writes SA (+ISA) and the next list.
 // A suffix is resolved when its group (equal sort key) is a singleton.
 //
 // Two refinement modes for the NEXT round's words:
@@ -411,130 +293,8 @@ __global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__rest
 constexpr int MODE_ISA = 0, MODE_TEXT = 1;
 constexpr uint32_t TXT_GRP_SHIFT = 45, TXT_CODE_SHIFT = 20;
 
-template <bool APPLY>
-__global__ __launch_bounds__(SA_THREADS) void k_sa_rank(const uint64_t *__restrict__ key,
-                                                        const uint32_t *__restrict__ pos,
-                                                        const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                        uint4 *__restrict__ tile_agg,
-                                                        uint32_t *__restrict__ isa, uint32_t *__restrict__ sa,
-                                                        uint64_t *__restrict__ key_next,
-                                                        uint32_t *__restrict__ pos_next,
-                                                        uint32_t *__restrict__ hd_next,
-                                                        uint32_t nmax, uint32_t max_tiles, int mode,
-                                                        const uint8_t *__restrict__ text, size_t text_stride,
-                                                        uint32_t n, uint32_t depth)
-{
-    __shared__ uint32_t s_tmp[12];
-    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-    const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
-    if (base >= m) return;
-    const uint64_t *K = key + (size_t)b * nmax;
-    const uint32_t *P = pos ? pos + (size_t)b * nmax : nullptr;
-    const uint32_t e0 = base + tid * SA_ITEMS;
-
-    // kk[i] = word of element e0 - 1 + i  (i = 0..9); compare on the sort-key bits only
-    uint64_t kk[SA_ITEMS + 2];
-#pragma unroll
-    for (int i = 0; i < SA_ITEMS + 2; i++) {
-        const int64_t g = (int64_t)e0 - 1 + i;
-        kk[i] = (g >= 0 && g < (int64_t)m) ? (K[g] >> VAL_BITS) : 0ull;
-    }
-    uint32_t headm = 0, unresm = 0, lh = 0, uc = 0, uh = 0;
-#pragma unroll
-    for (int i = 0; i < SA_ITEMS; i++) {
-        const uint32_t e = e0 + i;
-        if (e < m) {
-            const bool head = (e == 0) || (kk[i + 1] != kk[i]);
-            const bool nhead = (e + 1 >= m) || (kk[i + 2] != kk[i + 1]);
-            if (head) { headm |= 1u << i; lh = e; }
-            if (!(head && nhead)) { unresm |= 1u << i; uc++; if (head) uh++; }
-        }
-    }
-    if (!APPLY) {
-        uint32_t mx = wave_max(lh), sm = wave_sum(uc), sh = wave_sum(uh);
-        if ((tid & 63) == 0) { s_tmp[tid >> 6] = mx; s_tmp[4 + (tid >> 6)] = sm; s_tmp[8 + (tid >> 6)] = sh; }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t a = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
-            uint32_t c = s_tmp[4] + s_tmp[5] + s_tmp[6] + s_tmp[7];
-            uint32_t h = s_tmp[8] + s_tmp[9] + s_tmp[10] + s_tmp[11];
-            tile_agg[(size_t)b * max_tiles + t] = make_uint4(a, c, h, 0);
-        }
-        return;
-    } else {
-        const uint4 agg = tile_agg[(size_t)b * max_tiles + t];   // (carry head, unresolved offset, group offset)
-        uint32_t carry = block_excl_max<SA_THREADS>(lh, s_tmp);
-        carry = max(carry, agg.x);
-        uint32_t off = agg.y + block_excl_add<SA_THREADS>(uc, s_tmp);
-        uint32_t gcount = (mode == MODE_TEXT) ? agg.z + block_excl_add<SA_THREADS>(uh, s_tmp) : 0u;
-        uint32_t *ISA = isa + (size_t)b * nmax, *SAo = sa + (size_t)b * nmax;
-        uint64_t *KN = key_next + (size_t)b * nmax;
-        uint32_t *PN = pos_next + (size_t)b * nmax;
-        uint32_t *HN = hd_next + (size_t)b * nmax;
-        const uint8_t *T = text + (size_t)b * text_stride;
-        uint32_t running = carry;
-#pragma unroll
-        for (int i = 0; i < SA_ITEMS; i++) {
-            const uint32_t e = e0 + i;
-            if (e < m) {
-                const bool head = headm & (1u << i), unres = unresm & (1u << i);
-                if (head) running = e;
-                const uint32_t grp = P ? P[running] : running;    // SA slot of the group head
-                const uint32_t v = (uint32_t)(K[e] & VAL_MASK);
-                const uint32_t slot = P ? P[e] : e;
-                SAo[slot] = v;
-                if (mode == MODE_ISA) {
-                    ISA[v] = grp + 1;
-                    if (unres) {
-                        PN[off] = slot;
-                        KN[off] = ((uint64_t)(grp + 1) << R1_SHIFT) | v;
-                        off++;
-                    }
-                } else {
-                    if (head && unres) gcount++;
-                    if (unres) {
-                        const uint32_t p0 = v + depth;
-                        const uint32_t c0 = p0 < n ? (uint32_t)T[p0] + 1 : 0u;
-                        const uint32_t c1 = p0 + 1 < n ? (uint32_t)T[p0 + 1] + 1 : 0u;
-                        const uint32_t c2 = p0 + 2 < n ? (uint32_t)T[p0 + 2] + 1 : 0u;
-                        const uint64_t code = ((uint64_t)c0 * 257 + c1) * 257 + c2;
-                        PN[off] = slot;
-                        HN[off] = grp;
-                        KN[off] = ((uint64_t)(gcount - 1) << TXT_GRP_SHIFT) | (code << TXT_CODE_SHIFT) | v;
-                        off++;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// scan of the per-tile aggregates; one 512-thread workgroup per block
-__global__ __launch_bounds__(512) void k_sa_aggscan(uint4 *__restrict__ tile_agg,
-                                                    const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                    uint32_t *__restrict__ cnt_next,
-                                                    uint32_t *__restrict__ d_max_cnt, uint32_t max_tiles)
-{
-    __shared__ uint32_t s_tmp[16];
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
-    const uint32_t m = live_count(cnt, nfixed, b);
-    const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
-    uint4 a = make_uint4(0, 0, 0, 0);
-    if (t < ntiles) a = tile_agg[(size_t)b * max_tiles + t];
-    uint32_t carry = block_excl_max<512>(a.x, s_tmp);
-    uint32_t total = 0;
-    uint32_t off = block_excl_add<512>(a.y, s_tmp, &total);
-    uint32_t goff = block_excl_add<512>(a.z, s_tmp);
-    if (t < ntiles) tile_agg[(size_t)b * max_tiles + t] = make_uint4(carry, off, goff, 0);
-    if (t == 0) {
-        cnt_next[b] = total;
-        if (total) { atomicMax(d_max_cnt, total); atomicAdd(d_max_cnt + 1, total); }
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Single-pass version of the step above: one kernel per round instead of
-// mark + scan + apply.  Tiles of a block take tickets in arrival order and chain
+// One kernel per round.  Tiles of a block take tickets in arrival order and chain
 // their (last head, #unresolved, #unresolved groups) prefix through 8-byte
 // {flag, value} granules with a wave-parallel decoupled look-back (agent-scope
 // relaxed atomics: the granule IS the flag, so no fence is needed).  The sorted
@@ -781,37 +541,6 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_fill_rank2(uint64_t *__restri
     }
 }
 
-// ---------------------------------------------------------------------------
-// BWT gather (bwt_compute_final_kernel, compress_kernel.cuh:55-74)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bwt_gather(const uint8_t *__restrict__ text, size_t text_stride,
-                                                    const uint32_t *__restrict__ sa, size_t sa_stride,
-                                                    uint32_t n, uint8_t *__restrict__ out, size_t out_stride,
-                                                    int *__restrict__ d_index)
-{
-    const uint32_t b = blockIdx.y;
-    const uint8_t *T = text + (size_t)b * text_stride;
-    const uint32_t *S = sa + (size_t)b * sa_stride;
-    uint8_t *O = out + (size_t)b * out_stride;
-    // 4 outputs per thread so the store is one dword
-    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= n) return;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t i = i0 + j;
-        if (i < n) {
-            const uint32_t v = S[i];
-            uint8_t c;
-            if (v == 0) { c = T[n - 1]; d_index[b] = (int)i; }
-            else c = T[v - 1];
-            packed |= (uint32_t)c << (8 * j);
-        }
-    }
-    if (i0 + 3 < n && ((reinterpret_cast<uintptr_t>(O) & 3) == 0)) *reinterpret_cast<uint32_t *>(O + i0) = packed;
-    else for (int j = 0; j < 4 && i0 + j < n; j++) O[i0 + j] = (uint8_t)(packed >> (8 * j));
-}
-
 __global__ void k_sa_export(const uint32_t *__restrict__ sa, uint32_t n, uint32_t *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -837,7 +566,6 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.rs_tiles * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * RS_MAXPASS * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.ghist, (size_t)rows * RS_MAXPASS * SA_MAXRADIX * 4));
-    GLC_TRY(A((void **)&s.tile_agg, (size_t)rows * s.max_tiles * sizeof(uint4)));
     GLC_TRY(A((void **)&s.tile_state, (size_t)rows * s.max_tiles * 8));
     GLC_TRY(A((void **)&s.ticket, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.hdA, ne * 4)); GLC_TRY(A((void **)&s.hdB, ne * 4));
@@ -851,7 +579,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 void sa_scratch_free(SaScratch &s)
 {
     void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
-                  s.tile_agg, s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt};
+                  s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
     for (auto &e : s.prof_ev) if (e) (void)hipEventDestroy(e);
@@ -1003,16 +731,6 @@ hipError_t tile_hist_scan9(hipStream_t st, uint32_t *tile_hist, uint32_t count, 
 {
     hipLaunchKernelGGL(k_rs_scan<9>, dim3(nblk), dim3(512), 0, st, tile_hist, (const uint32_t *)nullptr, count,
                        digit_base, max_tiles, tile_elems);
-    return hipGetLastError();
-}
-
-hipError_t bwt_gather(hipStream_t st, const uint8_t *text, size_t text_stride, const uint32_t *sa,
-                      size_t sa_stride, uint32_t n, uint32_t nblk, uint8_t *out, size_t out_stride,
-                      int *d_index)
-{
-    dim3 g((n + 1023) / 1024, nblk);
-    hipLaunchKernelGGL(k_bwt_gather, g, dim3(256), 0, st, text, text_stride, sa, sa_stride, n, out,
-                       out_stride, d_index);
     return hipGetLastError();
 }
 

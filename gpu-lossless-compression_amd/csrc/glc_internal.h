@@ -30,7 +30,6 @@ struct SaScratch {
     uint32_t *digit_base = nullptr;              // [rows][5][512] exclusive digit offsets, one table per pass
     uint32_t *ghist = nullptr;                   // [rows][5][512] digit totals
     uint32_t  epoch = 255;                       // launch tag of the look-back granules (forces a clear first)
-    uint4    *tile_agg = nullptr;                // [rows][max_tiles]
     uint64_t *tile_state = nullptr;              // [rows][max_tiles] look-back granules {flag:2, head:21, unres:21, groups:20}
     uint32_t *ticket = nullptr;                  // [rows] tile tickets of the single-pass rank kernel
     uint32_t *hdA = nullptr, *hdB = nullptr;     // [rows][nmax] SA slot of the group head of each unresolved entry
@@ -59,11 +58,6 @@ void       sa_scratch_free(SaScratch &s);
 hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
                     SaScratch &s, uint8_t *bwt_out = nullptr, size_t bwt_stride = 0, int *d_index = nullptr,
                     int *rounds_out = nullptr);
-
-// L[i] = SA[i]==0 ? T[n-1] : T[SA[i]-1];  index[b] = i with SA[i]==0
-hipError_t bwt_gather(hipStream_t st, const uint8_t *text, size_t text_stride, const uint32_t *sa,
-                      size_t sa_stride, uint32_t n, uint32_t nblk, uint8_t *out, size_t out_stride,
-                      int *d_index);
 
 // copy SA to the cudppSuffixArray layout (out[0]=n, out[1..n]=SA)
 hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out);
