@@ -14,6 +14,7 @@
 #include "../../include/culzss.h"
 #include "culzss_internal.h"
 
+#include <algorithm>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -340,6 +341,236 @@ float glcLzssLastKernelMs(void)
         if (g.slot[i].e0 && hipEventElapsedTime(&ms, g.slot[i].e0, g.slot[i].e1) == hipSuccess && ms > best) best = ms;
     }
     return best;
+}
+
+} // extern "C"
+
+// ==========================================================================
+// Container + pipeline: the file format written by the
+// reference's pthread pipeline (cuda-lzss-cluster/main.c:236-245, culzss.c:204-269,
+// decompression.c:66-173, deculzss.c:125-180):
+//     u32 nbufs | u32 padding | u32 cumulative_size[nbufs] | payload_0 | payload_1 ...
+// (host-endian u32, as fwrite'd by culzss.c:220,263-264).  payload_i is the packed
+// form of 1 MiB buffer i, or the raw buffer when packing "took more"
+// (size == BUFSIZE, culzss.c:241-242; recognised by deculzss.c:94-95).  `padding`
+// = bytes missing from the last buffer.  One deliberate fix: the reference
+// compresses the last partial buffer together with stale bytes of the ring slot
+// (main.c:122-130), so its bytes are run-dependent; here the tail is zero-filled.
+//
+// The reference overlaps file I/O, PCIe and the GPU with four pthreads and a
+// 4-slot ledger.  Here the same overlap comes from two HIP streams working on
+// alternating groups of buffers (copy-in / kernels / copy-out of group g+1 run
+// while the host assembles group g) -- no thread ring, no busy-wait on
+// cudaStreamQuery (gpu_compress.cu:415-424).
+// ==========================================================================
+namespace {
+
+constexpr int CBUF = 1 << 20;                   // BUFSIZE (main.c:62)
+constexpr int GROUP = 16;                       // buffers per in-flight group
+
+struct Group {
+    hipStream_t st = nullptr;
+    uint8_t *d_in = nullptr, *d_packed = nullptr, *h_in = nullptr, *h_packed = nullptr;
+    int *d_sizes = nullptr, *h_sizes = nullptr;
+    void *d_work = nullptr;
+    uint8_t *d_out = nullptr, *h_out = nullptr;  // decode side
+    int nbuf = 0;
+    size_t first = 0;
+};
+
+bool group_alloc(Group &g, bool decode)
+{
+    const size_t stride = lzss_pack_stride(CBUF);
+    if (!ok(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking), "group stream")) return false;
+    if (!ok(hipMalloc((void **)&g.d_packed, stride * GROUP), "group packed")) return false;
+    if (!ok(hipMalloc((void **)&g.d_sizes, sizeof(int) * GROUP), "group sizes")) return false;
+    if (!ok(hipHostMalloc((void **)&g.h_packed, stride * GROUP, hipHostMallocDefault), "group h_packed")) return false;
+    if (!ok(hipHostMalloc((void **)&g.h_sizes, sizeof(int) * GROUP, hipHostMallocDefault), "group h_sizes")) return false;
+    if (!decode) {
+        if (!ok(hipMalloc((void **)&g.d_in, (size_t)CBUF * GROUP), "group in")) return false;
+        if (!ok(hipHostMalloc((void **)&g.h_in, (size_t)CBUF * GROUP, hipHostMallocDefault), "group h_in")) return false;
+        if (!ok(hipMalloc(&g.d_work, lzss_work_bytes(CBUF, GROUP)), "group work")) return false;
+    } else {
+        if (!ok(hipMalloc((void **)&g.d_out, (size_t)CBUF * GROUP), "group out")) return false;
+        if (!ok(hipHostMalloc((void **)&g.h_out, (size_t)CBUF * GROUP, hipHostMallocDefault), "group h_out")) return false;
+    }
+    return true;
+}
+
+void group_free(Group &g)
+{
+    if (g.st) { (void)hipStreamSynchronize(g.st); (void)hipStreamDestroy(g.st); }
+    void *dp[] = {g.d_in, g.d_packed, g.d_sizes, g.d_work, g.d_out};
+    for (void *p : dp) if (p) (void)hipFree(p);
+    void *hp[] = {g.h_in, g.h_packed, g.h_sizes, g.h_out};
+    for (void *p : hp) if (p) (void)hipHostFree(p);
+    g = Group();
+}
+
+} // namespace
+
+extern "C" {
+
+unsigned long long culzss_container_bound(unsigned long long len)
+{
+    const unsigned long long nb = (len + CBUF - 1) / CBUF;
+    return 8 + 4 * nb + nb * (unsigned long long)CBUF;       // every buffer stored raw is the worst case
+}
+
+int culzss_container_compress(const unsigned char *in, unsigned long long len, unsigned char *out,
+                              unsigned long long out_cap, unsigned long long *out_len)
+{
+    if (!in || !out || !out_len) return 0;
+    if (len < (unsigned long long)CBUF) return 0;            // "too small to benefit from GPU" (main.c:228-232)
+    const size_t nb = (size_t)((len + CBUF - 1) / CBUF);
+    if (nb > 0x3FFFFFFFu || out_cap < culzss_container_bound(len)) return 0;
+    const uint32_t padding = (uint32_t)(nb * (size_t)CBUF - len);
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(out);       // out comes from malloc/numpy: aligned
+    uint32_t w0 = (uint32_t)nb; memcpy(out, &w0, 4); memcpy(out + 4, &padding, 4);
+    size_t wpos = 8 + 4 * nb, cum = 0;
+    (void)hdr;
+    std::lock_guard<std::mutex> lk(g.mu);
+    init_locked();
+    Group grp[2];
+    if (!group_alloc(grp[0], false) || !group_alloc(grp[1], false)) { group_free(grp[0]); group_free(grp[1]); return 0; }
+    const size_t stride = lzss_pack_stride(CBUF);
+    bool good = true;
+    auto submit = [&](Group &G, size_t first) {
+        G.first = first; G.nbuf = (int)std::min((size_t)GROUP, nb - first);
+        for (int i = 0; i < G.nbuf; i++) {
+            const size_t off = (first + i) * (size_t)CBUF;
+            const size_t take = std::min((size_t)CBUF, (size_t)len - off);
+            memcpy(G.h_in + (size_t)i * CBUF, in + off, take);
+            if (take < (size_t)CBUF) memset(G.h_in + (size_t)i * CBUF + take, 0, CBUF - take);   // zero-filled tail
+        }
+        good = good && ok(hipMemcpyAsync(G.d_in, G.h_in, (size_t)G.nbuf * CBUF, hipMemcpyHostToDevice, G.st), "H2D")
+            && ok(lzss_encode(G.st, G.d_in, CBUF, G.nbuf, nullptr, G.d_packed, G.d_sizes, G.d_work), "encode")
+            && ok(hipMemcpyAsync(G.h_sizes, G.d_sizes, sizeof(int) * G.nbuf, hipMemcpyDeviceToHost, G.st), "D2H sizes")
+            && ok(hipMemcpyAsync(G.h_packed, G.d_packed, stride * G.nbuf, hipMemcpyDeviceToHost, G.st), "D2H packed");
+    };
+    auto collect = [&](Group &G) {
+        good = good && ok(hipStreamSynchronize(G.st), "sync");
+        for (int i = 0; good && i < G.nbuf; i++) {
+            const int sz = G.h_sizes[i];
+            const size_t bytes = sz > 0 ? (size_t)sz : (size_t)CBUF;          // 0 => stored raw (culzss.c:241-242)
+            memcpy(out + wpos, sz > 0 ? G.h_packed + (size_t)i * stride : G.h_in + (size_t)i * CBUF, bytes);
+            wpos += bytes; cum += bytes;
+            const uint32_t c32 = (uint32_t)cum;
+            memcpy(out + 8 + 4 * (G.first + i), &c32, 4);
+        }
+    };
+    size_t next = 0;
+    int cur = 0;
+    submit(grp[cur], next); next += GROUP;
+    while (good) {
+        const bool more = next < nb;
+        if (more) { submit(grp[cur ^ 1], next); next += GROUP; }
+        collect(grp[cur]);
+        if (!more) break;
+        cur ^= 1;
+    }
+    group_free(grp[0]); group_free(grp[1]);
+    if (!good) return 0;
+    *out_len = wpos;
+    return 1;
+}
+
+int culzss_container_decompress(const unsigned char *in, unsigned long long len, unsigned char *out,
+                                unsigned long long out_cap, unsigned long long *out_len)
+{
+    if (!in || !out || !out_len || len < 8) return 0;
+    uint32_t nb32, padding;
+    memcpy(&nb32, in, 4); memcpy(&padding, in + 4, 4);
+    const size_t nb = nb32;
+    if (nb == 0 || len < 8 + 4 * nb || padding >= (uint32_t)CBUF) return 0;
+    const unsigned long long total = (unsigned long long)nb * CBUF - padding;
+    if (out_cap < total) return 0;
+    std::lock_guard<std::mutex> lk(g.mu);
+    init_locked();
+    Group grp[2];
+    if (!group_alloc(grp[0], true) || !group_alloc(grp[1], true)) { group_free(grp[0]); group_free(grp[1]); return 0; }
+    const size_t stride = lzss_pack_stride(CBUF);
+    const size_t payload = 8 + 4 * nb;
+    bool good = true;
+    auto cumat = [&](size_t i) -> size_t { if (i == 0) return 0; uint32_t c; memcpy(&c, in + 8 + 4 * (i - 1), 4); return c; };
+    auto submit = [&](Group &G, size_t first) {
+        G.first = first; G.nbuf = (int)std::min((size_t)GROUP, nb - first);
+        for (int i = 0; good && i < G.nbuf; i++) {
+            const size_t a = cumat(first + i), b = cumat(first + i + 1);
+            const size_t sz = b - a;
+            if (b < a || sz > stride || payload + b > len) { good = false; break; }
+            memcpy(G.h_packed + (size_t)i * stride, in + payload + a, sz);
+            G.h_sizes[i] = (sz == (size_t)CBUF) ? 0 : (int)sz;             // raw buffers: deculzss.c:94-95
+        }
+        good = good && ok(hipMemcpyAsync(G.d_packed, G.h_packed, stride * G.nbuf, hipMemcpyHostToDevice, G.st), "H2D")
+            && ok(hipMemcpyAsync(G.d_sizes, G.h_sizes, sizeof(int) * G.nbuf, hipMemcpyHostToDevice, G.st), "H2D sizes")
+            && ok(lzss_decode(G.st, G.d_packed, G.d_sizes, CBUF, G.nbuf, G.d_out), "decode")
+            && ok(hipMemcpyAsync(G.h_out, G.d_out, (size_t)G.nbuf * CBUF, hipMemcpyDeviceToHost, G.st), "D2H");
+    };
+    auto collect = [&](Group &G) {
+        good = good && ok(hipStreamSynchronize(G.st), "sync");
+        for (int i = 0; good && i < G.nbuf; i++) {
+            const size_t off = (G.first + i) * (size_t)CBUF;
+            const size_t take = std::min((size_t)CBUF, (size_t)total - off);  // last buffer loses the padding (deculzss.c:156-159)
+            memcpy(out + off, G.h_out + (size_t)i * CBUF, take);
+        }
+    };
+    size_t next = 0;
+    int cur = 0;
+    submit(grp[cur], next); next += GROUP;
+    while (good) {
+        const bool more = next < nb;
+        if (more) { submit(grp[cur ^ 1], next); next += GROUP; }
+        collect(grp[cur]);
+        if (!more) break;
+        cur ^= 1;
+    }
+    group_free(grp[0]); group_free(grp[1]);
+    if (!good) return 0;
+    *out_len = total;
+    return 1;
+}
+
+static int slurp(const char *path, unsigned char **data, unsigned long long *len)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return 0;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    unsigned char *p = (unsigned char *)malloc(sz > 0 ? (size_t)sz : 1);
+    if (!p) { fclose(f); return 0; }
+    const size_t got = fread(p, 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) { free(p); return 0; }
+    *data = p; *len = (unsigned long long)sz;
+    return 1;
+}
+
+/* ./main -i in -o out   (main.c:160-186, compress branch) */
+int culzss_compress_file(const char *in_path, const char *out_path)
+{
+    unsigned char *in = nullptr; unsigned long long len = 0, olen = 0;
+    if (!in_path || !out_path || !slurp(in_path, &in, &len)) return 0;
+    unsigned char *out = (unsigned char *)malloc((size_t)culzss_container_bound(len) + 16);
+    int rc = out ? culzss_container_compress(in, len, out, culzss_container_bound(len), &olen) : 0;
+    if (rc) { FILE *f = fopen(out_path, "wb"); rc = f && fwrite(out, 1, (size_t)olen, f) == (size_t)olen; if (f) fclose(f); }
+    free(in); free(out);
+    return rc;
+}
+
+/* ./main -d 1 -i in -o out   (main.c:207-222) */
+int culzss_decompress_file(const char *in_path, const char *out_path)
+{
+    unsigned char *in = nullptr; unsigned long long len = 0, olen = 0;
+    if (!in_path || !out_path || !slurp(in_path, &in, &len) || len < 8) { free(in); return 0; }
+    uint32_t nb; memcpy(&nb, in, 4);
+    const unsigned long long cap = (unsigned long long)nb * CBUF;
+    unsigned char *out = (unsigned char *)malloc(cap ? (size_t)cap : 1);
+    int rc = out ? culzss_container_decompress(in, len, out, cap, &olen) : 0;
+    if (rc) { FILE *f = fopen(out_path, "wb"); rc = f && fwrite(out, 1, (size_t)olen, f) == (size_t)olen; if (f) fclose(f); }
+    free(in); free(out);
+    return rc;
 }
 
 } // extern "C"

@@ -45,7 +45,8 @@ CULZSS_SYMBOLS = [
     "resetGPU", "streams_in_GPU", "deleteGPUStreams", "signalExitThreads", "deinitGPUmem",
     "dedeleteGPUmem", "deinitGPU", "culzss_compress", "culzss_decompress",
     "glcLzssEncodeDevice", "glcLzssDecodeDevice", "glcLzssLastKernelMs", "glcLzssPackStride",
-    "glcLzssWorkBytes",
+    "glcLzssWorkBytes", "culzss_container_bound", "culzss_container_compress", "culzss_container_decompress",
+    "culzss_compress_file", "culzss_decompress_file",
 ]
 
 
@@ -128,6 +129,17 @@ def lib():
         L.glcLzssPackStride.restype = C.c_ulonglong
         L.glcLzssWorkBytes.argtypes = [C.c_int, C.c_int]
         L.glcLzssWorkBytes.restype = C.c_ulonglong
+        ull = C.c_ulonglong
+        L.culzss_container_bound.argtypes = [ull]
+        L.culzss_container_bound.restype = ull
+        L.culzss_container_compress.argtypes = [vp, ull, vp, ull, C.POINTER(ull)]
+        L.culzss_container_compress.restype = C.c_int
+        L.culzss_container_decompress.argtypes = [vp, ull, vp, ull, C.POINTER(ull)]
+        L.culzss_container_decompress.restype = C.c_int
+        L.culzss_compress_file.argtypes = [C.c_char_p, C.c_char_p]
+        L.culzss_compress_file.restype = C.c_int
+        L.culzss_decompress_file.argtypes = [C.c_char_p, C.c_char_p]
+        L.culzss_decompress_file.restype = C.c_int
         L.glcLzssLastKernelMs.argtypes = []
         L.glcLzssLastKernelMs.restype = C.c_float
     _lib = L

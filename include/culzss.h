@@ -80,6 +80,21 @@ int decompression_kernel_wrapper(unsigned char *buffer, int buf_length, int *dec
 int culzss_compress(const unsigned char *in, int len, unsigned char *out, int *out_len);
 int culzss_decompress(const unsigned char *in, int len, unsigned char *out, int *out_len);
 
+/* ---- container + pipeline (the reference's main.c / culzss.c / deculzss.c) -- */
+/* File format: u32 nbufs | u32 padding | u32 cumulative_size[nbufs] | payloads
+ * (host-endian; main.c:236-245, culzss.c:220,241-243,263-264).  payload i = packed
+ * form of 1 MiB buffer i, or the raw 1 MiB when packing took more (size == 1 MiB,
+ * deculzss.c:94-95).  Inputs shorter than 1 MiB are refused like main.c:228-232.
+ * The last partial buffer is zero-filled (the reference leaves stale ring-slot
+ * bytes there, main.c:122-130).  All return 1 on success, 0 on failure. */
+unsigned long long culzss_container_bound(unsigned long long len);
+int culzss_container_compress(const unsigned char *in, unsigned long long len, unsigned char *out,
+                              unsigned long long out_cap, unsigned long long *out_len);
+int culzss_container_decompress(const unsigned char *in, unsigned long long len, unsigned char *out,
+                                unsigned long long out_cap, unsigned long long *out_len);
+int culzss_compress_file(const char *in_path, const char *out_path);     /* ./main -i in -o out      */
+int culzss_decompress_file(const char *in_path, const char *out_path);   /* ./main -d 1 -i in -o out */
+
 /* ---- device-resident batch API (no PCIe in the timed region) ------------- */
 /* nbuf buffers of buf_length bytes at d_in (contiguous).  d_cand: 2x input
  * bytes (candidate stream, may be NULL to skip exporting it); d_packed: nbuf

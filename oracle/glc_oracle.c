@@ -550,6 +550,55 @@ ORC_API int orc_lzss_decode(const uint8_t *buf, int buf_length, uint8_t *out, in
 }
 
 /* ========================================================================= */
+/* 7a. CULZSS container (main.c:236-245; culzss.c:204-269 cpu_sender;         */
+/*     decompression.c:66-173; deculzss.c:94-95,125-180):                     */
+/*     u32 nbufs | u32 padding | u32 cumulative[nbufs] | payloads; a buffer    */
+/*     whose packing "took more" is stored raw (size == 1 MiB).  Last partial  */
+/*     buffer zero-filled (documented deviation from main.c:122-130).          */
+/* ========================================================================= */
+#define LZ_BUF (1 << 20)
+ORC_API int orc_lzss_container_compress(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t *out_len)
+{
+    if (len < LZ_BUF) return 0;
+    uint32_t nb = (uint32_t)((len + LZ_BUF - 1) / LZ_BUF);
+    uint32_t padding = (uint32_t)((uint64_t)nb * LZ_BUF - len);
+    memcpy(out, &nb, 4); memcpy(out + 4, &padding, 4);
+    uint64_t w = 8 + 4ull * nb, cum = 0;
+    uint8_t *buf = (uint8_t *)calloc(1, LZ_BUF), *cand = (uint8_t *)malloc(2 * LZ_BUF), *pk = (uint8_t *)malloc(LZ_BUF + 4096);
+    for (uint32_t i = 0; i < nb; i++) {
+        uint64_t off = (uint64_t)i * LZ_BUF, take = len - off < LZ_BUF ? len - off : LZ_BUF;
+        memset(buf, 0, LZ_BUF); memcpy(buf, in + off, take);
+        orc_lzss_candidates(buf, LZ_BUF, cand);
+        int n = 0;
+        if (orc_lzss_pack(cand, LZ_BUF, pk, &n)) { memcpy(out + w, pk, (size_t)n); w += (uint64_t)n; cum += (uint64_t)n; }
+        else { memcpy(out + w, buf, LZ_BUF); w += LZ_BUF; cum += LZ_BUF; }
+        uint32_t c32 = (uint32_t)cum; memcpy(out + 8 + 4ull * i, &c32, 4);
+    }
+    free(buf); free(cand); free(pk);
+    *out_len = w;
+    return 1;
+}
+
+ORC_API int orc_lzss_container_decompress(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t *out_len)
+{
+    uint32_t nb, padding; memcpy(&nb, in, 4); memcpy(&padding, in + 4, 4);
+    uint64_t payload = 8 + 4ull * nb, prev = 0;
+    uint8_t *tmp = (uint8_t *)malloc(LZ_BUF + 8192);
+    for (uint32_t i = 0; i < nb; i++) {
+        uint32_t c; memcpy(&c, in + 8 + 4ull * i, 4);
+        uint64_t sz = c - prev;
+        if (payload + c > len) { free(tmp); return 0; }
+        uint64_t take = (i == nb - 1) ? LZ_BUF - padding : LZ_BUF;
+        if (sz == LZ_BUF) memcpy(out + (uint64_t)i * LZ_BUF, in + payload + prev, take);
+        else { int n = 0; orc_lzss_decode(in + payload + prev, (int)sz, tmp, &n); memcpy(out + (uint64_t)i * LZ_BUF, tmp, take); }
+        prev = c;
+    }
+    free(tmp);
+    *out_len = (uint64_t)nb * LZ_BUF - padding;
+    return 1;
+}
+
+/* ========================================================================= */
 /* 7b. all-core CPU baseline driver (bench.py cpu_baseline only): compresses  */
 /*     nblocks blocks of n bytes with `nthreads` pthreads, block i on thread  */
 /*     i % nthreads; returns total compressed words through *total_words.     */

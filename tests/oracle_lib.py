@@ -48,6 +48,10 @@ def _load():
     lib.orc_lzss_pack.restype = C.c_int
     lib.orc_lzss_decode.argtypes = [_u8p, C.c_int, _u8p, C.POINTER(C.c_int)]
     lib.orc_lzss_decode.restype = C.c_int
+    lib.orc_lzss_container_compress.argtypes = [_u8p, C.c_uint64, _u8p, C.POINTER(C.c_uint64)]
+    lib.orc_lzss_container_compress.restype = C.c_int
+    lib.orc_lzss_container_decompress.argtypes = [_u8p, C.c_uint64, _u8p, C.POINTER(C.c_uint64)]
+    lib.orc_lzss_container_decompress.restype = C.c_int
     lib.orc_compress_many.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.orc_compress_many.restype = C.c_int
     lib.orc_crc32.argtypes = [_u8p, C.c_size_t]
@@ -202,6 +206,26 @@ def lzss_decode(packed):
     out = np.zeros(max(1, orig) + 4096, dtype=np.uint8)
     n = C.c_int(0)
     lib().orc_lzss_decode(_p8(p), p.size, _p8(out), C.byref(n))
+    return out[: n.value].copy()
+
+
+def lzss_container_compress(data):
+    a = _as_u8(data)
+    nb = (a.size + (1 << 20) - 1) >> 20
+    out = np.zeros(8 + 4 * nb + nb * ((1 << 20) + 4096), dtype=np.uint8)
+    n = C.c_uint64(0)
+    if not lib().orc_lzss_container_compress(_p8(a), a.size, _p8(out), C.byref(n)):
+        return None
+    return out[: n.value].copy()
+
+
+def lzss_container_decompress(blob):
+    a = _as_u8(blob)
+    nb = int(a[:4].view(np.uint32)[0])
+    out = np.zeros(nb << 20, dtype=np.uint8)
+    n = C.c_uint64(0)
+    if not lib().orc_lzss_container_decompress(_p8(a), a.size, _p8(out), C.byref(n)):
+        return None
     return out[: n.value].copy()
 
 

@@ -163,3 +163,59 @@ def test_culzss_compress_decompress_roundtrip(glc, cuda):
     assert m.value == MiB and np.array_equal(back, x)
     # rejects lengths that are not whole packets
     assert L.culzss_compress(x.ctypes.data, 5000, out.ctypes.data, C.byref(n)) == 0
+
+
+def test_container_matches_oracle_and_round_trips(glc, cuda, tmp_path):
+    """the file format of main.c / culzss.c / deculzss.c, incl. padding of the
+    last buffer and a buffer that is stored raw"""
+    L = glc.lib()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([datagen.log_bytes(2 * MiB, seed=31), rng.integers(97, 107, MiB, dtype=np.uint8),
+                        datagen.text_bytes(MiB + 12345, seed=32)])
+    want = O.lzss_container_compress(x)
+    cap = L.culzss_container_bound(x.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_ulonglong(0)
+    assert L.culzss_container_compress(x.ctypes.data, x.size, out.ctypes.data, cap, C.byref(n)) == 1
+    got = out[: n.value]
+    assert np.array_equal(got, want), _first_diff(got, want)
+    hdr = got[:8].view(np.uint32)
+    assert hdr[0] == 5 and hdr[1] == 5 * MiB - x.size
+    cum = got[8:8 + 20].view(np.uint32)
+    assert cum[2] - cum[1] == MiB                                  # the incompressible buffer is stored raw
+    back = np.zeros(5 * MiB, dtype=np.uint8)
+    m = C.c_ulonglong(0)
+    assert L.culzss_container_decompress(got.ctypes.data, got.size, back.ctypes.data, back.size, C.byref(m)) == 1
+    assert m.value == x.size and np.array_equal(back[: x.size], x)
+    assert np.array_equal(O.lzss_container_decompress(got), x)    # and the oracle reads our file
+    # file API (./main -i / ./main -d 1 -i)
+    fin, fc, fo = tmp_path / "in.bin", tmp_path / "c.bin", tmp_path / "out.bin"
+    fin.write_bytes(x.tobytes())
+    assert L.culzss_compress_file(str(fin).encode(), str(fc).encode()) == 1
+    assert fc.read_bytes() == want.tobytes()
+    assert L.culzss_decompress_file(str(fc).encode(), str(fo).encode()) == 1
+    assert fo.read_bytes() == x.tobytes()
+    # shorter than one buffer: refused (main.c:228-232)
+    assert L.culzss_container_compress(x.ctypes.data, MiB - 1, out.ctypes.data, cap, C.byref(n)) == 0
+
+
+def test_container_many_buffers(glc, cuda):
+    L = glc.lib()
+    x = np.tile(datagen.log_bytes(3 * MiB, seed=77), 14)[: 40 * MiB + 777]     # > 2 groups of 16 buffers
+    cap = L.culzss_container_bound(x.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = C.c_ulonglong(0)
+    assert L.culzss_container_compress(x.ctypes.data, x.size, out.ctypes.data, cap, C.byref(n)) == 1
+    back = np.zeros(41 * MiB, dtype=np.uint8)
+    m = C.c_ulonglong(0)
+    assert L.culzss_container_decompress(out.ctypes.data, n.value, back.ctypes.data, back.size, C.byref(m)) == 1
+    assert m.value == x.size and np.array_equal(back[: x.size], x)
+    # spot-check buffers 0, 17 and the last against the oracle's per-buffer packing
+    cum = np.concatenate([[0], out[8:8 + 4 * 41].view(np.uint32)])
+    for i in (0, 17, 40):
+        blk = np.zeros(MiB, dtype=np.uint8)
+        src = x[i * MiB:(i + 1) * MiB]
+        blk[: src.size] = src
+        want = O.lzss_pack(O.lzss_candidates(blk), MiB)
+        got = out[8 + 4 * 41 + cum[i]: 8 + 4 * 41 + cum[i + 1]]
+        assert np.array_equal(got, want), "buffer %d" % i
