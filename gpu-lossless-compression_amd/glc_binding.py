@@ -31,6 +31,7 @@ CUDPP_OPTION_BACKWARD = 0x2
 
 HUFF_BLOCK = 4096
 HUFF_MAX_WORDS = 1536
+GLC_HD_MAX_LEN = 11
 
 CUDPP_SYMBOLS = [
     "cudppCreate", "cudppDestroy", "cudppPlan", "cudppDestroyPlan", "cudppCompress",
@@ -48,6 +49,7 @@ CULZSS_SYMBOLS = [
     "glcLzssWorkBytes", "culzss_container_bound", "culzss_container_compress", "culzss_container_decompress",
     "culzss_compress_file", "culzss_decompress_file",
 ]
+HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice"]
 
 
 class CUDPPConfiguration(C.Structure):
@@ -142,8 +144,21 @@ def lib():
         L.culzss_decompress_file.restype = C.c_int
         L.glcLzssLastKernelMs.argtypes = []
         L.glcLzssLastKernelMs.restype = C.c_float
+    if hasattr(L, "glcHdDecodeDevice"):
+        L.glcHdBuildTable.argtypes = [vp, vp, vp]
+        L.glcHdBuildTable.restype = C.c_int
+        L.glcHdEncodeHost.argtypes = [vp, sz, vp, vp, vp, sz]
+        L.glcHdEncodeHost.restype = sz
+        L.glcHdWorkBytes.argtypes = [sz]
+        L.glcHdWorkBytes.restype = sz
+        L.glcHdDecodeDevice.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp]
+        L.glcHdDecodeDevice.restype = C.c_int
     _lib = L
     return L
+
+
+class HdError(RuntimeError):
+    pass
 
 
 class CudppError(RuntimeError):
@@ -266,3 +281,42 @@ def decompress_batch(plan, comp, n, nblk):
                                   comp["stride"], d_out.data_ptr(), n, nblk)
     _chk("glcDecompressBatch", rc)
     return d_out
+
+
+# ---------------------------------------------------------------------------
+# CUHD-shaped stream (include/glc_hd.h)
+# ---------------------------------------------------------------------------
+def hd_build_table(hist256):
+    """hist256: 256 counts.  Returns (lens u8[256], codes u16[256])."""
+    import numpy as np
+    h = np.ascontiguousarray(hist256, dtype=np.uint64)
+    lens = np.zeros(256, dtype=np.uint8)
+    codes = np.zeros(256, dtype=np.uint16)
+    if lib().glcHdBuildTable(h.ctypes.data, lens.ctypes.data, codes.ctypes.data) == 0:
+        raise HdError("glcHdBuildTable failed (empty histogram?)")
+    return lens, codes
+
+
+def hd_encode_host(data_u8, lens, codes):
+    """Host encoder: returns the stream as uint32 units (incl. the zero pad unit)."""
+    import numpy as np
+    a = np.ascontiguousarray(data_u8, dtype=np.uint8)
+    cap = (a.size * GLC_HD_MAX_LEN + 31) // 32 + 2
+    out = np.zeros(cap, dtype=np.uint32)
+    n = lib().glcHdEncodeHost(a.ctypes.data, a.size, lens.ctypes.data, codes.ctypes.data, out.ctypes.data, cap)
+    if n == 0:
+        raise HdError("glcHdEncodeHost failed (symbol without a code?)")
+    return out[:n].copy()
+
+
+def hd_decode_device(d_units, lens, codes, nsym, stream=None):
+    """d_units: int32/uint32 cuda tensor.  Returns a uint8 cuda tensor of nsym bytes."""
+    import torch
+    nunits = d_units.numel()
+    work = torch.empty(lib().glcHdWorkBytes(nunits), dtype=torch.uint8, device=d_units.device)
+    out = torch.empty(max(1, nsym), dtype=torch.uint8, device=d_units.device)
+    ok = lib().glcHdDecodeDevice(d_units.data_ptr(), nunits, lens.ctypes.data, codes.ctypes.data,
+                                 out.data_ptr(), nsym, work.data_ptr(), stream)
+    if not ok:
+        raise HdError("glcHdDecodeDevice failed")
+    return out[:nsym]

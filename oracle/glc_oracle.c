@@ -651,3 +651,62 @@ ORC_API uint32_t orc_crc32(const uint8_t *p, size_t n)
     }
     return c ^ 0xFFFFFFFFu;
 }
+
+/* ========================================================================= */
+/* 9. CUHD-shaped stream (row f3): sequential reference decoder               */
+/* ========================================================================= */
+/* The stream the reference decodes (cuhd_constants.h:15-24): byte symbols, codewords of
+ * at most 11 bits, packed MSB-first into 32-bit units (cuhd_input_buffer.cc:20-27).  The
+ * reference's demo checks "decoded == original" (demo.cc:176-178); its CPU-side decoder is
+ * the plain bit-serial walk restated here: take bits MSB-first, match the shortest
+ * codeword (prefix-free), emit, until nsym symbols are out.  Returns 0 ok, <0 corrupt. */
+ORC_API int orc_hd_decode(const uint32_t *units, uint64_t nunits, const uint8_t *lens, const uint16_t *codes,
+                          uint8_t *out, uint64_t nsym)
+{
+    int16_t *tab = (int16_t *)malloc(sizeof(int16_t) * 12 * 2048);   /* tab[len][code] = symbol or -1 */
+    if (!tab) return -9;
+    for (int i = 0; i < 12 * 2048; i++) tab[i] = -1;
+    for (int s = 0; s < 256; s++) {
+        if (!lens[s]) continue;
+        if (lens[s] > 11 || codes[s] >= (1u << lens[s])) { free(tab); return -1; }
+        tab[lens[s] * 2048 + codes[s]] = (int16_t)s;
+    }
+    uint64_t bit = 0, nbits = nunits * 32ull;
+    for (uint64_t k = 0; k < nsym; k++) {
+        uint32_t c = 0; int l = 0, sym = -1;
+        while (l < 11 && sym < 0) {
+            if (bit >= nbits) { free(tab); return -2; }
+            c = (c << 1) | ((units[bit >> 5] >> (31 - (bit & 31))) & 1u);
+            bit++; l++;
+            sym = tab[l * 2048 + c];
+        }
+        if (sym < 0) { free(tab); return -3; }
+        out[k] = (uint8_t)sym;
+    }
+    free(tab);
+    return 0;
+}
+
+/* Cost in bits of an unrestricted Huffman code for hist (sum of merged weights), and its
+ * depth: used to check that the length-limited table is optimal whenever the unrestricted
+ * tree already fits in 11 bits, and never cheaper than it otherwise. */
+ORC_API uint64_t orc_huffman_cost(const uint64_t *hist, int *depth_out)
+{
+    uint64_t w[512]; int d[512]; int n = 0;
+    for (int s = 0; s < 256; s++) if (hist[s]) { w[n] = hist[s]; d[n] = 0; n++; }
+    if (n == 0) { if (depth_out) *depth_out = 0; return 0; }
+    if (n == 1) { if (depth_out) *depth_out = 1; return w[0]; }
+    uint64_t cost = 0;
+    while (n > 1) {
+        int a = 0, b = -1;
+        for (int i = 1; i < n; i++) if (w[i] < w[a] || (w[i] == w[a] && d[i] < d[a])) a = i;
+        for (int i = 0; i < n; i++) if (i != a && (b < 0 || w[i] < w[b] || (w[i] == w[b] && d[i] < d[b]))) b = i;
+        uint64_t s = w[a] + w[b]; int dd = (d[a] > d[b] ? d[a] : d[b]) + 1;
+        cost += s;
+        int lo = a < b ? a : b, hi = a < b ? b : a;
+        w[lo] = s; d[lo] = dd;
+        w[hi] = w[n - 1]; d[hi] = d[n - 1]; n--;
+    }
+    if (depth_out) *depth_out = d[0];
+    return cost;
+}

@@ -54,6 +54,10 @@ def _load():
     lib.orc_lzss_container_decompress.restype = C.c_int
     lib.orc_compress_many.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.orc_compress_many.restype = C.c_int
+    lib.orc_hd_decode.argtypes = [_u32p, C.c_uint64, _u8p, C.POINTER(C.c_uint16), _u8p, C.c_uint64]
+    lib.orc_hd_decode.restype = C.c_int
+    lib.orc_huffman_cost.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    lib.orc_huffman_cost.restype = C.c_uint64
     lib.orc_crc32.argtypes = [_u8p, C.c_size_t]
     lib.orc_crc32.restype = C.c_uint32
     return lib
@@ -227,6 +231,25 @@ def lzss_container_decompress(blob):
     if not lib().orc_lzss_container_decompress(_p8(a), a.size, _p8(out), C.byref(n)):
         return None
     return out[: n.value].copy()
+
+
+def hd_decode(units, lens, codes, nsym):
+    """bit-serial decode of a CUHD-shaped stream (row f3 checker)"""
+    u = np.ascontiguousarray(units, dtype=np.uint32)
+    l = np.ascontiguousarray(lens, dtype=np.uint8)
+    c = np.ascontiguousarray(codes, dtype=np.uint16)
+    out = np.zeros(max(1, nsym), dtype=np.uint8)
+    rc = lib().orc_hd_decode(_p32(u), u.size, _p8(l), c.ctypes.data_as(C.POINTER(C.c_uint16)), _p8(out), nsym)
+    if rc != 0:
+        raise ValueError("oracle hd decoder: corrupt stream (%d)" % rc)
+    return out[:nsym]
+
+
+def huffman_cost(hist256):
+    h = np.ascontiguousarray(hist256, dtype=np.uint64)
+    d = C.c_int(0)
+    cost = lib().orc_huffman_cost(h.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(d))
+    return cost, d.value
 
 
 def crc32(data):
