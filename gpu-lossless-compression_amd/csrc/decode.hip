@@ -135,45 +135,92 @@ __global__ __launch_bounds__(64) void k_dec_huff(const uint32_t *__restrict__ co
 // ---------------------------------------------------------------------------
 // 3. inverse MTF
 // ---------------------------------------------------------------------------
-constexpr int IMTF_WAVES = 4;
 
-// PERM = true : start from the identity list of POSITIONS, no output, store the final list
-//               (= the chunk's position permutation) in lists[chunk]
-// PERM = false: start from lists[chunk] (the real list at the chunk start), write the symbols
-template <bool PERM>
-__global__ __launch_bounds__(IMTF_WAVES * 64) void k_imtf(const uint8_t *__restrict__ in, size_t in_stride,
-                                                          uint32_t n, uint8_t *__restrict__ lists,
-                                                          uint32_t max_chunks, uint8_t *__restrict__ out,
-                                                          size_t out_stride)
+// Pass 1 (k_imtf_pos): one LANE per chunk.  The lane keeps a 256-entry list of POSITIONS
+// (identity at the chunk start) in LDS as 16 x 16-byte words laid out [word][lane] (bank =
+// lane, so data-dependent word indices never conflict).  For every MTF index r it reads
+// entry r, shifts entries 0..r-1 up by one byte (16 bytes per ds_read/ds_write_b128) and puts
+// the entry in front.  Output: the position byte of every symbol (symbol = start_list[pos])
+// and the chunk's final list = its position permutation.
+// Pass 2 (k_imtf_scan) composes the permutations; pass 3 (k_imtf_apply) is a 256-byte LUT
+// lookup per chunk -- the sequential work is done once, not twice.
+constexpr uint32_t IMTF_CHUNK = 2048;
+
+__device__ __forceinline__ uint32_t imtf_mask(int c)     // low c bytes set, c clamped to [0,4]
 {
-    const uint32_t b = blockIdx.y, l = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t chunk = blockIdx.x * IMTF_WAVES + w;
-    const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
-    if (chunk >= nchunks) return;
-    if (PERM && chunk + 1 == nchunks) return;                 // nobody needs the last permutation
-    const uint32_t lo = chunk * MTF_CHUNK, hi = min(n, lo + MTF_CHUNK);
-    const uint8_t *src = in + (size_t)b * in_stride;
-    uint32_t *LW = reinterpret_cast<uint32_t *>(lists + ((size_t)b * max_chunks + chunk) * 256);
-    uint32_t v = PERM ? (0x03020100u + 0x04040404u * l) : LW[l];
-    for (uint32_t p0 = lo; p0 < hi; p0 += 64) {
-        const uint32_t cntv = min(64u, hi - p0);
-        const uint32_t inb = (p0 + l < hi) ? src[p0 + l] : 0u;
-        uint32_t outb = 0;
-        for (uint32_t j = 0; j < cntv; j++) {
-            const uint32_t p = __builtin_amdgcn_readlane(inb, j);            // MTF index, uniform
-            const uint32_t L = p >> 2, bidx = p & 3;
-            const uint32_t x = (__builtin_amdgcn_readlane(v, L) >> (8 * bidx)) & 0xFFu;
-            outb = (l == j) ? x : outb;
-            const uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)(v >> 24), 0x138, 0xf, 0xf, false);
-            const uint32_t shifted = (v << 8) | carry;
-            const uint32_t m2 = (bidx == 3) ? 0xFFFFFFFFu : ((1u << (8 * (bidx + 1))) - 1u);
-            const uint32_t mask = (l < L) ? 0xFFFFFFFFu : ((l == L) ? m2 : 0u);
-            v = (v & ~mask) | (shifted & mask);
-        }
-        if (!PERM && p0 + l < hi) out[(size_t)b * out_stride + p0 + l] = (uint8_t)outb;
+    return c >= 4 ? 0xFFFFFFFFu : (c <= 0 ? 0u : ((1u << (8 * c)) - 1u));
+}
+
+__global__ __launch_bounds__(64) void k_imtf_pos(const uint8_t *__restrict__ in, size_t in_stride, uint32_t n,
+                                                 uint8_t *__restrict__ lists, uint32_t max_chunks,
+                                                 uint8_t *__restrict__ pos_out, size_t out_stride)
+{
+    __shared__ uint4 s_list[16 * 64];
+    const uint32_t b = blockIdx.y, l = threadIdx.x;
+    const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
+    const uint32_t chunk = blockIdx.x * 64 + l;
+    const bool live = chunk < nchunks;
+    const uint32_t lo = chunk * IMTF_CHUNK;
+    const uint32_t cnt = live ? min(IMTF_CHUNK, n - lo) : 0u;
+    const uint8_t *src = in + (size_t)b * in_stride + lo;
+    uint8_t *dst = pos_out + (size_t)b * out_stride + lo;
+    const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_list);
+    const bool vec_ok = ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t v = 0x03020100u + 0x10101010u * k;
+        s_list[k * 64 + l] = make_uint4(v, v + 0x04040404u, v + 0x08080808u, v + 0x0C0C0C0Cu);
     }
-    if (PERM) LW[l] = v;
+    for (uint32_t j = 0; j < IMTF_CHUNK; j += 16) {
+        if (__ballot(j < cnt) == 0) break;
+        uint32_t rv[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
+        if (vec_ok && j + 16 <= cnt) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(src + j);
+            rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
+        } else if (j < cnt) {
+            for (uint32_t t = 0; t < min(16u, cnt - j); t++) rv[t >> 2] |= (uint32_t)src[j + t] << (8 * (t & 3));
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 16; t++) {
+            const uint32_t r = (rv[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+            const bool on = j + t < cnt;
+            const uint32_t W = on ? (r >> 4) : 0u;
+            const uint32_t sym = s_bytes[((r >> 4) * 64 + l) * 16 + (r & 15)];
+            uint32_t carry = sym;
+            for (uint32_t k = 0; k < W; k++) {                   // whole 16-byte words below the hit
+                const uint4 o = s_list[k * 64 + l];
+                uint4 nw;
+                nw.x = (o.x << 8) | carry;
+                nw.y = __builtin_amdgcn_alignbit(o.y, o.x, 24);
+                nw.z = __builtin_amdgcn_alignbit(o.z, o.y, 24);
+                nw.w = __builtin_amdgcn_alignbit(o.w, o.z, 24);
+                carry = o.w >> 24;
+                s_list[k * 64 + l] = nw;
+            }
+            if (on) {                                            // the word holding entry r: bytes 0..r&15 move
+                const uint4 o = s_list[W * 64 + l];
+                const int rb = (int)(r & 15) + 1;
+                const uint32_t m0 = imtf_mask(rb), m1 = imtf_mask(rb - 4), m2 = imtf_mask(rb - 8), m3 = imtf_mask(rb - 12);
+                uint4 nw;
+                nw.x = (o.x & ~m0) | (((o.x << 8) | carry) & m0);
+                nw.y = (o.y & ~m1) | (__builtin_amdgcn_alignbit(o.y, o.x, 24) & m1);
+                nw.z = (o.z & ~m2) | (__builtin_amdgcn_alignbit(o.z, o.y, 24) & m2);
+                nw.w = (o.w & ~m3) | (__builtin_amdgcn_alignbit(o.w, o.z, 24) & m3);
+                s_list[W * 64 + l] = nw;
+            }
+            ov[t >> 2] |= sym << (8 * (t & 3));
+        }
+        if (vec_ok && j + 16 <= cnt) {
+            *reinterpret_cast<uint4 *>(dst + j) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+        } else if (j < cnt) {
+            for (uint32_t t = 0; t < min(16u, cnt - j); t++) dst[j + t] = (uint8_t)(ov[t >> 2] >> (8 * (t & 3)));
+        }
+    }
+    if (live && chunk + 1 < nchunks) {                           // nobody needs the last permutation
+        uint4 *LW = reinterpret_cast<uint4 *>(lists + ((size_t)b * max_chunks + chunk) * 256);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) LW[k] = s_list[k * 64 + l];
+    }
 }
 
 // lists[c] <- list at the start of chunk c ; state' [k] = state[perm_c[k]]
@@ -181,12 +228,13 @@ __global__ __launch_bounds__(64) void k_imtf_scan(uint8_t *__restrict__ lists, u
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_state[256];
     const uint32_t b = blockIdx.x, l = threadIdx.x;
-    const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
+    const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
     reinterpret_cast<uint32_t *>(s_state)[l] = 0x03020100u + 0x04040404u * l;
     __builtin_amdgcn_wave_barrier();
+    uint32_t p4 = (1 < nchunks) ? reinterpret_cast<uint32_t *>(lists + (size_t)b * max_chunks * 256)[l] : 0u;
     for (uint32_t c = 0; c < nchunks; c++) {
         uint32_t *LW = reinterpret_cast<uint32_t *>(lists + ((size_t)b * max_chunks + c) * 256);
-        const uint32_t p4 = (c + 1 < nchunks) ? LW[l] : 0u;
+        const uint32_t pn = (c + 2 < nchunks) ? LW[64 + l] : 0u;  // prefetch the next chunk's permutation
         const uint32_t cur = reinterpret_cast<const uint32_t *>(s_state)[l];
         LW[l] = cur;
         if (c + 1 == nchunks) break;
@@ -195,6 +243,32 @@ __global__ __launch_bounds__(64) void k_imtf_scan(uint8_t *__restrict__ lists, u
         __builtin_amdgcn_wave_barrier();
         reinterpret_cast<uint32_t *>(s_state)[l] = nv;
         __builtin_amdgcn_wave_barrier();
+        p4 = pn;
+    }
+}
+
+// symbols = start_list[pos], in place.  One workgroup per chunk.
+__global__ __launch_bounds__(256) void k_imtf_apply(uint8_t *__restrict__ buf, size_t stride, uint32_t n,
+                                                    const uint8_t *__restrict__ lists, uint32_t max_chunks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+    const uint32_t b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64)
+        reinterpret_cast<uint32_t *>(s_lut)[tid] =
+            reinterpret_cast<const uint32_t *>(lists + ((size_t)b * max_chunks + chunk) * 256)[tid];
+    __syncthreads();
+    const uint32_t lo = chunk * IMTF_CHUNK + tid * 8;
+    uint8_t *P = buf + (size_t)b * stride + lo;
+    if (lo + 8 <= n && (reinterpret_cast<size_t>(P) & 7) == 0) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(P);
+        uint2 o;
+        o.x = (uint32_t)s_lut[q.x & 0xFF] | ((uint32_t)s_lut[(q.x >> 8) & 0xFF] << 8) |
+              ((uint32_t)s_lut[(q.x >> 16) & 0xFF] << 16) | ((uint32_t)s_lut[q.x >> 24] << 24);
+        o.y = (uint32_t)s_lut[q.y & 0xFF] | ((uint32_t)s_lut[(q.y >> 8) & 0xFF] << 8) |
+              ((uint32_t)s_lut[(q.y >> 16) & 0xFF] << 16) | ((uint32_t)s_lut[q.y >> 24] << 24);
+        *reinterpret_cast<uint2 *>(P) = o;
+    } else {
+        for (uint32_t i = lo; i < n && i < lo + 8; i++) P[i - lo] = s_lut[P[i - lo]];
     }
 }
 
@@ -357,6 +431,7 @@ hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows)
     s.nmax = nmax; s.rows = rows;
     s.max_tiles = (nmax + 1 + LF_TILE - 1) / LF_TILE;
     s.max_split = (nmax + 1 + SPLIT - 1) / SPLIT;
+    s.max_chunks = (nmax + IMTF_CHUNK - 1) / IMTF_CHUNK;
     size_t total = 0;
     auto A = [&](void **p, size_t bytes) -> hipError_t { total += bytes; return hipMalloc(p, bytes); };
     GLC_TRY(A((void **)&s.mtf, (size_t)nmax * rows));
@@ -367,13 +442,14 @@ hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.max_tiles * 512 * 4));
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * 512 * 4));
     GLC_TRY(A((void **)&s.seg, (size_t)rows * s.max_split * 16));
+    GLC_TRY(A((void **)&s.ilists, (size_t)rows * s.max_chunks * 256));
     s.bytes = total;
     return hipSuccess;
 }
 
 void decode_scratch_free(DecodeScratch &s)
 {
-    void *ps[] = {s.mtf, s.bwt, s.lf, s.lut, s.nodes, s.tile_hist, s.digit_base, s.seg};
+    void *ps[] = {s.mtf, s.bwt, s.lf, s.lut, s.nodes, s.tile_hist, s.digit_base, s.seg, s.ilists};
     for (void *p : ps) if (p) (void)hipFree(p);
     s = DecodeScratch();
 }
@@ -384,16 +460,15 @@ hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t 
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
-    const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
+    const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
     hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes);
     hipLaunchKernelGGL(k_dec_huff, dim3((nsub + 63) / 64, nblk), dim3(64), 0, st, d_comp, comp_stride_words,
                        d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax);
-    dim3 gm((nchunks + IMTF_WAVES - 1) / IMTF_WAVES, nblk), tm(IMTF_WAVES * 64);
-    hipLaunchKernelGGL(k_imtf<true>, gm, tm, 0, st, s.mtf, (size_t)s.nmax, n, ms.lists, ms.max_chunks, s.bwt,
-                       (size_t)s.nmax);
-    hipLaunchKernelGGL(k_imtf_scan, dim3(nblk), dim3(64), 0, st, ms.lists, n, ms.max_chunks);
-    hipLaunchKernelGGL(k_imtf<false>, gm, tm, 0, st, s.mtf, (size_t)s.nmax, n, ms.lists, ms.max_chunks, s.bwt,
-                       (size_t)s.nmax);
+    hipLaunchKernelGGL(k_imtf_pos, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
+                       s.max_chunks, s.bwt, (size_t)s.nmax);
+    hipLaunchKernelGGL(k_imtf_scan, dim3(nblk), dim3(64), 0, st, s.ilists, n, s.max_chunks);
+    hipLaunchKernelGGL(k_imtf_apply, dim3(nchunks, nblk), dim3(256), 0, st, s.bwt, (size_t)s.nmax, n, s.ilists,
+                       s.max_chunks);
     const uint32_t rows = n + 1, tiles = (rows + LF_TILE - 1) / LF_TILE, nsplit = (rows + SPLIT - 1) / SPLIT;
     const size_t lf_stride = (size_t)s.nmax + 4;
     hipLaunchKernelGGL(k_ibwt_hist, dim3(tiles, nblk), dim3(256), 0, st, s.bwt, (size_t)s.nmax, d_bwt_index, n,

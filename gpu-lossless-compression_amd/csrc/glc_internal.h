@@ -108,8 +108,9 @@ hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride
 // decoder (round-trip parity only; the reference has no GPU decoder)
 // ---------------------------------------------------------------------------
 struct DecodeScratch {
-    uint32_t nmax = 0, rows = 0, max_tiles = 0, max_split = 0;
+    uint32_t nmax = 0, rows = 0, max_tiles = 0, max_split = 0, max_chunks = 0;
     uint8_t  *mtf = nullptr, *bwt = nullptr;     // [rows][nmax]
+    uint8_t  *ilists = nullptr;                  // [rows][max_chunks][256] iMTF chunk permutations / start lists
     uint32_t *lf = nullptr;                      // [rows][nmax+1]  (symbol << 21) | LF(row)
     uint32_t *lut = nullptr;                     // [rows][4096] 12-bit Huffman decode table
     uint32_t *nodes = nullptr;                   // [rows][513]  tree for codes longer than 12 bits
