@@ -38,6 +38,8 @@ constexpr int      LF_TILE      = 2048;
 constexpr uint32_t LF_MASK      = (1u << 21) - 1;
 constexpr uint32_t SPLIT        = 128;                   // LF-cycle rows between splitters
 constexpr uint32_t MAX_SPLITS   = (1u << 20) / SPLIT + 8;
+constexpr uint32_t SLOT         = 256;                   // bytes a walk emits before it continues in a new segment
+constexpr uint32_t EMIT_SEGS    = 4;                     // segments per wave in k_ibwt_emit
 
 // ---------------------------------------------------------------------------
 // 1. tree -> 12-bit LUT + node table.  One workgroup per block.
@@ -361,65 +363,118 @@ __global__ __launch_bounds__(256) void k_ibwt_lf(const uint8_t *__restrict__ bwt
     }
 }
 
-// segment walk 1: length of the LF path from splitter row s*SPLIT to the next splitter row
-__global__ __launch_bounds__(256) void k_ibwt_walk1(const uint32_t *__restrict__ lf, size_t lf_stride, uint32_t n,
-                                                    uint32_t *__restrict__ seg, uint32_t max_split)
+// Single LF walk.  Measured on MI355X (tools/probes/gather_probe.hip): dependent random 4-byte
+// reads over a >256 MiB working set top out at ~55 G accesses/s (one 128-byte line from HBM per
+// access), and the walk below runs at that ceiling -- so the text is emitted DURING the one walk
+// instead of walking twice.  A lane starts at splitter row s*SPLIT and emits into a private
+// SLOT-byte slot; a walk that fills its slot before reaching the next splitter row continues in
+// a freshly allocated ("dynamic") segment, so slots are bounded whatever the cycle looks like.
+//   seg_info[id] = len | next << 9 ; ids < nsplit are the static splitters.
+__global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ lf, size_t lf_stride, uint32_t n,
+                                                   uint32_t *__restrict__ seg_info, uint32_t max_seg,
+                                                   uint32_t *__restrict__ seg_count, uint8_t *__restrict__ tmp)
 {
     const uint32_t b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
     const uint32_t rows = n + 1, nsplit = (rows + SPLIT - 1) / SPLIT;
     if (s >= nsplit) return;
     const uint32_t *LF = lf + (size_t)b * lf_stride;
-    uint32_t r = s * SPLIT, len = 0;
-    do { r = LF[r] & LF_MASK; len++; } while ((r & (SPLIT - 1)) != 0 && len <= rows);
-    uint32_t *S = seg + ((size_t)b * max_split + s) * 4;
-    S[0] = len; S[1] = r / SPLIT;
-}
-
-// order the segments along the cycle starting at row 0 (the "$" suffix): segment s emits
-// text positions pos, pos-1, ...  One wave per block; the chase runs in LDS.
-__global__ __launch_bounds__(64) void k_ibwt_order(uint32_t *__restrict__ seg, uint32_t n, uint32_t max_split)
-{
-    __shared__ uint32_t s_len[MAX_SPLITS], s_next[MAX_SPLITS];
-    __shared__ int s_pos[MAX_SPLITS];
-    const uint32_t b = blockIdx.x, l = threadIdx.x;
-    const uint32_t rows = n + 1, nsplit = (rows + SPLIT - 1) / SPLIT;
-    uint32_t *S = seg + (size_t)b * max_split * 4;
-    for (uint32_t i = l; i < nsplit; i += 64) { s_len[i] = S[i * 4]; s_next[i] = S[i * 4 + 1]; s_pos[i] = 0; }
-    __syncthreads();
-    if (l == 0) {
-        uint32_t s = 0;
-        int k = (int)n - 1;
-        for (uint32_t it = 0; it < nsplit; it++) {
-            s_pos[s] = k;
-            k -= (int)s_len[s];
-            s = s_next[s];
-            if (s == 0) break;
+    uint32_t *SI = seg_info + (size_t)b * max_seg;
+    uint4 *T = reinterpret_cast<uint4 *>(tmp + (size_t)b * max_seg * SLOT);
+    uint32_t id = s, r = s * SPLIT, len = 0, steps = 0;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    for (;;) {
+        const uint32_t wv = LF[r];
+        const uint32_t byte = ((wv >> 21) - 1u) & 0xFFu;
+        const uint32_t sh = byte << (8 * (len & 3)), q = (len >> 2) & 3;
+        w0 |= (q == 0) ? sh : 0u; w1 |= (q == 1) ? sh : 0u; w2 |= (q == 2) ? sh : 0u; w3 |= (q == 3) ? sh : 0u;
+        r = wv & LF_MASK;
+        len++; steps++;
+        const bool at_split = (r & (SPLIT - 1)) == 0 || steps > rows;
+        if ((len & 15) == 0 || at_split) {
+            T[(size_t)id * (SLOT / 16) + ((len - 1) >> 4)] = make_uint4(w0, w1, w2, w3);
+            w0 = w1 = w2 = w3 = 0;
+        }
+        if (at_split) { SI[id] = len | ((r / SPLIT) << 9); break; }
+        if (len == SLOT) {
+            const uint32_t nid = atomicAdd(&seg_count[b], 1u);
+            if (nid >= max_seg) { SI[id] = len; break; }            // corrupt stream: give up on this path
+            SI[id] = len | (nid << 9);
+            id = nid; len = 0;
         }
     }
-    __syncthreads();
-    for (uint32_t i = l; i < nsplit; i += 64) S[i * 4 + 2] = (uint32_t)s_pos[i];
 }
 
-// segment walk 2: emit the text
-__global__ __launch_bounds__(256) void k_ibwt_walk2(const uint32_t *__restrict__ lf, size_t lf_stride, uint32_t n,
-                                                    const uint32_t *__restrict__ seg, uint32_t max_split,
-                                                    uint8_t *__restrict__ out, size_t out_stride)
+__global__ void k_ibwt_seg_init(uint32_t *__restrict__ seg_count, uint32_t n, uint32_t nblk)
 {
-    const uint32_t b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t rows = n + 1, nsplit = (rows + SPLIT - 1) / SPLIT;
-    if (s >= nsplit) return;
-    const uint32_t *LF = lf + (size_t)b * lf_stride;
-    const uint32_t *S = seg + ((size_t)b * max_split + s) * 4;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nblk) seg_count[i] = (n + 1 + SPLIT - 1) / SPLIT;
+}
+
+// Text position of every segment: list ranking (pointer jumping) in LDS over the <= MAX_SEG
+// segments of the cycle that starts at segment 0 (row 0 = the "$" suffix).  d[s] = symbols
+// from the start of s to the end of the cycle, so segment s emits positions d[s]-2, d[s]-3, ...
+constexpr uint32_t MAX_SEG  = MAX_SPLITS + ((1u << 20) + 1) / SLOT + 8;
+constexpr uint32_t RANK_NT  = 1024;
+constexpr uint32_t RANK_E   = (MAX_SEG + RANK_NT - 1) / RANK_NT;
+constexpr uint32_t SEG_NIL  = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(RANK_NT) void k_ibwt_rank(const uint32_t *__restrict__ seg_info, uint32_t max_seg,
+                                                       const uint32_t *__restrict__ seg_count,
+                                                       int *__restrict__ seg_pos)
+{
+    __shared__ uint32_t s_d[MAX_SEG], s_nx[MAX_SEG];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nseg = min(seg_count[b], min(max_seg, MAX_SEG));
+    const uint32_t *SI = seg_info + (size_t)b * max_seg;
+    for (uint32_t i = tid; i < nseg; i += RANK_NT) {
+        const uint32_t v = SI[i], nx = v >> 9;
+        s_d[i] = v & 511u;
+        s_nx[i] = (nx == 0 || nx >= nseg) ? SEG_NIL : nx;
+    }
+    __syncthreads();
+    uint32_t nd[RANK_E], nn[RANK_E];
+    for (uint32_t span = 1; span < nseg; span <<= 1) {
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_E; e++) {
+            const uint32_t i = tid + e * RANK_NT;
+            if (i < nseg) {
+                const uint32_t j = s_nx[i];
+                nd[e] = s_d[i] + (j != SEG_NIL ? s_d[j] : 0u);
+                nn[e] = (j != SEG_NIL) ? s_nx[j] : SEG_NIL;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t e = 0; e < RANK_E; e++) {
+            const uint32_t i = tid + e * RANK_NT;
+            if (i < nseg) { s_d[i] = nd[e]; s_nx[i] = nn[e]; }
+        }
+        __syncthreads();
+    }
+    int *P = seg_pos + (size_t)b * max_seg;
+    for (uint32_t i = tid; i < nseg; i += RANK_NT) P[i] = (int)s_d[i] - 2;
+}
+
+// slots -> text (reversed within a segment).  One wave per segment.
+__global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ tmp, const uint32_t *__restrict__ seg_info,
+                                                   const int *__restrict__ seg_pos, uint32_t max_seg,
+                                                   const uint32_t *__restrict__ seg_count, uint32_t n,
+                                                   uint8_t *__restrict__ out, size_t out_stride)
+{
+    const uint32_t b = blockIdx.y, l = threadIdx.x & 63;
+    const uint32_t nseg = min(seg_count[b], max_seg);
     uint8_t *O = out + (size_t)b * out_stride;
-    uint32_t r = s * SPLIT;
-    const uint32_t len = S[0];
-    int k = (int)S[2];
-    for (uint32_t i = 0; i < len; i++) {
-        const uint32_t wv = LF[r];
-        const uint32_t sym = wv >> 21;
-        if (sym != 0 && k >= 0) O[k] = (uint8_t)(sym - 1);
-        k--;
-        r = wv & LF_MASK;
+#pragma unroll 1
+    for (uint32_t k = 0; k < EMIT_SEGS; k++) {
+        const uint32_t id = (blockIdx.x * 4 + (threadIdx.x >> 6)) * EMIT_SEGS + k;
+        if (id >= nseg) return;
+        const uint32_t len = seg_info[(size_t)b * max_seg + id] & 511u;
+        const int pos = seg_pos[(size_t)b * max_seg + id];
+        const uint8_t *S = tmp + ((size_t)b * max_seg + id) * SLOT;
+        for (uint32_t i = l; i < len; i += 64) {
+            const uint32_t t = (uint32_t)(pos - (int)i);
+            if (t < n) O[t] = S[i];
+        }
     }
 }
 
@@ -441,7 +496,11 @@ hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.nodes, (size_t)rows * HUFF_NODES * 4));
     GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.max_tiles * 512 * 4));
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * 512 * 4));
-    GLC_TRY(A((void **)&s.seg, (size_t)rows * s.max_split * 16));
+    s.max_seg = s.max_split + (nmax + 1) / SLOT + 8;
+    GLC_TRY(A((void **)&s.seg, (size_t)rows * s.max_seg * 4));
+    GLC_TRY(A((void **)&s.seg_pos, (size_t)rows * s.max_seg * 4));
+    GLC_TRY(A((void **)&s.seg_count, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.slots, (size_t)rows * s.max_seg * SLOT));
     GLC_TRY(A((void **)&s.ilists, (size_t)rows * s.max_chunks * 256));
     s.bytes = total;
     return hipSuccess;
@@ -449,7 +508,7 @@ hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows)
 
 void decode_scratch_free(DecodeScratch &s)
 {
-    void *ps[] = {s.mtf, s.bwt, s.lf, s.lut, s.nodes, s.tile_hist, s.digit_base, s.seg, s.ilists};
+    void *ps[] = {s.mtf, s.bwt, s.lf, s.lut, s.nodes, s.tile_hist, s.digit_base, s.seg, s.ilists, s.seg_pos, s.seg_count, s.slots};
     for (void *p : ps) if (p) (void)hipFree(p);
     s = DecodeScratch();
 }
@@ -476,11 +535,13 @@ hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t 
     GLC_TRY(tile_hist_scan9(st, s.tile_hist, rows, s.digit_base, s.max_tiles, nblk, LF_TILE));
     hipLaunchKernelGGL(k_ibwt_lf, dim3(tiles, nblk), dim3(256), 0, st, s.bwt, (size_t)s.nmax, d_bwt_index, n,
                        s.tile_hist, s.digit_base, s.max_tiles, s.lf, lf_stride);
-    hipLaunchKernelGGL(k_ibwt_walk1, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,
-                       s.max_split);
-    hipLaunchKernelGGL(k_ibwt_order, dim3(nblk), dim3(64), 0, st, s.seg, n, s.max_split);
-    hipLaunchKernelGGL(k_ibwt_walk2, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,
-                       s.max_split, d_out, (size_t)n);
+    hipLaunchKernelGGL(k_ibwt_seg_init, dim3((nblk + 255) / 256), dim3(256), 0, st, s.seg_count, n, nblk);
+    hipLaunchKernelGGL(k_ibwt_walk, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,
+                       s.max_seg, s.seg_count, s.slots);
+    hipLaunchKernelGGL(k_ibwt_rank, dim3(nblk), dim3(RANK_NT), 0, st, s.seg, s.max_seg, s.seg_count, s.seg_pos);
+    const uint32_t seg_bound = nsplit + rows / SLOT + 1;
+    hipLaunchKernelGGL(k_ibwt_emit, dim3((seg_bound + 4 * EMIT_SEGS - 1) / (4 * EMIT_SEGS), nblk), dim3(256), 0, st,
+                       s.slots, s.seg, s.seg_pos, s.max_seg, s.seg_count, n, d_out, (size_t)n);
     return hipGetLastError();
 }
 

@@ -116,7 +116,11 @@ struct DecodeScratch {
     uint32_t *nodes = nullptr;                   // [rows][513]  tree for codes longer than 12 bits
     uint32_t *tile_hist = nullptr;               // [rows][max_tiles][512]
     uint32_t *digit_base = nullptr;              // [rows][512]
-    uint32_t *seg = nullptr;                     // [rows][max_split][4] len, next, pos, -
+    uint32_t *seg = nullptr;                     // [rows][max_seg] len | next << 9
+    int      *seg_pos = nullptr;                 // [rows][max_seg] text position of the segment's first symbol
+    uint32_t *seg_count = nullptr;               // [rows] segments in use (static splitters + dynamic)
+    uint8_t  *slots = nullptr;                   // [rows][max_seg][256] symbols emitted by each segment
+    uint32_t  max_seg = 0;
     size_t    bytes = 0;
 };
 hipError_t tile_hist_scan9(hipStream_t st, uint32_t *tile_hist, uint32_t count, uint32_t *digit_base,
