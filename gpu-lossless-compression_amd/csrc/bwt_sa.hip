@@ -52,9 +52,19 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_init_keys(const uint8_t *__re
     __shared__ uint16_t s_sym[SA_TILE + 8];
     const uint32_t b = blockIdx.y, base = blockIdx.x * SA_TILE, tid = threadIdx.x;
     const uint8_t *T = text + (size_t)b * text_stride;
-    for (uint32_t i = tid; i < SA_TILE + 4; i += SA_THREADS) {
-        uint32_t gi = base + i;
-        s_sym[i] = gi < n ? (uint16_t)(T[gi] + 1) : (uint16_t)0;
+    {   // all loads of the tile in flight together (a load->LDS-store loop is one latency per trip)
+        uint16_t sy[SA_ITEMS + 1];
+#pragma unroll
+        for (int r = 0; r <= SA_ITEMS; r++) {
+            const uint32_t i = r * SA_THREADS + tid, gi = base + i;
+            const uint32_t x = T[gi < n ? gi : 0u];               // branch-free: the loads overlap
+            sy[r] = (gi < n) ? (uint16_t)(x + 1) : (uint16_t)0;
+        }
+#pragma unroll
+        for (int r = 0; r <= SA_ITEMS; r++) {
+            const uint32_t i = r * SA_THREADS + tid;
+            if (i < SA_TILE + 4) s_sym[i] = sy[r];
+        }
     }
     __syncthreads();
     uint64_t *K = key + (size_t)b * nmax;
@@ -140,11 +150,17 @@ __global__ __launch_bounds__(RS_NT) void k_rs_prehist(const uint64_t *__restrict
     __syncthreads();
     const uint64_t *K = key + (size_t)b * nmax;
     for (uint32_t base = blockIdx.x * RS_TILE; base < m; base += gridDim.x * RS_TILE) {
+        uint64_t kq[RS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {                  // loads first (LDS atomics would serialise them)
+            const uint32_t i = base + r * RS_NT + tid;
+            kq[r] = (i < m) ? K[i] : 0ull;
+        }
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; r++) {
             const uint32_t i = base + r * RS_NT + tid;
             if (i < m) {
-                const uint64_t k = K[i];
+                const uint64_t k = kq[r];
                 for (uint32_t p = 0; p < pp.npass; p++)
                     atomicAdd(&s_h[p][(uint32_t)(k >> pp.shift[p]) & ((1u << pp.bits[p]) - 1u)], 1u);
             }
@@ -199,11 +215,17 @@ __global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__rest
 
     uint64_t k[RS_ITEMS];
     uint32_t rk[RS_ITEMS];
+    // all loads first: the wave barriers in the ranking loop pin memory operations, and a load
+    // issued inside it is waited for before the next one starts (8 serial HBM latencies per tile)
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
+        k[r] = (i < tile_n) ? K[i] : 0ull;
+    }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
         const bool valid = i < tile_n;
-        k[r] = valid ? K[i] : 0ull;
         const uint32_t d = (uint32_t)(k[r] >> shift) & (RADIX - 1);
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -351,9 +373,19 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
     const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
     const uint64_t *K = key + (size_t)b * nmax;
     const uint32_t *P = pos ? pos + (size_t)b * nmax : nullptr;
-    for (uint32_t i = tid; i < SA_TILE + 2; i += SA_THREADS) {
-        const int64_t g = (int64_t)base - 1 + i;
-        LK(i) = (g >= 0 && g < (int64_t)m) ? K[g] : 0ull;
+    {   // SA_ITEMS + 1 loads per thread, all in flight before the first LDS store
+        uint64_t kq[SA_ITEMS + 1];
+#pragma unroll
+        for (int r = 0; r <= SA_ITEMS; r++) {
+            const uint32_t i = r * SA_THREADS + tid;
+            const int64_t g = (int64_t)base - 1 + i;
+            kq[r] = (i < SA_TILE + 2 && g >= 0 && g < (int64_t)m) ? K[g] : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r <= SA_ITEMS; r++) {
+            const uint32_t i = r * SA_THREADS + tid;
+            if (i < SA_TILE + 2) LK(i) = kq[r];
+        }
     }
     __syncthreads();
     const uint32_t l0 = tid * SA_ITEMS, e0 = base + l0;
@@ -438,43 +470,72 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
     uint32_t *HN = hd_next + (size_t)b * nmax;
     const uint8_t *T = text + (size_t)b * text_stride;
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride : nullptr;
-    uint32_t running = carry;
+    // Phase 1 (registers / LDS only): suffix index, group head position of every element
+    uint32_t v[SA_ITEMS], hdpos[SA_ITEMS];
+    {
+        uint32_t running = carry;
+#pragma unroll
+        for (int i = 0; i < SA_ITEMS; i++) {
+            if (headm & (1u << i)) running = e0 + i;
+            hdpos[i] = running;
+            v[i] = (uint32_t)(LK(l0 + i + 1) & VAL_MASK);
+        }
+    }
+    // Phase 2: every gather of the tile issued back to back (a gather inside the store loop is
+    // waited for before the next one starts: 8 x 3 serial latencies per thread)
+    uint32_t slot[SA_ITEMS], grp[SA_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SA_ITEMS; i++) {
+        const uint32_t e = e0 + i;
+        slot[i] = e; grp[i] = hdpos[i];
+        if (P) { slot[i] = P[e < m ? e : 0u]; grp[i] = P[e < m ? hdpos[i] : 0u]; }
+    }
+    uint32_t ch[SA_ITEMS];
+    if (O) {
+#pragma unroll
+        for (int i = 0; i < SA_ITEMS; i++) ch[i] = T[(e0 + i < m) ? (v[i] ? v[i] - 1 : n - 1) : 0u];
+    }
+    uint32_t c0[SA_ITEMS], c1[SA_ITEMS], c2[SA_ITEMS];
+    if (mode != MODE_ISA) {
+#pragma unroll
+        for (int i = 0; i < SA_ITEMS; i++) {
+            const bool un = (unresm & (1u << i)) && (e0 + i < m);
+            const uint32_t p0 = v[i] + depth;
+            // unconditional loads (index 0 when not needed): branch-free, so they all overlap
+            const bool u0 = un && p0 < n, u1 = un && p0 + 1 < n, u2 = un && p0 + 2 < n;
+            const uint32_t x0 = T[u0 ? p0 : 0u], x1 = T[u1 ? p0 + 1 : 0u], x2 = T[u2 ? p0 + 2 : 0u];
+            c0[i] = u0 ? x0 + 1 : 0u;
+            c1[i] = u1 ? x1 + 1 : 0u;
+            c2[i] = u2 ? x2 + 1 : 0u;
+        }
+    }
+    // Phase 3: stores
     uint32_t packed[SA_ITEMS / 4] = {};
 #pragma unroll
     for (int i = 0; i < SA_ITEMS; i++) {
         const uint32_t e = e0 + i;
         if (e < m) {
             const bool head = headm & (1u << i), unres = unresm & (1u << i);
-            if (head) running = e;
-            const uint32_t grp = P ? P[running] : running;    // SA slot of the group head
-            const uint32_t v = (uint32_t)(LK(l0 + i + 1) & VAL_MASK);
-            const uint32_t slot = P ? P[e] : e;
-            if (P) SAo[slot] = v;                             // round 0 (slot == e) goes out coalesced below
+            if (P) SAo[slot[i]] = v[i];                       // round 0 (slot == e) goes out coalesced below
             if (O) {
-                uint8_t c;
-                if (v == 0) { c = T[n - 1]; d_index[b] = (int)slot; }
-                else c = T[v - 1];
-                if (P) O[slot] = c;
-                else packed[i >> 2] |= (uint32_t)c << (8 * (i & 3));
+                if (v[i] == 0) d_index[b] = (int)slot[i];
+                if (P) O[slot[i]] = (uint8_t)ch[i];
+                else packed[i >> 2] |= ch[i] << (8 * (i & 3));
             }
             if (mode == MODE_ISA) {
-                ISA[v] = grp + 1;
+                ISA[v[i]] = grp[i] + 1;
                 if (unres) {
-                    PN[off] = slot;
-                    KN[off] = ((uint64_t)(grp + 1) << R1_SHIFT) | v;
+                    PN[off] = slot[i];
+                    KN[off] = ((uint64_t)(grp[i] + 1) << R1_SHIFT) | v[i];
                     off++;
                 }
             } else {
                 if (head && unres) gcount++;
                 if (unres) {
-                    const uint32_t p0 = v + depth;
-                    const uint32_t c0 = p0 < n ? (uint32_t)T[p0] + 1 : 0u;
-                    const uint32_t c1 = p0 + 1 < n ? (uint32_t)T[p0 + 1] + 1 : 0u;
-                    const uint32_t c2 = p0 + 2 < n ? (uint32_t)T[p0 + 2] + 1 : 0u;
-                    const uint64_t code = ((uint64_t)c0 * 257 + c1) * 257 + c2;
-                    PN[off] = slot;
-                    HN[off] = grp;
-                    KN[off] = ((uint64_t)(gcount - 1) << TXT_GRP_SHIFT) | (code << TXT_CODE_SHIFT) | v;
+                    const uint64_t code = ((uint64_t)c0[i] * 257 + c1[i]) * 257 + c2[i];
+                    PN[off] = slot[i];
+                    HN[off] = grp[i];
+                    KN[off] = ((uint64_t)(gcount - 1) << TXT_GRP_SHIFT) | (code << TXT_CODE_SHIFT) | v[i];
                     off++;
                 }
             }

@@ -76,62 +76,117 @@ __global__ __launch_bounds__(256) void k_dec_prepare(const uint32_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// 2. Huffman decode: lane = one 4096-symbol block
+// 2. Huffman decode: one WAVE per 4096-symbol block.
+//    The block's words are staged in LDS and cut into 64 equal spans, one per lane.  Every lane
+//    decodes its span from bit 0 (speculatively), then lanes whose predecessor ended at a
+//    different bit than they assumed re-decode from there until the chain that starts at lane 0
+//    is consistent -- Huffman codes resynchronise within a few codewords, so this takes 2-3
+//    rounds in practice and at most 64 (lane i is final after round i).  A scan of the symbol
+//    counts gives every lane its output index; a last decode writes the symbols through LDS so
+//    the global store is coalesced.  (A lane per block -- the obvious mapping, and the one the
+//    CPU gold uses -- leaves a 256-block batch with 1024 waves of 4096 dependent steps each.)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_dec_huff(const uint32_t *__restrict__ comp, size_t comp_stride,
-                                                 const uint32_t *__restrict__ offsets, size_t offset_stride,
-                                                 const uint32_t *__restrict__ lut, const uint32_t *__restrict__ nodes,
-                                                 uint32_t n, uint8_t *__restrict__ mtf, size_t mtf_stride)
+constexpr uint32_t DH_WAVES     = 4;
+constexpr uint32_t DH_MAX_SPAN  = (HUFF_MAX_WORDS + 63) / 64;          // 24 words
+constexpr uint32_t DH_WORDS_LDS = 66 * (DH_MAX_SPAN | 1u);             // spans padded to an odd pitch
+
+struct DhTables { const uint16_t *lut; const uint32_t *nodes; };
+
+// decode lane span [0, span_bits) from bit `o`; returns (count << 8) | overshoot.
+// WRITE: symbols go to s_out[base + k] while < limit.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t dh_decode_span(const uint32_t *s_w, uint32_t addr, uint32_t S, uint32_t P,
+                                                   uint32_t o, const DhTables T, uint8_t *s_out, uint32_t base,
+                                                   uint32_t limit)
 {
-    __shared__ uint32_t s_lut[1 << DEC_LUT_BITS];
-    __shared__ uint32_t s_nodes[HUFF_NODES];
-    const uint32_t b = blockIdx.y, tid = threadIdx.x;
-    for (uint32_t i = tid; i < (1u << DEC_LUT_BITS); i += 64) s_lut[i] = lut[((size_t)b << DEC_LUT_BITS) + i];
-    for (uint32_t i = tid; i < HUFF_NODES; i += 64) s_nodes[i] = nodes[(size_t)b * HUFF_NODES + i];
-    __syncthreads();
-    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
-    const uint32_t sub = blockIdx.x * 64 + tid;
-    if (sub >= nsub) return;
-    const uint32_t lo = sub * HUFF_BLOCK, cnt = min((uint32_t)HUFF_BLOCK, n - lo);
-    const uint32_t *w = comp + (size_t)b * comp_stride + offsets[(size_t)b * offset_stride + sub];
-    const uint32_t nwords = w[0];
-    w++;
-    uint8_t *dst = mtf + (size_t)b * mtf_stride + lo;
-    const bool aligned = (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
-    uint64_t buf = 0;                  // next bits at the top
-    uint32_t nb = 0, wi = 0, pack = 0;
-    for (uint32_t i = 0; i < cnt; i++) {
-        if (nb <= 32) {
-            const uint32_t x = wi < nwords ? w[wi] : 0u;
-            wi++;
-            buf |= (uint64_t)x << (32 - nb);
-            nb += 32;
-        }
-        uint32_t e = s_lut[(uint32_t)(buf >> (64 - DEC_LUT_BITS))];
+    const uint32_t span_bits = S * 32;
+    uint32_t left = S;
+    auto next_word = [&]() -> uint32_t {
+        const uint32_t x = s_w[addr];
+        addr++;
+        if (--left == 0) { addr += P - S; left = S; }
+        return x;
+    };
+    uint64_t buf = (uint64_t)next_word() << 32;
+    buf |= next_word();
+    buf <<= o;
+    uint32_t nb = 64 - o, pos = o, cnt = 0;
+    while (pos < span_bits) {
+        if (nb <= 32) { buf |= (uint64_t)next_word() << (32 - nb); nb += 32; }
+        const uint32_t e = T.lut[(uint32_t)(buf >> (64 - DEC_LUT_BITS))];
         uint32_t len, sym;
-        if (!(e & DEC_FLAG)) { sym = e & 0xFFFF; len = e >> 16; }
+        if (!(e & 0x8000u)) { sym = e & 0x3FFu; len = e >> 10; }
         else {
-            uint32_t node = e & 0xFFFF;
+            uint32_t ne = T.nodes[e & 0x3FFu];
             len = DEC_LUT_BITS;
-            uint32_t ne = s_nodes[node];
-            while (!(ne & DEC_FLAG)) {
+            while (!(ne & DEC_FLAG) && len < 33) {
                 const uint32_t bit = (uint32_t)(buf >> (63 - len)) & 1u;
-                node = bit ? (ne >> 16) : (ne & 0xFFFF);
-                ne = s_nodes[node];
+                ne = T.nodes[bit ? (ne >> 16) : (ne & 0xFFFF)];
                 len++;
             }
             sym = ne & 0xFFFF;
         }
-        buf <<= len;
-        nb -= len;
-        pack |= (sym & 0xFF) << (8 * (i & 3));
-        if ((i & 3) == 3) {
-            if (aligned) *reinterpret_cast<uint32_t *>(dst + (i & ~3u)) = pack;
-            else for (int q = 0; q < 4; q++) dst[(i & ~3u) + q] = (uint8_t)(pack >> (8 * q));
-            pack = 0;
-        }
+        len = len ? len : 1u;
+        if (WRITE) { if (base + cnt < limit) s_out[base + cnt] = (uint8_t)sym; }
+        buf <<= len; nb -= len; pos += len; cnt++;
     }
-    for (uint32_t i = cnt & ~3u; i < cnt; i++) dst[i] = (uint8_t)(pack >> (8 * (i & 3)));
+    return (cnt << 8) | (pos - span_bits);
+}
+
+__global__ __launch_bounds__(DH_WAVES * 64) void k_dec_huff(const uint32_t *__restrict__ comp, size_t comp_stride,
+                                                            const uint32_t *__restrict__ offsets, size_t offset_stride,
+                                                            const uint32_t *__restrict__ lut,
+                                                            const uint32_t *__restrict__ nodes, uint32_t n,
+                                                            uint8_t *__restrict__ mtf, size_t mtf_stride)
+{
+    __shared__ uint16_t s_lut[1 << DEC_LUT_BITS];
+    __shared__ uint32_t s_nodes[HUFF_NODES];
+    __shared__ uint32_t s_words[DH_WAVES][DH_WORDS_LDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[DH_WAVES][HUFF_BLOCK];
+    const uint32_t b = blockIdx.y, tid = threadIdx.x, l = tid & 63;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t i = tid; i < (1u << DEC_LUT_BITS); i += DH_WAVES * 64) {
+        const uint32_t e = lut[((size_t)b << DEC_LUT_BITS) + i];
+        s_lut[i] = (e & DEC_FLAG) ? (uint16_t)(0x8000u | (e & 0x3FFu)) : (uint16_t)((e & 0x3FFu) | ((e >> 16) << 10));
+    }
+    for (uint32_t i = tid; i < HUFF_NODES; i += DH_WAVES * 64) s_nodes[i] = nodes[(size_t)b * HUFF_NODES + i];
+    __syncthreads();
+    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    const uint32_t sub = blockIdx.x * DH_WAVES + wv;
+    if (sub >= nsub) return;
+    const uint32_t lo = sub * HUFF_BLOCK, cnt = min((uint32_t)HUFF_BLOCK, n - lo);
+    const uint32_t *w = comp + (size_t)b * comp_stride + offsets[(size_t)b * offset_stride + sub];
+    const uint32_t nwords = min(w[0], (uint32_t)HUFF_MAX_WORDS);
+    w++;
+    const uint32_t S = max(1u, (nwords + 63) / 64), P = S | 1u;
+    uint32_t *sw = s_words[wv];
+    for (uint32_t g = l; g < 66 * S; g += 64) {                   // 64 spans + two zero spans of look-ahead
+        const uint32_t q = g / S;
+        sw[q * P + (g - q * S)] = g < nwords ? w[g] : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const DhTables T{s_lut, s_nodes};
+    uint8_t *so = s_out[wv];
+    uint32_t start = 0;
+    uint32_t r = dh_decode_span<false>(sw, l * P, S, P, 0, T, so, 0, 0);
+    for (uint32_t it = 0; it < 64; it++) {
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(r & 0xFFu), 0x138, 0xf, 0xf, false);  // wave_shr:1
+        const bool need = prev != start;
+        if (__ballot(need) == 0) break;
+        if (need) { start = prev; r = dh_decode_span<false>(sw, l * P, S, P, start, T, so, 0, 0); }
+    }
+    const uint32_t c = r >> 8;
+    const uint32_t base = wave_incl_add(c) - c;
+    (void)dh_decode_span<true>(sw, l * P, S, P, start, T, so, base, cnt);
+    __builtin_amdgcn_wave_barrier();
+    uint8_t *dst = mtf + (size_t)b * mtf_stride + lo;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && cnt == HUFF_BLOCK) {
+#pragma unroll
+        for (uint32_t k = 0; k < HUFF_BLOCK / 1024; k++)
+            reinterpret_cast<uint4 *>(dst)[k * 64 + l] = reinterpret_cast<const uint4 *>(so)[k * 64 + l];
+    } else {
+        for (uint32_t i = l; i < cnt; i += 64) dst[i] = so[i];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -173,15 +228,21 @@ __global__ __launch_bounds__(64) void k_imtf_pos(const uint8_t *__restrict__ in,
         const uint32_t v = 0x03020100u + 0x10101010u * k;
         s_list[k * 64 + l] = make_uint4(v, v + 0x04040404u, v + 0x08080808u, v + 0x0C0C0C0Cu);
     }
-    for (uint32_t j = 0; j < IMTF_CHUNK; j += 16) {
-        if (__ballot(j < cnt) == 0) break;
-        uint32_t rv[4] = {0, 0, 0, 0}, ov[4] = {0, 0, 0, 0};
+    auto load16 = [&](uint32_t j, uint32_t *rv) {
+        rv[0] = rv[1] = rv[2] = rv[3] = 0;
         if (vec_ok && j + 16 <= cnt) {
             const uint4 q = *reinterpret_cast<const uint4 *>(src + j);
             rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
         } else if (j < cnt) {
             for (uint32_t t = 0; t < min(16u, cnt - j); t++) rv[t >> 2] |= (uint32_t)src[j + t] << (8 * (t & 3));
         }
+    };
+    uint32_t nx[4];
+    load16(0, nx);
+    for (uint32_t j = 0; j < IMTF_CHUNK; j += 16) {
+        if (__ballot(j < cnt) == 0) break;
+        uint32_t rv[4] = {nx[0], nx[1], nx[2], nx[3]}, ov[4] = {0, 0, 0, 0};
+        load16(j + 16, nx);                                   // in flight while these 16 are processed
 #pragma unroll
         for (uint32_t t = 0; t < 16; t++) {
             const uint32_t r = (rv[t >> 2] >> (8 * (t & 3))) & 0xFFu;
@@ -189,7 +250,32 @@ __global__ __launch_bounds__(64) void k_imtf_pos(const uint8_t *__restrict__ in,
             const uint32_t W = on ? (r >> 4) : 0u;
             const uint32_t sym = s_bytes[((r >> 4) * 64 + l) * 16 + (r & 15)];
             uint32_t carry = sym;
-            for (uint32_t k = 0; k < W; k++) {                   // whole 16-byte words below the hit
+            uint32_t k = 0;
+            for (; k + 4 <= W; k += 4) {                         // 64 bytes per trip: the four reads overlap
+                const uint4 a = s_list[(k + 0) * 64 + l], bq = s_list[(k + 1) * 64 + l];
+                const uint4 c = s_list[(k + 2) * 64 + l], d = s_list[(k + 3) * 64 + l];
+                uint4 na, nb, nc, nd;
+                na.x = (a.x << 8) | carry;
+                na.y = __builtin_amdgcn_alignbit(a.y, a.x, 24);
+                na.z = __builtin_amdgcn_alignbit(a.z, a.y, 24);
+                na.w = __builtin_amdgcn_alignbit(a.w, a.z, 24);
+                nb.x = __builtin_amdgcn_alignbit(bq.x, a.w, 24);
+                nb.y = __builtin_amdgcn_alignbit(bq.y, bq.x, 24);
+                nb.z = __builtin_amdgcn_alignbit(bq.z, bq.y, 24);
+                nb.w = __builtin_amdgcn_alignbit(bq.w, bq.z, 24);
+                nc.x = __builtin_amdgcn_alignbit(c.x, bq.w, 24);
+                nc.y = __builtin_amdgcn_alignbit(c.y, c.x, 24);
+                nc.z = __builtin_amdgcn_alignbit(c.z, c.y, 24);
+                nc.w = __builtin_amdgcn_alignbit(c.w, c.z, 24);
+                nd.x = __builtin_amdgcn_alignbit(d.x, c.w, 24);
+                nd.y = __builtin_amdgcn_alignbit(d.y, d.x, 24);
+                nd.z = __builtin_amdgcn_alignbit(d.z, d.y, 24);
+                nd.w = __builtin_amdgcn_alignbit(d.w, d.z, 24);
+                carry = d.w >> 24;
+                s_list[(k + 0) * 64 + l] = na; s_list[(k + 1) * 64 + l] = nb;
+                s_list[(k + 2) * 64 + l] = nc; s_list[(k + 3) * 64 + l] = nd;
+            }
+            for (; k < W; k++) {                                 // whole 16-byte words below the hit
                 const uint4 o = s_list[k * 64 + l];
                 uint4 nw;
                 nw.x = (o.x << 8) | carry;
@@ -281,9 +367,8 @@ __global__ __launch_bounds__(256) void k_imtf_apply(uint8_t *__restrict__ buf, s
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t row_symbol(const uint8_t *__restrict__ B, uint32_t r, uint32_t index)
 {
-    if (r == 0) return (uint32_t)B[index] + 1;
-    if (r == index + 1) return 0;
-    return (uint32_t)B[r - 1] + 1;
+    const uint32_t x = B[r == 0 ? index : r - 1];          // one branch-free load, so unrolled callers overlap them
+    return (r == index + 1) ? 0u : x + 1;
 }
 
 __global__ __launch_bounds__(256) void k_ibwt_hist(const uint8_t *__restrict__ bwt, size_t bwt_stride,
@@ -298,10 +383,16 @@ __global__ __launch_bounds__(256) void k_ibwt_hist(const uint8_t *__restrict__ b
     __syncthreads();
     const uint8_t *B = bwt + (size_t)b * bwt_stride;
     const uint32_t index = (uint32_t)d_index[b];
+    uint32_t sy[LF_TILE / 256];
 #pragma unroll
     for (int k = 0; k < LF_TILE / 256; k++) {
         const uint32_t r = base + k * 256 + tid;
-        if (r < rows) atomicAdd(&s_h[w][row_symbol(B, r, index)], 1u);
+        sy[k] = row_symbol(B, r < rows ? r : 0u, index);
+    }
+#pragma unroll
+    for (int k = 0; k < LF_TILE / 256; k++) {
+        const uint32_t r = base + k * 256 + tid;
+        if (r < rows) atomicAdd(&s_h[w][sy[k]], 1u);
     }
     __syncthreads();
     uint32_t *H = tile_hist + ((size_t)b * max_tiles + t) * 512;
@@ -326,10 +417,15 @@ __global__ __launch_bounds__(256) void k_ibwt_lf(const uint8_t *__restrict__ bwt
     const uint32_t index = (uint32_t)d_index[b];
     uint32_t sy[LF_TILE / 256], rk[LF_TILE / 256];
 #pragma unroll
+    for (int k = 0; k < LF_TILE / 256; k++) {                 // loads first: the wave barriers below pin them
+        const uint32_t r = base + w * (LF_TILE / 4) + k * 64 + l;
+        sy[k] = row_symbol(B, r < rows ? r : 0u, index);
+    }
+#pragma unroll
     for (int k = 0; k < LF_TILE / 256; k++) {
         const uint32_t r = base + w * (LF_TILE / 4) + k * 64 + l;
         const bool valid = r < rows;
-        const uint32_t d = valid ? row_symbol(B, r, index) : 0u;
+        const uint32_t d = valid ? sy[k] : 0u;
         sy[k] = d;
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -521,7 +617,7 @@ hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t 
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
     hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes);
-    hipLaunchKernelGGL(k_dec_huff, dim3((nsub + 63) / 64, nblk), dim3(64), 0, st, d_comp, comp_stride_words,
+    hipLaunchKernelGGL(k_dec_huff, dim3((nsub + DH_WAVES - 1) / DH_WAVES, nblk), dim3(DH_WAVES * 64), 0, st, d_comp, comp_stride_words,
                        d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax);
     hipLaunchKernelGGL(k_imtf_pos, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
                        s.max_chunks, s.bwt, (size_t)s.nmax);

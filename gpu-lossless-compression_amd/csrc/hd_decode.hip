@@ -41,10 +41,28 @@ __device__ __forceinline__ void hd_stage(const uint32_t *__restrict__ units, siz
                                          uint32_t *s_u, const uint16_t *__restrict__ lut, uint16_t *s_lut)
 {
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < 2048; i += HD_LANES) s_lut[i] = lut[i];
-    for (uint32_t i = tid; i < HD_WG_UNITS; i += HD_LANES) {
-        const size_t gu = base_unit + i;
-        s_u[(i >> 5) * HD_PITCH + (i & 31)] = gu < nunits ? units[gu] : 0u;
+    {   // batches of 8 independent loads, then the LDS stores (a load->store loop is one latency per trip)
+        uint32_t q[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) q[r] = lut[r * HD_LANES + tid];        // two 16-bit entries per word are not
+#pragma unroll                                                            // worth it: the table is read once
+        for (int r = 0; r < 8; r++) s_lut[r * HD_LANES + tid] = (uint16_t)q[r];
+        const bool full = base_unit + HD_WG_UNITS <= nunits;
+#pragma unroll 1
+        for (uint32_t i0 = 0; i0 < HD_WG_UNITS; i0 += 8 * HD_LANES) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t i = i0 + r * HD_LANES + tid;
+                const size_t gu = base_unit + i;
+                q[r] = units[full || gu < nunits ? gu : 0];
+                if (!full && gu >= nunits) q[r] = 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t i = i0 + r * HD_LANES + tid;
+                s_u[(i >> 5) * HD_PITCH + (i & 31)] = q[r];
+            }
+        }
     }
     __syncthreads();
     {   // look-ahead unit of every lane = first unit of the next lane / next workgroup

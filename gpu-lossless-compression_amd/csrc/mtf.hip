@@ -154,10 +154,12 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
         __builtin_amdgcn_wave_barrier();
     }
     const uint64_t lt_mask = (1ull << l) - 1ull;
+    uint32_t sym_next = src[l < C ? l : 0u];
     for (uint32_t base = 0; base < C; base += 64) {
         const uint32_t i = base + l;
         const bool valid = i < C;
-        const uint32_t sym = valid ? src[i] : 0u;
+        const uint32_t sym = valid ? sym_next : 0u;
+        sym_next = src[i + 64 < C ? i + 64 : 0u];                                // in flight during this batch
         // lanes of this batch holding the same symbol
         uint64_t peers = __ballot(valid);
 #pragma unroll
