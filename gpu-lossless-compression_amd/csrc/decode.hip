@@ -427,13 +427,7 @@ __global__ __launch_bounds__(256) void k_ibwt_lf(const uint8_t *__restrict__ bwt
         const bool valid = r < rows;
         const uint32_t d = valid ? sy[k] : 0u;
         sy[k] = d;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 9; bit++) {
-            const bool set = (d >> bit) & 1u;
-            const uint64_t bal = __ballot(set);
-            peers &= set ? bal : ~bal;
-        }
+        const uint64_t peers = wave_match<9>(d, __ballot(valid));
         const uint32_t pre = mbcnt(peers), tot = (uint32_t)__popcll(peers);
         const uint32_t old = s_wc[w][d];
         __builtin_amdgcn_wave_barrier();

@@ -16,6 +16,25 @@ __device__ __forceinline__ unsigned mbcnt(uint64_t m)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// Lanes of `valid` whose low BITS bits of d equal this lane's (the multi-split "match").
+// Accumulates the MISMATCH mask: per bit, x = 0 / ~0 (v_bfe_i32), ballot(x), and lanes that differ
+// from me are ballot ^ x; two bits fold into the accumulator with one v_or3 per half.  5 VALU
+// per bit instead of the 8-9 the select form (set ? bal : ~bal) compiles to -- the LSD passes
+// are VALU-bound on this loop.
+template <int BITS>
+__device__ __forceinline__ uint64_t wave_match(uint32_t d, uint64_t valid)
+{
+    uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+    for (int bit = 0; bit < BITS; bit++) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_sbfe((int)d, bit, 1);
+        const uint64_t bal = __ballot((int)x < 0);
+        mlo |= (uint32_t)bal ^ x;
+        mhi |= (uint32_t)(bal >> 32) ^ x;
+    }
+    return valid & ~(((uint64_t)mhi << 32) | mlo);
+}
+
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t x)
 {
     const unsigned l = lane_id();

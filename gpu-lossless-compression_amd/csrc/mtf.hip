@@ -161,13 +161,7 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
         const uint32_t sym = valid ? sym_next : 0u;
         sym_next = src[i + 64 < C ? i + 64 : 0u];                                // in flight during this batch
         // lanes of this batch holding the same symbol
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
-            const bool set = (sym >> bit) & 1u;
-            const uint64_t bal = __ballot(set);
-            peers &= set ? bal : ~bal;
-        }
+        const uint64_t peers = wave_match<8>(sym, __ballot(valid));
         const uint64_t before = peers & lt_mask;
         const bool hasprev = before != 0;
         const int p = 63 - __builtin_clzll(before | 1ull);                       // previous lane with my symbol
