@@ -13,19 +13,18 @@
 // Parity criterion = round trip (decode(encode(x)) == x) plus equality with the
 // oracle's decoder on the same stream.
 //
-// MI355X design:
-//   Huffman : 12-bit first-level LUT in LDS per workgroup (built once per block
-//             by the tree kernel), one lane per 4096-symbol block (the blocks are
-//             independently addressable through d_encodeOffset).
-//   iMTF    : the MTF index stream of a chunk defines a permutation of list
-//             POSITIONS independent of the list contents, so chunk permutations
-//             are computed in parallel (wave per chunk), composed by a scan, and
-//             every chunk is then decoded in parallel from its start list.
-//   iBWT    : LF mapping by a stable 257-bucket counting sort (tile histograms +
-//             wave64 ballot ranking, no data movement), then the LF cycle is cut
-//             at every row that is a multiple of 1024: all segments are walked
-//             in parallel, ordered by a tiny serial pass over <= 1025 splitters,
-//             and walked again to emit the text.
+// MI355X design (details at each kernel; measurements in DESIGN.md section 5):
+//   Huffman : 12-bit first-level LUT in LDS per workgroup (built once per block by the tree
+//             kernel); one WAVE per 4096-symbol block: 64 lanes decode 64 spans speculatively
+//             and re-synchronise (the blocks are independently addressable via d_encodeOffset).
+//   iMTF    : the MTF index stream of a chunk defines a permutation of list POSITIONS
+//             independent of the list contents: one LANE per chunk produces position bytes +
+//             the chunk permutation, a scan composes the permutations, a LUT pass maps
+//             positions to symbols.
+//   iBWT    : LF mapping by a stable 257-bucket counting sort (tile histograms + wave64 ballot
+//             ranking, no data movement); the LF cycle is cut at every row that is a multiple
+//             of 128, each piece is walked ONCE emitting into a bounded slot, pieces are
+//             ordered by list ranking in LDS and copied to their text positions.
 #include "glc_device.h"
 #include "glc_internal.h"
 #include "huff_tree.cuh"
