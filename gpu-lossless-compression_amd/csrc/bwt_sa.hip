@@ -204,7 +204,8 @@ __global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__rest
     __shared__ uint32_t s_tile;
     // (Measured and rejected on MI355X: persistent workgroups, 4 per block, prefetching the next
     //  tile's ticket and words while ranking -- 1.49-1.95 ms per full pass against 1.27 ms: the
-    //  second set of words costs the 64-VGPR budget and sibling workgroups look back in lock step.)
+    //  second set of words costs the 64-VGPR budget and sibling workgroups look back in lock step.
+    //  A global ticket over (tile, block) pairs -- no lock step -- at 6 waves/SIMD: 1.40-1.54 ms.)
     // blocks are the FAST grid dimension: consecutive workgroups take tiles of different blocks, so the
     // predecessors of a tile (same block) were dispatched a whole row of workgroups earlier and its
     // look-back finds a finished prefix at the first probe (tiles-fast dispatch: 33 % of the pass was
