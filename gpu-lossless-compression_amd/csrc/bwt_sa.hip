@@ -43,46 +43,6 @@ __device__ __forceinline__ uint32_t live_count(const uint32_t *cnt, uint32_t nfi
 }
 
 // ---------------------------------------------------------------------------
-// round-0 words: 5 symbols in base 257 (257^5 < 2^41) | suffix index
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(SA_THREADS) void k_sa_init_keys(const uint8_t *__restrict__ text,
-                                                             size_t text_stride, uint32_t n,
-                                                             uint64_t *__restrict__ key, uint32_t nmax)
-{
-    __shared__ uint16_t s_sym[SA_TILE + 8];
-    const uint32_t b = blockIdx.y, base = blockIdx.x * SA_TILE, tid = threadIdx.x;
-    const uint8_t *T = text + (size_t)b * text_stride;
-    {   // all loads of the tile in flight together (a load->LDS-store loop is one latency per trip)
-        uint16_t sy[SA_ITEMS + 1];
-#pragma unroll
-        for (int r = 0; r <= SA_ITEMS; r++) {
-            const uint32_t i = r * SA_THREADS + tid, gi = base + i;
-            const uint32_t x = T[gi < n ? gi : 0u];               // branch-free: the loads overlap
-            sy[r] = (gi < n) ? (uint16_t)(x + 1) : (uint16_t)0;
-        }
-#pragma unroll
-        for (int r = 0; r <= SA_ITEMS; r++) {
-            const uint32_t i = r * SA_THREADS + tid;
-            if (i < SA_TILE + 4) s_sym[i] = sy[r];
-        }
-    }
-    __syncthreads();
-    uint64_t *K = key + (size_t)b * nmax;
-#pragma unroll
-    for (int r = 0; r < SA_ITEMS; r++) {
-        uint32_t li = r * SA_THREADS + tid, gi = base + li;
-        if (gi < n) {
-            uint64_t c = s_sym[li];
-            c = c * 257 + s_sym[li + 1];
-            c = c * 257 + s_sym[li + 2];
-            c = c * 257 + s_sym[li + 3];
-            c = c * 257 + s_sym[li + 4];
-            K[gi] = (c << VAL_BITS) | gi;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // The radix kernels use their own tile: RS_NT threads x 8 words.
 // ---------------------------------------------------------------------------
 constexpr int RS_NT    = 512;                    // threads per radix workgroup
@@ -138,11 +98,57 @@ __global__ __launch_bounds__(512) void k_rs_scan(uint32_t *__restrict__ tile_his
 struct PassPlan { uint32_t npass; uint32_t shift[5]; uint32_t bits[5]; };
 constexpr int RS_MAXPASS = 5;
 
+// Round 0 never materialises its input: the first radix pass and the histogram kernel read the TEXT
+// (1 byte per suffix instead of an 8-byte word written by one kernel and read by two) and build the
+// round-0 words [5 symbols base 257 : 41 | index : 20] in registers from a tile staged in LDS.
+struct TextSrc { const uint8_t *text; size_t stride; uint32_t n; };
+
+// stage text[base, base + RS_TILE + 4) of the block into s_txt (bytes past n read as 0 and are masked below)
+__device__ __forceinline__ void stage_text_tile(const TextSrc ts, uint32_t b, uint32_t base, uint8_t *s_txt)
+{
+    const uint8_t *T = ts.text + (size_t)b * ts.stride;
+    const uint32_t tid = threadIdx.x;
+    if ((reinterpret_cast<size_t>(T + base) & 3) == 0 && base + RS_TILE + 4 <= ts.n) {
+        const uint32_t *T4 = reinterpret_cast<const uint32_t *>(T + base);
+        uint32_t q[RS_TILE / 4 / RS_NT];
+#pragma unroll
+        for (int r = 0; r < RS_TILE / 4 / RS_NT; r++) q[r] = T4[r * RS_NT + tid];
+        const uint32_t halo = (tid == 0) ? T4[RS_TILE / 4] : 0u;
+#pragma unroll
+        for (int r = 0; r < RS_TILE / 4 / RS_NT; r++) reinterpret_cast<uint32_t *>(s_txt)[r * RS_NT + tid] = q[r];
+        if (tid == 0) reinterpret_cast<uint32_t *>(s_txt)[RS_TILE / 4] = halo;
+    } else {
+        uint8_t q[RS_TILE / RS_NT + 1];
+#pragma unroll
+        for (int r = 0; r <= RS_TILE / RS_NT; r++) {
+            const uint32_t i = r * RS_NT + tid, gi = base + i;
+            q[r] = T[gi < ts.n ? gi : 0u];
+        }
+#pragma unroll
+        for (int r = 0; r <= RS_TILE / RS_NT; r++) {
+            const uint32_t i = r * RS_NT + tid;
+            if (i < RS_TILE + 4) s_txt[i] = q[r];
+        }
+    }
+}
+
+// word of suffix base + li from the staged tile
+__device__ __forceinline__ uint64_t text_word(const uint8_t *s_txt, uint32_t li, uint32_t gi, uint32_t n)
+{
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) c = c * 257 + ((gi + j < n) ? (uint32_t)s_txt[li + j] + 1u : 0u);
+    return (c << VAL_BITS) | gi;
+}
+
+template <bool FROM_TEXT>
 __global__ __launch_bounds__(RS_NT) void k_rs_prehist(const uint64_t *__restrict__ key,
                                                       const uint32_t *__restrict__ cnt, uint32_t nfixed,
-                                                      PassPlan pp, uint32_t *__restrict__ ghist, uint32_t nmax)
+                                                      PassPlan pp, uint32_t *__restrict__ ghist, uint32_t nmax,
+                                                      TextSrc ts)
 {
     __shared__ uint32_t s_h[RS_MAXPASS][SA_MAXRADIX];
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[FROM_TEXT ? RS_TILE + 8 : 8];
     const uint32_t b = blockIdx.y, tid = threadIdx.x;
     const uint32_t m = live_count(cnt, nfixed, b);
     if (blockIdx.x * RS_TILE >= m) return;
@@ -151,14 +157,40 @@ __global__ __launch_bounds__(RS_NT) void k_rs_prehist(const uint64_t *__restrict
     const uint64_t *K = key + (size_t)b * nmax;
     for (uint32_t base = blockIdx.x * RS_TILE; base < m; base += gridDim.x * RS_TILE) {
         uint64_t kq[RS_ITEMS];
+        if (FROM_TEXT) {
+            __syncthreads();                                  // previous tile's readers are done
+            stage_text_tile(ts, b, base, s_txt);
+            __syncthreads();
+            // blocked: 8 consecutive suffixes per thread share their symbols -- 12 bytes (one b64 + one b32
+            // LDS read) and a rolling base-257 code instead of 40 byte reads (which suffix a thread counts
+            // does not matter for a histogram)
+            const uint32_t li0 = tid * RS_ITEMS, gi0 = base + li0;
+            const uint2 lo = *reinterpret_cast<const uint2 *>(s_txt + li0);
+            const uint32_t hi = *reinterpret_cast<const uint32_t *>(s_txt + li0 + 8);
+            uint32_t sy[RS_ITEMS + 4];
 #pragma unroll
-        for (int r = 0; r < RS_ITEMS; r++) {                  // loads first (LDS atomics would serialise them)
-            const uint32_t i = base + r * RS_NT + tid;
-            kq[r] = (i < m) ? K[i] : 0ull;
+            for (int j = 0; j < RS_ITEMS + 4; j++) {
+                const uint32_t wd = j < 4 ? lo.x : (j < 8 ? lo.y : hi);
+                sy[j] = (gi0 + j < ts.n) ? ((wd >> (8 * (j & 3))) & 0xFFu) + 1u : 0u;
+            }
+            uint64_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++) c = c * 257 + sy[j];
+#pragma unroll
+            for (int r = 0; r < RS_ITEMS; r++) {
+                kq[r] = c << VAL_BITS;                        // the index bits are not part of any digit
+                c = (c - (uint64_t)sy[r] * 4362470401ull) * 257 + sy[r + 5 < RS_ITEMS + 4 ? r + 5 : 0];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RS_ITEMS; r++) {              // loads first (LDS atomics would serialise them)
+                const uint32_t i = base + r * RS_NT + tid;
+                kq[r] = (i < m) ? K[i] : 0ull;
+            }
         }
 #pragma unroll
         for (int r = 0; r < RS_ITEMS; r++) {
-            const uint32_t i = base + r * RS_NT + tid;
+            const uint32_t i = FROM_TEXT ? base + tid * RS_ITEMS + r : base + r * RS_NT + tid;
             if (i < m) {
                 const uint64_t k = kq[r];
                 for (uint32_t p = 0; p < pp.npass; p++)
@@ -185,7 +217,7 @@ __global__ __launch_bounds__(512) void k_rs_digitbase(const uint32_t *__restrict
 
 constexpr uint32_t OS_AGG = 1u << 22, OS_PFX = 2u << 22, OS_FLAGS = 3u << 22, OS_CNT = (1u << 22) - 1;
 
-template <int BITS>
+template <int BITS, bool FROM_TEXT = false>
 __global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__restrict__ key_in,
                                                        uint64_t *__restrict__ key_out,
                                                        const uint32_t *__restrict__ cnt, uint32_t nfixed,
@@ -193,7 +225,7 @@ __global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__rest
                                                        uint32_t *__restrict__ ticket, uint32_t epoch,
                                                        const uint32_t *__restrict__ digit_base, uint32_t db_stride,
                                                        uint32_t nmax, uint32_t max_tiles,
-                                                       uint32_t *__restrict__ d_err)
+                                                       uint32_t *__restrict__ d_err, TextSrc ts = TextSrc{})
 {
     constexpr int RADIX = 1 << BITS;
     static_assert(RADIX <= RS_NT, "one digit per thread in the look-back");
@@ -226,10 +258,21 @@ __global__ __launch_bounds__(RS_NT, 8) void k_rs_onesweep(const uint64_t *__rest
     uint32_t rk[RS_ITEMS];
     // all loads first: the wave barriers in the ranking loop pin memory operations, and a load
     // issued inside it is waited for before the next one starts (8 serial HBM latencies per tile)
+    if (FROM_TEXT) {                                          // s_key is free until the bucketing phase
+        uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_key);
+        stage_text_tile(ts, b, base, s_txt);
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; r++) {
-        const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
-        k[r] = (i < tile_n) ? K[i] : 0ull;
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
+            k[r] = (i < tile_n) ? text_word(s_txt, i, base + i, ts.n) : 0ull;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) {
+            const uint32_t i = w * (RS_TILE / RS_WAVES) + r * 64 + l;
+            k[r] = (i < tile_n) ? K[i] : 0ull;
+        }
     }
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
@@ -676,13 +719,18 @@ static void prof_collect(SaScratch &s)
 
 // one LSD sort = prehist + digitbase + npass onesweep launches; result ends in `*cur`
 static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, const uint32_t *cnt, uint32_t nfixed,
-                             const PassPlan &pp, uint32_t tiles, uint32_t nblk, SaScratch &s, double live_total)
+                             const PassPlan &pp, uint32_t tiles, uint32_t nblk, SaScratch &s, double live_total,
+                             const TextSrc *src = nullptr)
 {
     // `tiles` counts SA_TILE-word tiles (rank kernel); the radix kernels use RS_TILE
     const uint32_t rs_tiles = (tiles * (uint32_t)SA_TILE + RS_TILE - 1) / RS_TILE;
     GLC_TRY(hipMemsetAsync(s.ghist, 0, (size_t)nblk * RS_MAXPASS * SA_MAXRADIX * 4, st));
-    hipLaunchKernelGGL(k_rs_prehist, dim3(rs_tiles < 32 ? rs_tiles : 32, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed, pp,
-                       s.ghist, s.nmax);
+    if (src)
+        hipLaunchKernelGGL(k_rs_prehist<true>, dim3(rs_tiles < 32 ? rs_tiles : 32, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed,
+                           pp, s.ghist, s.nmax, *src);
+    else
+        hipLaunchKernelGGL(k_rs_prehist<false>, dim3(rs_tiles < 32 ? rs_tiles : 32, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed,
+                           pp, s.ghist, s.nmax, TextSrc{});
     hipLaunchKernelGGL(k_rs_digitbase, dim3(nblk, pp.npass), dim3(512), 0, st, s.ghist, s.digit_base);
     for (uint32_t p = 0; p < pp.npass; p++) {
         if (++s.epoch > 255) {                              // epoch tags wrapped: clear stale granules once
@@ -697,7 +745,11 @@ static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, con
             (void)hipEventRecord(s.prof_ev[2 * s.prof_used], st);
         }
         dim3 g(nblk, rs_tiles);
-        if (pp.bits[p] == 8)
+        if (pp.bits[p] == 8 && p == 0 && src)
+            hipLaunchKernelGGL((k_rs_onesweep<8, true>), g, dim3(RS_NT), 0, st, cur, alt, cnt, nfixed, pp.shift[p],
+                               s.tile_hist, s.ticket, s.epoch, s.digit_base + p * SA_MAXRADIX,
+                               (uint32_t)(RS_MAXPASS * SA_MAXRADIX), s.nmax, s.rs_tiles, s.d_max_cnt + 2, *src);
+        else if (pp.bits[p] == 8)
             hipLaunchKernelGGL(k_rs_onesweep<8>, g, dim3(RS_NT), 0, st, cur, alt, cnt, nfixed, pp.shift[p], s.tile_hist,
                                s.ticket, s.epoch, s.digit_base + p * SA_MAXRADIX, (uint32_t)(RS_MAXPASS * SA_MAXRADIX),
                                s.nmax, s.rs_tiles, s.d_max_cnt + 2);
@@ -721,12 +773,11 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     uint32_t tiles = (n + SA_TILE - 1) / SA_TILE;
     uint64_t *cur = s.keyA, *alt = s.keyB;
     double live_total = (double)n * nblk;
-    hipLaunchKernelGGL(k_sa_init_keys, dim3(tiles, nblk), dim3(SA_THREADS), 0, st, text, text_stride, n, cur,
-                       s.nmax);
     GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 16, st));          // [2] doubles as the device error word of the sort
     {   // 41 key bits at [20, 61): 8+8+8+8+9
         PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 16, VAL_BITS + 24, VAL_BITS + 32}, {8, 8, 8, 8, 9}};
-        GLC_TRY(radix_sort(st, cur, alt, nullptr, n, pp, tiles, nblk, s, live_total));
+        const TextSrc src{text, text_stride, n};               // pass 0 and the histograms read the text itself
+        GLC_TRY(radix_sort(st, cur, alt, nullptr, n, pp, tiles, nblk, s, live_total, &src));
     }
 
     uint32_t *cnt_cur = nullptr, *cnt_next = s.cntA, *cnt_spare = s.cntB;
