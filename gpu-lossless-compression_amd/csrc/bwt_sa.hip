@@ -395,6 +395,7 @@ __device__ __forceinline__ uint64_t lb_combine(uint64_t earlier, uint64_t later)
     return ((he > hl ? he : hl) << 41) | cnts;
 }
 
+template <bool ROUND0>
 __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restrict__ key,
                                                          const uint32_t *__restrict__ pos,
                                                          const uint32_t *__restrict__ cnt, uint32_t nfixed,
@@ -468,7 +469,9 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
     __syncthreads();
     if ((tid & 63) == 0) s_tmp[tid >> 6] = mx;
     __syncthreads();
-    const uint32_t tile_lh = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
+    uint32_t tile_lh = 0;
+#pragma unroll
+    for (int q = 0; q < SA_THREADS / 64; q++) tile_lh = max(tile_lh, s_tmp[q]);
 
     // ---- decoupled look-back over the tiles of this block (wave 0) ----
     unsigned long long *ST = tile_state + (size_t)b * max_tiles;
@@ -540,33 +543,30 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
         }
     }
     // Phase 2: every gather of the tile issued back to back (a gather inside the store loop is
-    // waited for before the next one starts: 8 x 3 serial latencies per thread)
-    uint32_t slot[SA_ITEMS], grp[SA_ITEMS];
+    // waited for before the next one starts).  ROUND0: slot == e and the head's slot is its own
+    // position, so nothing is gathered but the BWT byte.
+    uint32_t slot[ROUND0 ? 1 : SA_ITEMS], grp[ROUND0 ? 1 : SA_ITEMS];
+    if (!ROUND0) {
 #pragma unroll
-    for (int i = 0; i < SA_ITEMS; i++) {
-        const uint32_t e = e0 + i;
-        slot[i] = e; grp[i] = hdpos[i];
-        if (P) { slot[i] = P[e < m ? e : 0u]; grp[i] = P[e < m ? hdpos[i] : 0u]; }
+        for (int i = 0; i < SA_ITEMS; i++) {
+            const uint32_t e = e0 + i;
+            slot[i] = P[e < m ? e : 0u]; grp[i] = P[e < m ? hdpos[i] : 0u];
+        }
     }
+#define SLOT(i) (ROUND0 ? e0 + (i) : slot[ROUND0 ? 0 : (i)])
+#define GRP(i)  (ROUND0 ? hdpos[i] : grp[ROUND0 ? 0 : (i)])
     uint32_t ch[SA_ITEMS];
     if (O) {
 #pragma unroll
         for (int i = 0; i < SA_ITEMS; i++) ch[i] = T[(e0 + i < m) ? (v[i] ? v[i] - 1 : n - 1) : 0u];
     }
-    uint32_t c0[SA_ITEMS], c1[SA_ITEMS], c2[SA_ITEMS];
-    if (mode != MODE_ISA) {
-#pragma unroll
-        for (int i = 0; i < SA_ITEMS; i++) {
-            const bool un = (unresm & (1u << i)) && (e0 + i < m);
-            const uint32_t p0 = v[i] + depth;
-            // unconditional loads (index 0 when not needed): branch-free, so they all overlap
-            const bool u0 = un && p0 < n, u1 = un && p0 + 1 < n, u2 = un && p0 + 2 < n;
-            const uint32_t x0 = T[u0 ? p0 : 0u], x1 = T[u1 ? p0 + 1 : 0u], x2 = T[u2 ? p0 + 2 : 0u];
-            c0[i] = u0 ? x0 + 1 : 0u;
-            c1[i] = u1 ? x1 + 1 : 0u;
-            c2[i] = u2 ? x2 + 1 : 0u;
-        }
+    if (ROUND0) {                                             // SA[e] = v, coalesced straight from the staged words
+        for (uint32_t i = tid; i < SA_TILE; i += SA_THREADS)
+            if (base + i < m) SAo[base + i] = (uint32_t)(LK(i + 1) & VAL_MASK);
     }
+    __syncthreads();                                          // the staged words are dead: s_k becomes the
+    uint64_t *s_un = s_k;                                     // tile's list of unresolved {group, suffix}
+    const uint32_t tile_off0 = (uint32_t)((excl >> 20) & 0x1FFFFF);
     // Phase 3: stores
     uint32_t packed[SA_ITEMS / 4] = {};
 #pragma unroll
@@ -574,37 +574,47 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
         const uint32_t e = e0 + i;
         if (e < m) {
             const bool head = headm & (1u << i), unres = unresm & (1u << i);
-            if (P) SAo[slot[i]] = v[i];                       // round 0 (slot == e) goes out coalesced below
+            if (!ROUND0) SAo[SLOT(i)] = v[i];
             if (O) {
-                if (v[i] == 0) d_index[b] = (int)slot[i];
-                if (P) O[slot[i]] = (uint8_t)ch[i];
+                if (v[i] == 0) d_index[b] = (int)SLOT(i);
+                if (!ROUND0) O[SLOT(i)] = (uint8_t)ch[i];
                 else packed[i >> 2] |= ch[i] << (8 * (i & 3));
             }
             if (mode == MODE_ISA) {
-                ISA[v[i]] = grp[i] + 1;
+                ISA[v[i]] = GRP(i) + 1;
                 if (unres) {
-                    PN[off] = slot[i];
-                    KN[off] = ((uint64_t)(grp[i] + 1) << R1_SHIFT) | v[i];
+                    PN[off] = SLOT(i);
+                    KN[off] = ((uint64_t)(GRP(i) + 1) << R1_SHIFT) | v[i];
                     off++;
                 }
             } else {
                 if (head && unres) gcount++;
                 if (unres) {
-                    const uint64_t code = ((uint64_t)c0[i] * 257 + c1[i]) * 257 + c2[i];
-                    PN[off] = slot[i];
-                    HN[off] = grp[i];
-                    KN[off] = ((uint64_t)(gcount - 1) << TXT_GRP_SHIFT) | (code << TXT_CODE_SHIFT) | v[i];
+                    PN[off] = SLOT(i);
+                    HN[off] = GRP(i);
+                    s_un[off - tile_off0] = ((uint64_t)(gcount - 1) << TXT_GRP_SHIFT) | v[i];
                     off++;
                 }
             }
         }
     }
-    if (!P) {                                                 // round 0: SA[e] = v, transposed through LDS
-        __syncthreads();                                      // everyone is done reading the words
-        for (uint32_t i = tid; i < SA_TILE; i += SA_THREADS)
-            if (base + i < m) SAo[base + i] = (uint32_t)(LK(i + 1) & VAL_MASK);
+#undef SLOT
+#undef GRP
+    if (mode != MODE_ISA) {
+        // next round's words for the unresolved suffixes, densely: one thread per list entry reads the
+        // 3 symbols that follow the `depth` already compared (the same loads issued per tile ELEMENT
+        // touch 24 mostly-idle wave instructions when 4 % of the elements are unresolved)
+        __syncthreads();
+        for (uint32_t j = tid; j < tile_uc; j += SA_THREADS) {
+            const uint64_t ent = s_un[j];
+            const uint32_t p0 = (uint32_t)(ent & VAL_MASK) + depth;
+            const uint32_t x0 = T[p0 < n ? p0 : 0u], x1 = T[p0 + 1 < n ? p0 + 1 : 0u], x2 = T[p0 + 2 < n ? p0 + 2 : 0u];
+            const uint32_t c0 = p0 < n ? x0 + 1 : 0u, c1 = p0 + 1 < n ? x1 + 1 : 0u, c2 = p0 + 2 < n ? x2 + 1 : 0u;
+            const uint64_t code = ((uint64_t)c0 * 257 + c1) * 257 + c2;
+            KN[tile_off0 + j] = ent | (code << TXT_CODE_SHIFT);
+        }
     }
-    if (O && !P) {                                            // round 0: slot == e, 8 consecutive bytes per thread
+    if (O && ROUND0) {                                        // round 0: slot == e, 8 consecutive bytes per thread
         const bool al = ((reinterpret_cast<uintptr_t>(O) & 3) == 0);
 #pragma unroll
         for (int q = 0; q < SA_ITEMS / 4; q++) {
@@ -798,10 +808,16 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
         GLC_TRY(hipMemsetAsync(cnt_next, 0, (size_t)nblk * 4, st));   // blocks with nothing left launch no tile
         GLC_TRY(hipMemsetAsync(s.tile_state, 0, (size_t)nblk * s.max_tiles * 8, st));
-        hipLaunchKernelGGL(k_sa_rank1, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
-                           (unsigned long long *)s.tile_state, s.ticket, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
-                           s.d_max_cnt, s.nmax, s.max_tiles, mode, text, text_stride, n, depth, bwt_out, bwt_stride,
-                           d_index, s.d_max_cnt + 2);
+        if (!pos_cur)
+            hipLaunchKernelGGL(k_sa_rank1<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
+                               (unsigned long long *)s.tile_state, s.ticket, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
+                               s.d_max_cnt, s.nmax, s.max_tiles, mode, text, text_stride, n, depth, bwt_out, bwt_stride,
+                               d_index, s.d_max_cnt + 2);
+        else
+            hipLaunchKernelGGL(k_sa_rank1<false>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
+                               (unsigned long long *)s.tile_state, s.ticket, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
+                               s.d_max_cnt, s.nmax, s.max_tiles, mode, text, text_stride, n, depth, bwt_out, bwt_stride,
+                               d_index, s.d_max_cnt + 2);
         GLC_TRY(hipGetLastError());
         GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 16, hipMemcpyDeviceToHost, st));
         GLC_TRY(hipStreamSynchronize(st));
