@@ -35,40 +35,45 @@ __device__ __forceinline__ uint64_t wave_match(uint32_t d, uint64_t valid)
     return valid & ~(((uint64_t)mhi << 32) | mlo);
 }
 
+// Wave64 scans on DPP (gfx9 row_shr within rows of 16, then row_bcast:15 / row_bcast:31 across
+// rows): 6 VALU instructions, no LDS crossbar.  (__shfl_up compiles to ds_bpermute_b32: an LDS round
+// trip per step, 6 dependent steps per scan, and the rank kernel runs three scans per tile.)
+#define GLC_DPP(x, ctrl, rowmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rowmask), 0xf, false))
+
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t x)
 {
-    const unsigned l = lane_id();
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        uint32_t y = __shfl_up(x, o, WAVE);
-        if (l >= (unsigned)o) x += y;
-    }
+    x += GLC_DPP(x, 0x111, 0xf);       // row_shr:1  (lanes without a source read `old` = 0)
+    x += GLC_DPP(x, 0x112, 0xf);       // row_shr:2
+    x += GLC_DPP(x, 0x114, 0xf);       // row_shr:4
+    x += GLC_DPP(x, 0x118, 0xf);       // row_shr:8
+    x += GLC_DPP(x, 0x142, 0xa);       // row_bcast:15 -> rows 1 and 3
+    x += GLC_DPP(x, 0x143, 0xc);       // row_bcast:31 -> rows 2 and 3
     return x;
 }
 
 __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x)
 {
-    const unsigned l = lane_id();
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        uint32_t y = __shfl_up(x, o, WAVE);
-        if (l >= (unsigned)o) x = x > y ? x : y;
-    }
+    uint32_t y;
+    y = GLC_DPP(x, 0x111, 0xf); x = x > y ? x : y;
+    y = GLC_DPP(x, 0x112, 0xf); x = x > y ? x : y;
+    y = GLC_DPP(x, 0x114, 0xf); x = x > y ? x : y;
+    y = GLC_DPP(x, 0x118, 0xf); x = x > y ? x : y;
+    y = GLC_DPP(x, 0x142, 0xa); x = x > y ? x : y;
+    y = GLC_DPP(x, 0x143, 0xc); x = x > y ? x : y;
     return x;
 }
 
+// value of the previous lane (0 for lane 0): DPP wave_shr:1
+__device__ __forceinline__ uint32_t wave_prev(uint32_t x) { return GLC_DPP(x, 0x138, 0xf); }
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
 {
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
-    return x;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_add(x), 63);
 }
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t x)
 {
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) { uint32_t y = __shfl_xor(x, o, WAVE); x = x > y ? x : y; }
-    return x;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(x), 63);
 }
 
 // Workgroup exclusive prefix sum; every thread of the NT-thread block calls it.
@@ -102,8 +107,7 @@ __device__ __forceinline__ uint32_t block_excl_max(uint32_t x, uint32_t *s_tmp)
     uint32_t base = 0;
 #pragma unroll
     for (int i = 0; i < NW; i++) { uint32_t v = s_tmp[i]; if ((unsigned)i < w) base = base > v ? base : v; }
-    uint32_t prev = __shfl_up(inc, 1, WAVE);
-    if (l == 0) prev = 0;
+    const uint32_t prev = wave_prev(inc);
     return base > prev ? base : prev;
 }
 
