@@ -271,7 +271,7 @@ def main():
             "frac_of_hbm_read_roofline": round(value / world / HBM_PEAK_GBPS, 6),
             "stage_ms_last_batch": {"bwt": round(stage_ms[0], 3), "mtf": round(stage_ms[1], 3),
                                     "huffman": round(stage_ms[2], 3), "total": round(stage_ms[3], 3)},
-            "roofline": {"kernel": "glc::k_rs_onesweep<8> (stable LSD radix scatter with decoupled look-back, suffix sorter)",
+            "roofline": {"kernel": "glc::k_rs_onesweep<8, false> (stable LSD radix scatter with decoupled look-back, suffix sorter)",
                          "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": kp["launches"],

@@ -748,7 +748,9 @@ static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, con
             s.epoch = 1;
         }
         GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
-        const bool prof = s.prof && pp.bits[p] == 8 && s.prof_used < 64;
+        // profiled kernel = k_rs_onesweep<8,false> (16 algorithmic bytes per live suffix); the text-sourced
+        // first pass of round 0 is a different kernel (1 R + 8 W) and is left out
+        const bool prof = s.prof && pp.bits[p] == 8 && !(p == 0 && src) && s.prof_used < 64;
         if (prof) {
             for (int k = 0; k < 2; k++)
                 if (!s.prof_ev[2 * s.prof_used + k]) GLC_TRY(hipEventCreate(&s.prof_ev[2 * s.prof_used + k]));

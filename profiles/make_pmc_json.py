@@ -55,7 +55,7 @@ def main():
             if sub in k:
                 return v
         return None
-    o8 = find("k_rs_onesweep<8")
+    o8 = find("k_rs_onesweep<8, false") or find("k_rs_onesweep<8")
     res = {
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --gib 0.25 --steps 1 "
                    "--warmup 0 --no-cpu-baseline --no-verify (one pass per counter; MI355X; tag %s)" % tag,
