@@ -25,7 +25,7 @@ namespace glc {
 // ---------------------------------------------------------------------------
 // match search: one workgroup (256 threads) per packet, 16 positions / thread
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lzss_match(const uint8_t *__restrict__ in, uint8_t *__restrict__ cand)
+__global__ __launch_bounds__(256, 6) void k_lzss_match(const uint8_t *__restrict__ in, uint8_t *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[LZ_WIN + LZ_PCKT];
     const uint32_t pk = blockIdx.x, tid = threadIdx.x;
@@ -41,22 +41,57 @@ __global__ __launch_bounds__(256) void k_lzss_match(const uint8_t *__restrict__ 
     for (int it = 0; it < LZ_PCKT / 256; it++) {
         const int p = it * 256 + tid;
         const int tx = p & 127;
-        const bool last = (p >> 7) == (LZ_PCKT / 128 - 1);
-        const int iters = last ? max(1, 127 - tx) : 127;
-        const int la_wrap = last ? (128 - tx) : 1 << 20;      // look-ahead index where the stale half begins
-        int length = 1, offset = 1, j = 0;
-        bool matching = false;
-        const uint8_t *win = s_buf + p;                       // text[p-128 + k]
+        const bool last = (p >> 7) == (LZ_PCKT / 128 - 1);     // wave-uniform: waves 2,3 of the last trip
+        int length = 1, offset = 1;
         const uint8_t *la = s_buf + LZ_WIN + p;               // text[p + j]
-        for (int k = 0; k < iters; k++) {
-            const uint8_t lb = (j < la_wrap) ? la[j] : la[j - 256];
-            if (win[k] == lb) { j++; matching = true; }
-            else {
-                if (matching && j > length) { length = j; offset = (p + k - j) & 255; }
-                j = 0; matching = false;
+        if (!last) {
+            // FindMatch (gpu_compress.cu:104-168) restated without its flag and its branch: a run of
+            // equal bytes starting at window byte `st` has length j; the reference records a run when it
+            // ends, keeps the first longest (strict >) and restarts at la[0] on the byte AFTER the
+            // mismatch.  Recording (j, st) at every step through max((j << 16) | ~st) is the same thing:
+            // a run's last record dominates its earlier ones, longer beats shorter, earlier start beats
+            // later on ties.  The 127 window bytes text[p-128 .. p-2] sit in 32 register dwords (aligned
+            // LDS dword reads funnelled by p & 3), so a step is one LDS byte read + ~6 VALU.
+            uint32_t W[32];
+            {
+                const uint32_t *wa = reinterpret_cast<const uint32_t *>(s_buf + (p & ~3));
+                const uint32_t sh = (uint32_t)(p & 3);
+                uint32_t prev = wa[0];
+#pragma unroll
+                for (int q = 0; q < 32; q++) {
+                    const uint32_t nxt = wa[q + 1];
+                    W[q] = __builtin_amdgcn_alignbyte(nxt, prev, sh);
+                    prev = nxt;
+                }
             }
+            // state = (j << 16) | (0xFFFF - st): +0x10000 on a match, a per-step constant on a mismatch
+            uint32_t state = 0xFFFFu, best = 0, addr = (uint32_t)p;
+#pragma unroll
+            for (int k = 0; k < 127; k++) {
+                const uint32_t wb = (W[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const bool eq = wb == (uint32_t)s_buf[LZ_WIN + addr];
+                addr = eq ? addr + 1 : (uint32_t)p;
+                state = eq ? state + 0x10000u : (0xFFFFu - (uint32_t)(k + 1));
+                best = best > state ? best : state;
+            }
+            if ((best >> 16) >= 2) { length = (int)(best >> 16); offset = (p + (int)(0xFFFFu - (best & 0xFFFFu))) & 255; }
+        } else {
+            // last 128-byte chunk: shortened scan, look-ahead wrapping into the stale ring half
+            const int iters = max(1, 127 - tx);
+            const int la_wrap = 128 - tx;                     // look-ahead index where the stale half begins
+            int j = 0;
+            bool matching = false;
+            const uint8_t *win = s_buf + p;                   // text[p-128 + k]
+            for (int k = 0; k < iters; k++) {
+                const uint8_t lb = (j < la_wrap) ? la[j] : la[j - 256];
+                if (win[k] == lb) { j++; matching = true; }
+                else {
+                    if (matching && j > length) { length = j; offset = (p + k - j) & 255; }
+                    j = 0; matching = false;
+                }
+            }
+            if (j > length && matching) { length = j; offset = (p + iters - j) & 255; }
         }
-        if (j > length && matching) { length = j; offset = (p + iters - j) & 255; }
         if (last && length > 128 - tx) length = 128 - tx;
         if (length >= LZ_MAXC) length = LZ_MAXC - 1;
         uint8_t c0, c1;
@@ -85,14 +120,50 @@ __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ c
         reinterpret_cast<uint4 *>(s_c)[tid + 256] = c4[tid + 256];
     }
     __syncthreads();
-    if (tid == 0) {                                           // greedy walk (gpu_compress.cu:498-515)
-        uint32_t t = 0, p = 0;
-        while (p < LZ_PCKT) {
-            s_tok[t++] = (uint16_t)p;
+    // The greedy walk p -> p + len(p) from 0 (gpu_compress.cu:498-515) without a serial chain:
+    // positions reachable in fewer than 2^r steps are marked round by round while the jump table is
+    // squared (J <- J o J), 12 rounds for 4096 positions; the marked positions, compacted in order,
+    // are the tokens.  (One lane walking ~1500 dependent LDS reads held the other 255 idle.)
+    {
+        __shared__ uint16_t s_j1[LZ_PCKT];
+        __shared__ uint32_t mark[LZ_PCKT / 32];
+        uint16_t *J0 = s_tok, *J1 = s_j1;                     // s_tok is free until the tokens are compacted
+#pragma unroll
+        for (int r = 0; r < LZ_PCKT / 256; r++) {
+            const uint32_t p = r * 256 + tid;
             const uint32_t c0 = s_c[2 * p];
-            p += (c0 <= 1) ? 1u : c0;
+            const uint32_t nx = p + ((c0 <= 1) ? 1u : c0);
+            J0[p] = (uint16_t)(nx < LZ_PCKT ? nx : LZ_PCKT);
         }
-        s_ntok = t;
+        if (tid < LZ_PCKT / 32) mark[tid] = (tid == 0) ? 1u : 0u;
+        __syncthreads();
+        uint16_t *J = J0, *Jn = J1;
+        for (int round = 0; round < 12; round++) {
+            uint32_t jn[LZ_PCKT / 256];
+#pragma unroll
+            for (int r = 0; r < LZ_PCKT / 256; r++) {
+                const uint32_t p = r * 256 + tid;
+                const uint32_t a = J[p];
+                if (((mark[p >> 5] >> (p & 31)) & 1u) && a < LZ_PCKT) atomicOr(&mark[a >> 5], 1u << (a & 31));
+                jn[r] = a < LZ_PCKT ? (uint32_t)J[a] : (uint32_t)LZ_PCKT;
+            }
+#pragma unroll
+            for (int r = 0; r < LZ_PCKT / 256; r++) Jn[r * 256 + tid] = (uint16_t)jn[r];
+            __syncthreads();
+            uint16_t *x = J; J = Jn; Jn = x;
+        }
+        // compact: thread t owns positions [16t, 16t+16)
+        const uint32_t mw = (mark[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
+        uint32_t tot = 0;
+        const uint32_t pre = block_excl_add<256>((uint32_t)__popc(mw), s_tmp, &tot);
+        __syncthreads();                                      // everyone has read J / marks: s_tok is reused
+        uint32_t o = pre, m2 = mw;
+        while (m2) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(m2);
+            m2 &= m2 - 1;
+            s_tok[o++] = (uint16_t)(tid * 16 + bit);
+        }
+        if (tid == 0) s_ntok = tot;
     }
     __syncthreads();
     const uint32_t T = s_ntok;
@@ -234,43 +305,121 @@ __global__ __launch_bounds__(64) void k_lzss_decode(const uint8_t *__restrict__ 
     // trailer: npk big-endian u16 sizes, u32 length, u16 pad (gpu_decompress.cu:257-294)
     const uint8_t *tr = P + clen - 6 - 2 * npk;
     uint32_t start = 0;
-    for (uint32_t i = l; i < pk; i += 64) start += ((uint32_t)tr[2 * i] << 8) | tr[2 * i + 1];
+    {   // prefix of the packet sizes: all byte loads in flight together
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t i = r * 64 + l;
+            hi[r] = tr[2 * (i < pk ? i : 0u)]; lo[r] = tr[2 * (i < pk ? i : 0u) + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (r * 64 + l < pk) start += (hi[r] << 8) | lo[r];
+        for (uint32_t i = 256 + l; i < pk; i += 64) start += ((uint32_t)tr[2 * i] << 8) | tr[2 * i + 1];
+    }
     start = wave_sum(start);
     uint32_t size = ((uint32_t)tr[2 * pk] << 8) | tr[2 * pk + 1];
     if (size > LZ_STAGE) size = LZ_STAGE;
-    for (uint32_t i = l; i < size; i += 64) s_in[i] = P[start + i];
+    // the packet's bytes: 16-byte loads from the aligned address below `start`, all in flight, then LDS;
+    // s_in[sh + i] = stream byte i (a byte-per-trip copy loop costs one memory latency per 64 bytes)
+    const uint8_t *src = P + start;
+    uint32_t sh = (uint32_t)(reinterpret_cast<size_t>(src) & 15);
+    if (src - sh < packed) {                                  // caller's buffer is not 16-byte aligned: byte copy
+        sh = 0;
+        for (uint32_t i = l; i < size; i += 64) s_in[i] = src[i];
+    } else {
+        const uint4 *a16 = reinterpret_cast<const uint4 *>(src - sh);
+        const uint32_t n16 = (sh + size + 15) / 16;           // <= (15 + 4608 + 15) / 16 = 289
+        uint4 q[5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) { const uint32_t i = r * 64 + l; q[r] = a16[i < n16 ? i : 0u]; }
+#pragma unroll
+        for (int r = 0; r < 5; r++) { const uint32_t i = r * 64 + l; if (i < n16) reinterpret_cast<uint4 *>(s_in)[i] = q[r]; }
+    }
     for (uint32_t i = l; i < LZ_WIN / 4; i += 64) reinterpret_cast<uint32_t *>(s_o)[i] = 0x20202020u;
-    __builtin_amdgcn_wave_barrier();
     __syncthreads();
-    uint32_t fp = 0, wp = 0, flags = 0, used = 8;
-    for (;;) {
-        if (used == 8) {
-            if (fp >= size) break;
-            flags = __builtin_amdgcn_readfirstlane((uint32_t)s_in[fp]); fp++; used = 0;
+    // token parse, one flag group per trip: the group's flag byte and its <= 16 token bytes are read
+    // with ONE LDS access (a byte per lane) and then picked out of the register with v_readlane, so
+    // the only LDS round trip a token still waits for is the source read of a match copy
+    uint32_t fp = 0, wp = 0;
+    const uint8_t *sb = s_in + sh;
+    bool done = false;
+    while (!done) {
+        if (fp >= size) break;
+        const uint32_t v = (fp + l < size + 0u) ? (uint32_t)sb[fp + l] : 0u;
+        uint32_t flags = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+        if (fp + 17 <= size) {
+            // whole group present: lane t < 8 owns token t.  Stream position and output position of
+            // every token come from the flag byte and an 8-lane scan of the token lengths; all
+            // literals of the group go out in ONE store, only the matches are walked in order
+            // (a match reads output produced before it -- earlier literals are already in place,
+            // later ones do not overlap its source or destination).
+            const uint32_t below = flags & ((1u << (l & 7)) - 1u);
+            const uint32_t pos_t = 1u + 2u * (l & 7) - (uint32_t)__popc(below);
+            const bool lit_t = (flags >> (l & 7)) & 1u;
+            const uint32_t b0v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos_t << 2), (int)v);
+            const uint32_t len_t = (l < 8) ? (lit_t ? 1u : b0v) : 0u;
+            uint32_t inc = len_t;                                           // inclusive scan over lanes 0..7
+            inc += GLC_DPP(inc, 0x111, 0xf);
+            inc += GLC_DPP(inc, 0x112, 0xf);
+            inc += GLC_DPP(inc, 0x114, 0xf);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 7);
+            if (wp + total <= LZ_PCKT) {
+                const uint32_t wp_t = wp + inc - len_t;
+                if (l < 8 && lit_t) s_o[LZ_WIN + wp_t] = (uint8_t)b0v;
+                uint32_t mm = ~flags & 0xFFu;
+                while (mm) {
+                    const uint32_t t = (uint32_t)__builtin_ctz(mm);
+                    mm &= mm - 1;
+                    const uint32_t pt = (uint32_t)__builtin_amdgcn_readlane((int)pos_t, t);
+                    const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)v, pt);
+                    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)v, pt + 1);
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wp_t, t);
+                    uint32_t d = (w0 - off) & 127u;
+                    if (d == 0) d = 128;
+                    const uint32_t q = LZ_WIN + w0 - d;
+                    uint8_t c0 = 0, c1 = 0;
+                    const uint32_t i0 = l, i1 = l + 64;
+                    if (i0 < len) c0 = s_o[(i0 < d) ? q + i0 : q + i0 - 128];
+                    if (i1 < len) c1 = s_o[(i1 < d) ? q + i1 : q + i1 - 128];
+                    __builtin_amdgcn_wave_barrier();
+                    if (i0 < len) s_o[LZ_WIN + w0 + i0] = c0;
+                    if (i1 < len) s_o[LZ_WIN + w0 + i1] = c1;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                wp += total;
+                fp += 1u + 16u - (uint32_t)__popc(flags & 0xFFu);
+                continue;
+            }
         }
-        if (fp >= size || wp >= LZ_PCKT) break;
-        if (flags & 1) {
-            if (l == 0) s_o[LZ_WIN + wp] = s_in[fp];
-            fp++; wp++;
-        } else {
-            if (fp + 1 >= size) break;
-            const uint32_t len = __builtin_amdgcn_readfirstlane((uint32_t)s_in[fp]);
-            const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)s_in[fp + 1]);
-            fp += 2;
-            uint32_t d = (wp - off) & 127u;                    // distance back to the ring slot `off`
-            if (d == 0) d = 128;
-            const uint32_t q = LZ_WIN + wp - d;                // s_o index of the first source byte
-            uint8_t b0 = 0, b1 = 0;
-            const uint32_t i0 = l, i1 = l + 64;
-            if (i0 < len) b0 = s_o[(i0 < d) ? q + i0 : q + i0 - 128];
-            if (i1 < len) b1 = s_o[(i1 < d) ? q + i1 : q + i1 - 128];
+        uint32_t pos = 1;
+#pragma unroll 1
+        for (int t = 0; t < 8; t++) {
+            if (fp + pos >= size || wp >= LZ_PCKT) { done = true; break; }
+            if (flags & 1) {
+                const uint32_t byte = (uint32_t)__builtin_amdgcn_readlane((int)v, pos);
+                if (l == 0) s_o[LZ_WIN + wp] = (uint8_t)byte;
+                pos++; wp++;
+            } else {
+                if (fp + pos + 1 >= size) { done = true; break; }
+                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)v, pos);
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)v, pos + 1);
+                pos += 2;
+                uint32_t d = (wp - off) & 127u;                // distance back to the ring slot `off`
+                if (d == 0) d = 128;
+                const uint32_t q = LZ_WIN + wp - d;            // s_o index of the first source byte
+                uint8_t b0 = 0, b1 = 0;
+                const uint32_t i0 = l, i1 = l + 64;
+                if (i0 < len) b0 = s_o[(i0 < d) ? q + i0 : q + i0 - 128];
+                if (i1 < len) b1 = s_o[(i1 < d) ? q + i1 : q + i1 - 128];
+                __builtin_amdgcn_wave_barrier();
+                if (i0 < len && wp + i0 < LZ_PCKT) s_o[LZ_WIN + wp + i0] = b0;
+                if (i1 < len && wp + i1 < LZ_PCKT) s_o[LZ_WIN + wp + i1] = b1;
+                wp += len;
+            }
+            flags >>= 1;
             __builtin_amdgcn_wave_barrier();
-            if (i0 < len && wp + i0 < LZ_PCKT) s_o[LZ_WIN + wp + i0] = b0;
-            if (i1 < len && wp + i1 < LZ_PCKT) s_o[LZ_WIN + wp + i1] = b1;
-            wp += len;
         }
-        flags >>= 1; used++;
-        __builtin_amdgcn_wave_barrier();
+        fp += pos;
     }
     __syncthreads();
     for (uint32_t i = l; i < LZ_PCKT / 16; i += 64)
