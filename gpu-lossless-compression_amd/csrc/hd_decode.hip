@@ -91,6 +91,48 @@ __device__ __forceinline__ uint32_t hd_decode_span(const uint32_t *U, const uint
     return (cnt << 4) | (pos - HD_SPAN_BITS);
 }
 
+// Path from offset 0, recording for every unit the first codeword boundary inside it (every 32-bit
+// unit holds at least two boundaries: codewords are <= 11 bits): chk[u] = symbols before it << 5 | bit.
+__device__ __forceinline__ uint32_t hd_decode_ref(const uint32_t *U, const uint16_t *s_lut, uint16_t *chk)
+{
+    uint32_t pos = 0, cnt = 0, last_u = 0xFFFFFFFFu;
+    uint64_t w = ((uint64_t)U[0] << 32) | U[1];
+    uint32_t valid = 64, next = 2;
+    while (pos < HD_SPAN_BITS) {
+        const uint32_t u = pos >> 5;
+        if (u != last_u) { chk[u] = (uint16_t)((cnt << 5) | (pos & 31)); last_u = u; }
+        const uint32_t len = s_lut[(uint32_t)(w >> (64 - GLC_HD_MAX_LEN))] >> 8;
+        w <<= len; pos += len; valid -= len; cnt++;
+        if (valid <= 32 && next <= HD_SPAN) { w |= (uint64_t)U[next] << (32 - valid); valid += 32; next++; }
+    }
+    return (cnt << 4) | (pos - HD_SPAN_BITS);
+}
+
+// Path from offset o > 0: Huffman codes self-synchronise, so it usually falls onto the reference
+// path within a few codewords; from there on the two are identical, and the result is the
+// reference's (end offset, count) corrected by the symbols decoded so far.  Checked once per unit.
+__device__ __forceinline__ uint32_t hd_decode_merge(const uint32_t *U, const uint16_t *s_lut, const uint16_t *chk,
+                                                    uint32_t ref, uint32_t o)
+{
+    uint32_t pos = o, cnt = 0, last_u = 0;                     // unit 0 holds the start itself: no check there
+    uint64_t w = (((uint64_t)U[0] << 32) | U[1]) << o;
+    uint32_t valid = 64 - o, next = 2;
+    while (pos < HD_SPAN_BITS) {
+        const uint32_t u = pos >> 5;
+        if (u != last_u) {
+            const uint32_t c = chk[u];
+            if ((c & 31u) == (pos & 31u)) return (((ref >> 4) - (c >> 5) + cnt) << 4) | (ref & 15u);
+            last_u = u;
+        }
+        const uint32_t len = s_lut[(uint32_t)(w >> (64 - GLC_HD_MAX_LEN))] >> 8;
+        w <<= len; pos += len; valid -= len; cnt++;
+        if (valid <= 32 && next <= HD_SPAN) { w |= (uint64_t)U[next] << (32 - valid); valid += 32; next++; }
+    }
+    return (cnt << 4) | (pos - HD_SPAN_BITS);
+}
+
+constexpr int HD_CHK_PITCH = 34;                                // u16 per lane (17 words: odd, conflict-free)
+
 __global__ __launch_bounds__(HD_LANES) void k_hd_span_functions(const uint32_t *__restrict__ units, size_t nunits,
                                                                 const uint16_t *__restrict__ lut,
                                                                 uint32_t *__restrict__ pexcl,
@@ -99,12 +141,16 @@ __global__ __launch_bounds__(HD_LANES) void k_hd_span_functions(const uint32_t *
     __shared__ uint32_t s_u[HD_LANES * HD_PITCH];
     __shared__ uint16_t s_lut[2048];
     __shared__ uint32_t s_tab[2][HD_LANES][HD_NOFF];
+    __shared__ uint16_t s_chk[HD_LANES * HD_CHK_PITCH];
     const uint32_t tid = threadIdx.x;
     const size_t wg = blockIdx.x;
     hd_stage(units, nunits, wg * (size_t)HD_WG_UNITS, s_u, lut, s_lut);
     const uint32_t *U = s_u + tid * HD_PITCH;
+    uint16_t *chk = s_chk + tid * HD_CHK_PITCH;
+    const uint32_t ref = hd_decode_ref(U, s_lut, chk);
+    s_tab[0][tid][0] = ref;
 #pragma unroll 1
-    for (uint32_t o = 0; o < HD_NOFF; o++) s_tab[0][tid][o] = hd_decode_span<false>(U, s_lut, o, nullptr, 0, 0);
+    for (uint32_t o = 1; o < HD_NOFF; o++) s_tab[0][tid][o] = hd_decode_merge(U, s_lut, chk, ref, o);
     // inclusive scan of the span functions across the 256 lanes (Hillis-Steele, composition B(A(.)))
     int src = 0;
     for (uint32_t d = 1; d < HD_LANES; d <<= 1) {
@@ -178,7 +224,33 @@ __global__ __launch_bounds__(HD_LANES) void k_hd_emit(const uint32_t *__restrict
     const uint32_t p = pexcl[(wg * HD_LANES + tid) * HD_TSTRIDE + ow];
     const size_t base = (size_t)start_base[wg] + (p >> 4);
     if (base >= nsym) return;
-    (void)hd_decode_span<true>(s_u + tid * HD_PITCH, s_lut, p & 15, out, base, nsym);
+    // decode and write: four symbols per dword store once the output index is 4-aligned (the bytes
+    // before that belong to the previous lane's dword and go out one by one, as does the tail)
+    const uint32_t *U = s_u + tid * HD_PITCH;
+    const uint32_t o = p & 15;
+    uint32_t pos = o;
+    uint64_t w = (((uint64_t)U[0] << 32) | U[1]) << o;
+    uint32_t valid = 64 - o, next = 2, acc = 0;
+    size_t idx = base;
+    const bool al = (reinterpret_cast<size_t>(out) & 3) == 0;
+    while (pos < HD_SPAN_BITS && idx < nsym) {
+        const uint32_t e = s_lut[(uint32_t)(w >> (64 - GLC_HD_MAX_LEN))];
+        const uint32_t len = e >> 8, k = (uint32_t)idx & 3u;
+        acc |= (e & 0xFFu) << (8 * k);
+        if (k == 3) {
+            if (al && idx - base >= 3) *reinterpret_cast<uint32_t *>(out + idx - 3) = acc;
+            else for (uint32_t q = (idx - base >= 3) ? 0u : 3u - (uint32_t)(idx - base); q < 4; q++) out[idx - 3 + q] = (uint8_t)(acc >> (8 * q));
+            acc = 0;
+        }
+        idx++;
+        w <<= len; pos += len; valid -= len;
+        if (valid <= 32 && next <= HD_SPAN) { w |= (uint64_t)U[next] << (32 - valid); valid += 32; next++; }
+    }
+    {   // tail: the bytes of an unfinished dword
+        const uint32_t k = (uint32_t)idx & 3u;                 // bytes [idx - k, idx) pending, but not before `base`
+        const uint32_t have = (uint32_t)((idx - base) < k ? (idx - base) : k);
+        for (uint32_t q = k - have; q < k; q++) out[idx - k + q] = (uint8_t)(acc >> (8 * q));
+    }
 }
 
 // ---------------------------------------------------------------------------
