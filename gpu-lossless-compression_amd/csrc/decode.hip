@@ -25,6 +25,7 @@
 //             ranking, no data movement); the LF cycle is cut at every row that is a multiple
 //             of 128, each piece is walked ONCE emitting into a bounded slot, pieces are
 //             ordered by list ranking in LDS and copied to their text positions.
+#include <stdlib.h>
 #include "glc_device.h"
 #include "glc_internal.h"
 #include "huff_tree.cuh"
@@ -493,6 +494,11 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ 
     }
 }
 
+// (Measured and rejected: a persistent form -- 64 K to 512 K lanes pulling (block, splitter) tickets
+//  in block-major order so that only a few blocks' LF tables are live -- runs at the same 52-55 G
+//  steps/s whatever the lane count, with or without the slot stores.  With 8 K splitters per block a
+//  small window of blocks does not hold enough walkers to cover the ~1.2 us per dependent access;
+//  the next step is 16-row splitters (64 K walkers per block) with a two-level segment ordering.)
 __global__ void k_ibwt_seg_init(uint32_t *__restrict__ seg_count, uint32_t n, uint32_t nblk)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
