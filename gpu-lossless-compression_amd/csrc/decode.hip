@@ -494,11 +494,13 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ 
     }
 }
 
-// (Measured and rejected: a persistent form -- 64 K to 512 K lanes pulling (block, splitter) tickets
-//  in block-major order so that only a few blocks' LF tables are live -- runs at the same 52-55 G
-//  steps/s whatever the lane count, with or without the slot stores.  With 8 K splitters per block a
-//  small window of blocks does not hold enough walkers to cover the ~1.2 us per dependent access;
-//  the next step is 16-row splitters (64 K walkers per block) with a two-level segment ordering.)
+// (Measured and rejected, three times: persistent forms -- 32 K to 512 K lanes taking (block, splitter)
+//  pieces in block-major order so that only a few blocks' LF tables are live.  A bare chase over such
+//  a window reaches 125 G steps/s with 64 K lanes (tools/probes/window_probe.hip), but with the real
+//  step (symbol packing, slot stores, piece bookkeeping) and one wave per SIMD the issue time of the
+//  step is no longer hidden: wave-pooled tickets 5.2-5.6 ms, strided static pieces 6.3-6.9 ms
+//  (imbalance), against 5.2 ms for the plain launch below.  The way forward is more pieces per block
+//  (16-row splitters, two-level ordering) so that a small window still fills the machine.)
 __global__ void k_ibwt_seg_init(uint32_t *__restrict__ seg_count, uint32_t n, uint32_t nblk)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -54,6 +54,11 @@ int main()
         for (auto &x : h) x = x * 2246822519u + 374761393u;   // vary per 64 MiB slab
         if (o > ((size_t)1 << 28)) { /* reuse same slab content for speed */ }
     }
+    // lanes in flight vs throughput at cache-resident working sets (what a windowed LF walk would see)
+    for (size_t mib : {16, 32, 64}) {
+        const uint32_t mask = (uint32_t)(mib * 262144 - 1);
+        for (int wgs : {256, 512, 1024, 2048}) run<1>(d, mask, sink, wgs, "lanes  ", mib);
+    }
     for (size_t mib : {4, 16, 32, 64, 128, 256, 1024, 4096}) {
         const uint32_t mask = (uint32_t)(mib * 262144 - 1);
         run<1>(d, mask, sink, 2048, "occ100%", mib);
