@@ -63,3 +63,33 @@ def test_batch_round_trip(glc, cuda):
         back = glc.decompress_batch(plan, comp, n, nb)
         plan.synchronize()
         assert torch.equal(back, d_in)
+
+
+@pytest.mark.parametrize("plan_n,n,nb", [(45537, 45537, 5), (70001, 4099, 3), (1 << 16, 65535, 4), (8191, 1, 7)])
+def test_batch_round_trip_misaligned_rows(glc, cuda, plan_n, n, nb):
+    """rows of odd length: every row but the first starts at an unaligned address inside the plan's
+    scratch (vector paths must fall back), and n may be smaller than the plan's block size"""
+    import torch
+    rng = np.random.default_rng(plan_n + n)
+    blocks = []
+    for i in range(nb):
+        kind = i % 3
+        if kind == 0:
+            blocks.append(datagen.zipf_bytes(n, seed=100 + i))
+        elif kind == 1:
+            blocks.append(rng.integers(0, 4, n, dtype=np.uint8))
+        else:
+            blocks.append(np.frombuffer((b"the quick brown fox " * (n // 20 + 1))[:n], dtype=np.uint8))
+    x = np.concatenate(blocks)
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, plan_n, rows=nb) as plan:
+        d_in = torch.from_numpy(x.copy()).cuda()
+        comp = glc.compress_batch(plan, d_in, n, nb)
+        back = glc.decompress_batch(plan, comp, n, nb)
+        plan.synchronize()
+        assert torch.equal(back, d_in)
+        sizes = comp["size"].cpu().numpy()
+        for b in range(nb):                                    # and every block equals the oracle's stream
+            want = O.compress(blocks[b])
+            got = comp["words"][b * comp["stride"]: b * comp["stride"] + int(sizes[b])].cpu().numpy().view(np.uint32)
+            assert int(comp["bwt_index"][b].item()) == want["bwt_index"] and int(sizes[b]) == want["size"]
+            assert np.array_equal(got, want["words"])
