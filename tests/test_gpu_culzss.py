@@ -219,3 +219,25 @@ def test_container_many_buffers(glc, cuda):
         want = O.lzss_pack(O.lzss_candidates(blk), MiB)
         got = out[8 + 4 * 41 + cum[i]: 8 + 4 * 41 + cum[i + 1]]
         assert np.array_equal(got, want), "buffer %d" % i
+
+
+@pytest.mark.parametrize("shift", [1, 5, 13])
+def test_decode_from_unaligned_device_pointers(glc, cuda, shift):
+    """the decoder's 16-byte staging loads must not assume the caller's buffers are aligned"""
+    import torch
+    L = glc.lib()
+    n, nb = 4 * 4096, 3
+    bufs = [datagen.log_bytes(n, seed=70 + i) for i in range(nb)]
+    d_in = torch.from_numpy(np.concatenate(bufs)).to(cuda)
+    stride = L.glcLzssPackStride(n)
+    d_packed = torch.zeros(stride * nb, dtype=torch.uint8, device=cuda)
+    d_size = torch.zeros(nb, dtype=torch.int32, device=cuda)
+    d_work = torch.zeros(L.glcLzssWorkBytes(n, nb), dtype=torch.uint8, device=cuda)
+    assert L.glcLzssEncodeDevice(d_in.data_ptr(), n, nb, None, d_packed.data_ptr(), d_size.data_ptr(),
+                                 d_work.data_ptr(), None) == 1
+    moved = torch.zeros(stride * nb + 64, dtype=torch.uint8, device=cuda)
+    moved[shift:shift + stride * nb] = d_packed
+    d_out = torch.zeros(n * nb + 64, dtype=torch.uint8, device=cuda)
+    assert L.glcLzssDecodeDevice(moved.data_ptr() + shift, d_size.data_ptr(), n, nb, d_out.data_ptr() + shift, None) == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy()[shift:shift + n * nb], np.concatenate(bufs))
