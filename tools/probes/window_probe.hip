@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_walk(const uint32_t *__restrict__ a, ui
         if (t >= total) break;
         const uint32_t b = t / per_table, s = t - b * per_table;
         const uint32_t *T = a + ((size_t)b << 20);
-        uint32_t r = (s * 128u) & 0xFFFFFu;
+        uint32_t r = (s * (0x100000u / per_table)) & 0xFFFFFu;
         for (uint32_t i = 0; i < steps; i++) r = T[r];
         acc ^= r;
     }
@@ -41,17 +41,19 @@ int main()
     uint32_t *d, *ctr, *sink;
     hipMalloc(&d, (size_t)NB << 22); hipMalloc(&ctr, 4); hipMalloc(&sink, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int pass = 0; pass < 2; pass++)
-    for (uint32_t nb : {8u, 32u, 256u}) {
-        for (int wgs : {256, 512, 2048}) {
+    // pieces per table x steps per piece = 2^20: (8192 x 128) is the shipped splitter spacing, (65536 x 16)
+    // the 16-row spacing that keeps only ~8 tables live at full occupancy
+    for (uint32_t per_table : {8192u, 65536u})
+    for (uint32_t nb : {256u}) {
+        for (int wgs : {256, 512, 1024, 2048, 4096}) {
             hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d, (size_t)NB << 20);   // cold: just written
             hipMemset(ctr, 0, 4);
-            const uint32_t per_table = 8192, steps = 128;
+            const uint32_t steps = (1u << 20) / per_table;
             hipEventRecord(e0);
             hipLaunchKernelGGL(k_walk, dim3(wgs), dim3(256), 0, 0, d, nb, per_table, steps, ctr, sink);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            printf("tables=%3u (%4u MiB) wgs=%4d : %.3f ms  %.1f G steps/s\n", nb, nb * 4, wgs, ms,
+            printf("pieces/table=%5u tables=%3u (%4u MiB) wgs=%4d : %.3f ms  %.1f G steps/s\n", per_table, nb, nb * 4, wgs, ms,
                    (double)nb * per_table * steps / ms / 1e6);
         }
     }
