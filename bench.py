@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--rows", type=int, default=256, help="blocks per batched call (plan rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the three encode stages of a batch back to back")
     ap.add_argument("--with-gather", action="store_true",
                     help="N>1: include the RCCL gather of the bitstreams to rank 0 in the timed region")
     args = ap.parse_args()
@@ -136,6 +137,8 @@ def main():
     plan = glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows)
     stream = torch.cuda.current_stream(dev)
     plan.set_stream(stream.cuda_stream)
+    if not args.no_pipeline:
+        plan.set_pipelining(True)          # sort of batch i+1 overlaps MTF + Huffman of batch i
 
     def encode_all():
         for b0 in range(0, nblocks, rows):

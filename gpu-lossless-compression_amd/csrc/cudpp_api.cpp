@@ -67,10 +67,32 @@ struct CompressPlan : PlanBase {                 // CUDPPCompressPlan (cudpp_pla
     HuffScratch huff;
     DecodeScratch dec;
     uint8_t *d_bwt = nullptr, *d_mtf = nullptr;  // [rows][n]
+    // stage pipelining (glcPlanSetPipelining): the suffix sort of batch i+1 runs on `side` while the
+    // MTF + Huffman stages of batch i run on the plan's stream; d_bwt is double-buffered between them
+    bool pipelined = false;
+    uint8_t *d_bwt2 = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_released[2] = {nullptr, nullptr}, ev_s2 = nullptr;
+    bool released_valid[2] = {false, false};
+    uint32_t calls = 0;
+    hipError_t pipeline_init()
+    {
+        if (side) return hipSuccess;
+        hipError_t e = hipMalloc((void **)&d_bwt2, (size_t)n * rows);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        hipEvent_t *evs[] = {&ev_in, &ev_sorted[0], &ev_sorted[1], &ev_released[0], &ev_released[1]};
+        for (auto pe : evs) if (e == hipSuccess) e = hipEventCreateWithFlags(pe, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreate(&ev_s2);
+        return e;
+    }
     ~CompressPlan() override
     {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        hipEvent_t evs[] = {ev_in, ev_sorted[0], ev_sorted[1], ev_released[0], ev_released[1], ev_s2};
+        for (auto e : evs) if (e) (void)hipEventDestroy(e);
         sa_scratch_free(sa); mtf_scratch_free(mtf); huff_scratch_free(huff); decode_scratch_free(dec);
         if (d_bwt) (void)hipFree(d_bwt);
+        if (d_bwt2) (void)hipFree(d_bwt2);
         if (d_mtf) (void)hipFree(d_mtf);
     }
 };
@@ -220,10 +242,31 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     if (offsetStride < nsub) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     hipStream_t st = p->stream;
     StageTimer tm(p);
-    tm.mark(0);
-    hipError_t e = sa_build(st, d_uncompressed, n, n, nb, p->sa, p->d_bwt, p->n, d_bwtIndex);
-    tm.mark(1);
-    if (e == hipSuccess) e = mtf_forward(st, p->d_bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
+    hipError_t e = hipSuccess;
+    uint8_t *bwt = p->d_bwt;
+    const uint32_t k = p->calls++ & 1u;
+    if (p->pipelined) {
+        // sort on the side stream: after the caller's earlier work on `st` (its input) and after the
+        // stage-2 work of two calls ago has released this half of the BWT buffer.  sa_build blocks the
+        // host once per round, so the input is fully consumed when this call returns, exactly as before.
+        e = p->pipeline_init();
+        if (e != hipSuccess) return hip_result(e);
+        bwt = k ? p->d_bwt2 : p->d_bwt;
+        (void)hipEventRecord(p->ev_in, st);
+        (void)hipStreamWaitEvent(p->side, p->ev_in, 0);
+        if (p->released_valid[k]) (void)hipStreamWaitEvent(p->side, p->ev_released[k], 0);
+        if (p->timing) (void)hipEventRecord(p->ev[0], p->side);
+        e = sa_build(p->side, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
+        if (p->timing) (void)hipEventRecord(p->ev[1], p->side);
+        (void)hipEventRecord(p->ev_sorted[k], p->side);
+        (void)hipStreamWaitEvent(st, p->ev_sorted[k], 0);        // everything below stays stream-ordered on `st`
+        if (p->timing) (void)hipEventRecord(p->ev_s2, st);
+    } else {
+        tm.mark(0);
+        e = sa_build(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
+        tm.mark(1);
+    }
+    if (e == hipSuccess) e = mtf_forward(st, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
     tm.mark(2);
     if (e == hipSuccess) e = huff_build(st, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
                                         compressedStrideWords, p->d_status);
@@ -231,7 +274,20 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
                                        d_compressed, compressedStrideWords);
     tm.mark(3);
     tm.done();
+    if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], st); p->released_valid[k] = true; }
     return hip_result(e);
+}
+
+CUDPPResult glcPlanSetPipelining(CUDPPHandle planHandle, int on)
+{
+    CompressPlan *p = plan_from<CompressPlan>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm != CUDPP_COMPRESS) return CUDPP_ERROR_INVALID_PLAN;
+    if (p->side) (void)hipStreamSynchronize(p->side);
+    (void)hipStreamSynchronize(p->stream);
+    p->pipelined = on != 0;
+    p->released_valid[0] = p->released_valid[1] = false;
+    return CUDPP_SUCCESS;
 }
 
 CUDPPResult glcBwtBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsigned char *d_out, int *d_index,
@@ -344,9 +400,16 @@ CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle)
     if (e != hipSuccess) return CUDPP_ERROR_UNKNOWN;
     if (p->timing && p->ev_valid) {
         (void)hipEventElapsedTime(&p->last_ms[0], p->ev[0], p->ev[1]);
-        (void)hipEventElapsedTime(&p->last_ms[1], p->ev[1], p->ev[2]);
-        (void)hipEventElapsedTime(&p->last_ms[2], p->ev[2], p->ev[3]);
-        (void)hipEventElapsedTime(&p->last_ms[3], p->ev[0], p->ev[3]);
+        CompressPlan *cp = p->config.algorithm == CUDPP_COMPRESS ? static_cast<CompressPlan *>(p) : nullptr;
+        if (cp && cp->pipelined && cp->ev_s2) {                 // stages ran on two streams: report their own spans
+            (void)hipEventElapsedTime(&p->last_ms[1], cp->ev_s2, p->ev[2]);
+            (void)hipEventElapsedTime(&p->last_ms[2], p->ev[2], p->ev[3]);
+            p->last_ms[3] = p->last_ms[0] + p->last_ms[1] + p->last_ms[2];
+        } else {
+            (void)hipEventElapsedTime(&p->last_ms[1], p->ev[1], p->ev[2]);
+            (void)hipEventElapsedTime(&p->last_ms[2], p->ev[2], p->ev[3]);
+            (void)hipEventElapsedTime(&p->last_ms[3], p->ev[0], p->ev[3]);
+        }
     }
     return *p->h_status ? CUDPP_ERROR_UNKNOWN : CUDPP_SUCCESS;
 }

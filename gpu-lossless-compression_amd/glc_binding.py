@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams",
+    "glcCompactStreams", "glcPlanSetPipelining",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
@@ -92,6 +92,7 @@ def lib():
     L.glcDecompressBatch.argtypes = [sz, vp, vp, vp, sz, vp, sz, vp, sz, sz]
     L.glcPlanSetStream.argtypes = [sz, vp]
     L.glcPlanSynchronize.argtypes = [sz]
+    L.glcPlanSetPipelining.argtypes = [sz, C.c_int]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
     L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
     L.glcPlanKernelProfile.argtypes = [sz, C.POINTER(C.c_double)]
@@ -216,6 +217,10 @@ class Plan:
 
     def synchronize(self):
         _chk("glcPlanSynchronize", lib().glcPlanSynchronize(self.handle))
+
+    def set_pipelining(self, on=True):
+        """overlap the suffix sort of a batch with the MTF + Huffman stages of the previous one"""
+        _chk("glcPlanSetPipelining", lib().glcPlanSetPipelining(self.handle, 1 if on else 0))
 
     def enable_timing(self, mode=1):
         """0 off, 1 stage events, 3 stage events + dominant-kernel events"""

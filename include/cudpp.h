@@ -184,6 +184,12 @@ CUDPPResult glcPlanSetStream(CUDPPHandle planHandle, void *hipStream);
  * per-4096-symbol capacity of the reference format. */
 CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle);
 
+/* Stage pipelining for batched encode (off by default).  When on, glcCompressBatch / cudppCompress run
+ * the suffix sort of a call on an internal stream so that it overlaps the MTF + Huffman stages of the
+ * previous call, which stay on the plan's stream.  Nothing changes for the caller: the input is fully
+ * consumed when the call returns (as before), and every output is ordered on the plan's stream. */
+CUDPPResult glcPlanSetPipelining(CUDPPHandle planHandle, int on);
+
 /* Per-stage device time of the plan's last batched compress, in milliseconds,
  * measured with hipEvents on the plan's stream: [0]=BWT(suffix sort+gather),
  * [1]=MTF, [2]=Huffman, [3]=total.  Enables timing when `enable` != 0. */

@@ -324,3 +324,37 @@ def test_error_codes(glc, ctx, cuda):
         assert L.cudppBurrowsWheelerTransform(mtf_plan.handle, d.data_ptr(), d.data_ptr(), o.data_ptr(), 4096) == glc.CUDPP_ERROR_INVALID_PLAN
         assert L.cudppMoveToFrontTransform(mtf_plan.handle, d.data_ptr(), d.data_ptr(), 8192) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
     assert L.cudppDestroyPlan(glc.CUDPP_INVALID_HANDLE) == glc.CUDPP_ERROR_INVALID_HANDLE
+
+
+def test_pipelined_calls_match_plain_calls(glc, ctx, cuda):
+    """glcPlanSetPipelining: six back-to-back batched calls (suffix sort of call i+1 overlapping the
+    MTF + Huffman stages of call i on a second stream) give the same streams as plain calls, with the
+    outputs read through ordinary stream-ordered copies on the plan's stream."""
+    import torch
+    n, nb, calls = 1 << 17, 4, 6
+    batches = [np.concatenate([datagen.zipf_bytes(n, seed=1000 + 10 * c + b) if (b + c) % 2 else
+                               datagen.text_bytes(n, seed=2000 + 10 * c + b) for b in range(nb)]) for c in range(calls)]
+    d_in = [torch.from_numpy(x).cuda() for x in batches]
+
+    def run(pipelined):
+        outs = []
+        with glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=nb) as plan:
+            if pipelined:
+                plan.set_pipelining(True)
+            res = [glc.compress_batch(plan, d_in[c], n, nb) for c in range(calls)]   # no sync in between
+            plan.synchronize()
+            for r in res:
+                sizes = r["size"].cpu().numpy()
+                outs.append((r["bwt_index"].cpu().numpy().copy(), sizes.copy(), r["hist"].cpu().numpy().copy(),
+                             [r["words"][b * r["stride"]: b * r["stride"] + int(sizes[b])].cpu().numpy().copy()
+                              for b in range(nb)]))
+        return outs
+
+    plain, piped = run(False), run(True)
+    for c in range(calls):
+        assert np.array_equal(plain[c][0], piped[c][0]) and np.array_equal(plain[c][1], piped[c][1])
+        assert np.array_equal(plain[c][2], piped[c][2])
+        for b in range(nb):
+            assert np.array_equal(plain[c][3][b], piped[c][3][b])
+    want = O.compress(batches[3][2 * n:3 * n])                  # and one block against the oracle
+    assert np.array_equal(piped[3][3][2].view(np.uint32), want["words"])
