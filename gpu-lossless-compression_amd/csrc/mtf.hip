@@ -45,10 +45,12 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_chunk_lists(const uint8_
     __builtin_amdgcn_wave_barrier();
     uint32_t len = 0;
     // order index o = hi-1-p : 0 is the most recent byte of the chunk
+    uint32_t sym_next = src[hi - 1 - (l < hi - lo ? l : 0u)];
     for (uint32_t o0 = 0; o0 < hi - lo && len < 256; o0 += 64) {
         const uint32_t o = o0 + l;
         const bool valid = o < hi - lo;
-        const uint32_t sym = valid ? src[hi - 1 - o] : 0u;
+        const uint32_t sym = valid ? sym_next : 0u;
+        sym_next = src[hi - 1 - (o + 64 < hi - lo ? o + 64 : 0u)];               // in flight during this batch
         if (valid) atomicMin(&first[sym], o);
         __builtin_amdgcn_wave_barrier();
         const bool isnew = valid && first[sym] == o;        // most recent occurrence of sym in the chunk
@@ -73,11 +75,17 @@ __global__ __launch_bounds__(64) void k_mtf_scan_lists(uint8_t *__restrict__ lis
     int cur = 0;
     for (int i = l; i < 256; i += 64) s_state[0][i] = (uint8_t)i;
     __builtin_amdgcn_wave_barrier();
+    uint32_t p4n = reinterpret_cast<const uint32_t *>(lists + (size_t)b * max_chunks * 256)[l];
+    uint32_t mn = lens[(size_t)b * max_chunks];
     for (uint32_t c = 0; c < nchunks; c++) {
         uint8_t *L = lists + ((size_t)b * max_chunks + c) * 256;
-        const uint32_t m = lens[(size_t)b * max_chunks + c];
+        const uint32_t m = mn;
         // P = chunk-local list (registers), then publish the current state as the start list
-        uint32_t p4 = reinterpret_cast<const uint32_t *>(L)[l];       // entries 4l..4l+3 of P
+        const uint32_t p4 = p4n;                                       // entries 4l..4l+3 of P
+        if (c + 1 < nchunks) {                                         // next chunk's list: in flight during this fold
+            p4n = reinterpret_cast<const uint32_t *>(L + 256)[l];
+            mn = lens[(size_t)b * max_chunks + c + 1];
+        }
         reinterpret_cast<uint32_t *>(L)[l] = reinterpret_cast<const uint32_t *>(s_state[cur])[l];
         if (c + 1 == nchunks) break;
         // membership table of P
