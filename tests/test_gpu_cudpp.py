@@ -358,3 +358,43 @@ def test_pipelined_calls_match_plain_calls(glc, ctx, cuda):
             assert np.array_equal(plain[c][3][b], piped[c][3][b])
     want = O.compress(batches[3][2 * n:3 * n])                  # and one block against the oracle
     assert np.array_equal(piped[3][3][2].view(np.uint32), want["words"])
+
+
+def test_randomised_parity_sweep(glc, ctx, cuda):
+    """60 seeded random inputs (sizes 1..70 000, alphabets 1..256, i.i.d. / runs / periodic / tandem
+    repeats) through ONE reused plan, every output array compared with the oracle."""
+    import torch
+    rng = np.random.default_rng(20260928)
+    with glc.Plan(ctx, glc.CUDPP_COMPRESS, 70000, rows=1) as plan:
+        for case in range(60):
+            n = int(rng.integers(1, 70001)) if case % 5 else int(rng.choice([1, 2, 3, 5, 64, 4095, 4096, 4097, 8192, 65536]))
+            a = int(rng.choice([1, 2, 3, 16, 255, 256]))
+            kind = case % 4
+            if kind == 0:
+                x = rng.integers(0, a, n, dtype=np.uint16).astype(np.uint8)
+            elif kind == 1:                                        # long runs
+                x = np.repeat(rng.integers(0, a, n // 7 + 1, dtype=np.uint16), rng.integers(1, 14, n // 7 + 1))[:n].astype(np.uint8)
+                x = np.resize(x, n)
+            elif kind == 2:                                        # periodic
+                per = int(rng.integers(1, 40))
+                x = np.resize(rng.integers(0, a, per, dtype=np.uint16).astype(np.uint8), n)
+            else:                                                  # tandem repeats with mutations
+                unit = rng.integers(0, a, int(rng.integers(2, 300)), dtype=np.uint16).astype(np.uint8)
+                x = np.resize(unit, n).copy()
+                flips = rng.integers(0, n, max(1, n // 500))
+                x[flips] = rng.integers(0, a, flips.size, dtype=np.uint16).astype(np.uint8)
+            want = O.compress(x)
+            d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            r = glc.compress_batch(plan, d_in, n, 1)
+            plan.synchronize()
+            size = int(r["size"].item())
+            tag = "case %d n=%d alphabet=%d kind=%d" % (case, n, a, kind)
+            assert int(r["bwt_index"].item()) == want["bwt_index"], tag
+            assert size == want["size"], tag
+            assert np.array_equal(r["hist"].cpu().numpy().view(np.uint32), want["hist"]), tag
+            assert np.array_equal(r["words"][:size].cpu().numpy().view(np.uint32), want["words"]), tag
+            nsub = (n + 4095) // 4096
+            assert np.array_equal(r["offsets"][:nsub].cpu().numpy().view(np.uint32), want["offsets"]), tag
+            back = glc.decompress_batch(plan, r, n, 1)
+            plan.synchronize()
+            assert np.array_equal(back.cpu().numpy(), x), tag + " round trip"

@@ -241,3 +241,46 @@ def test_decode_from_unaligned_device_pointers(glc, cuda, shift):
     assert L.glcLzssDecodeDevice(moved.data_ptr() + shift, d_size.data_ptr(), n, nb, d_out.data_ptr() + shift, None) == 1
     torch.cuda.synchronize()
     assert np.array_equal(d_out.cpu().numpy()[shift:shift + n * nb], np.concatenate(bufs))
+
+
+def test_randomised_parity_sweep(glc, cuda):
+    """30 seeded random buffers (1..8 packets; i.i.d. small alphabets, runs, periodic text with
+    mutations): candidates, packed bytes and decode against the lock-step oracle."""
+    import torch
+    L = glc.lib()
+    rng = np.random.default_rng(4096)
+    for case in range(30):
+        n = 4096 * int(rng.integers(1, 9))
+        a = int(rng.choice([2, 4, 26, 256]))
+        kind = case % 3
+        if kind == 0:
+            x = rng.integers(0, a, n, dtype=np.uint16).astype(np.uint8)
+        elif kind == 1:
+            x = np.resize(np.repeat(rng.integers(0, a, n // 5 + 1, dtype=np.uint16), rng.integers(1, 200, n // 5 + 1)), n).astype(np.uint8)
+        else:
+            x = np.resize(rng.integers(32, 32 + min(a, 90), int(rng.integers(3, 400)), dtype=np.uint16).astype(np.uint8), n).copy()
+            flips = rng.integers(0, n, n // 300 + 1)
+            x[flips] = rng.integers(32, 122, flips.size, dtype=np.uint16).astype(np.uint8)
+        x = np.ascontiguousarray(x)
+        tag = "case %d n=%d alphabet=%d kind=%d" % (case, n, a, kind)
+        d_in = torch.from_numpy(x).to(cuda)
+        stride = L.glcLzssPackStride(n)
+        d_cand = torch.zeros(2 * n, dtype=torch.uint8, device=cuda)
+        d_packed = torch.zeros(stride, dtype=torch.uint8, device=cuda)
+        d_size = torch.full((1,), -7, dtype=torch.int32, device=cuda)
+        d_work = torch.zeros(L.glcLzssWorkBytes(n, 1), dtype=torch.uint8, device=cuda)
+        assert L.glcLzssEncodeDevice(d_in.data_ptr(), n, 1, d_cand.data_ptr(), d_packed.data_ptr(),
+                                     d_size.data_ptr(), d_work.data_ptr(), None) == 1
+        torch.cuda.synchronize()
+        want_cand = O.lzss_candidates(x)
+        assert np.array_equal(d_cand.cpu().numpy(), want_cand), tag + " candidates"
+        want = O.lzss_pack(want_cand, n)
+        size = int(d_size.item())
+        if want is None:
+            assert size == 0, tag
+        else:
+            assert size == want.size and np.array_equal(d_packed.cpu().numpy()[:size], want), tag + " packed"
+        d_out = torch.zeros(n, dtype=torch.uint8, device=cuda)
+        assert L.glcLzssDecodeDevice(d_packed.data_ptr(), d_size.data_ptr(), n, 1, d_out.data_ptr(), None) == 1
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), x), tag + " round trip"
