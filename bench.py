@@ -285,7 +285,7 @@ def main():
         if gather_ms is not None:
             res["gather_to_rank0"] = {"ms": round(gather_ms, 2),
                                       "what": "all_gather of totals + padded gather of the compacted streams (RCCL), outside the timed region"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # host-side baseline: rank 0 at N=1 only
             res["cpu_baseline"] = cpu_baseline(sample_host)
         print(json.dumps(res))
     plan.close()
