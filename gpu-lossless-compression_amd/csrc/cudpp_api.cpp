@@ -75,12 +75,24 @@ struct CompressPlan : PlanBase {                 // CUDPPCompressPlan (cudpp_pla
     hipEvent_t ev_in = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_released[2] = {nullptr, nullptr}, ev_s2 = nullptr;
     bool released_valid[2] = {false, false};
     uint32_t calls = 0;
+    hipEvent_t ev_dec_a[2] = {nullptr, nullptr}, ev_dec_released[2] = {nullptr, nullptr};
+    bool dec_released_valid[2] = {false, false};
+    uint32_t dec_calls = 0;
+    bool side_busy = false;                      // side-stream work issued since the last join
+    void join_side()                             // make the plan's stream wait for everything on the side stream
+    {
+        if (!side || !side_busy) return;
+        (void)hipEventRecord(ev_in, side);
+        (void)hipStreamWaitEvent(stream, ev_in, 0);
+        side_busy = false;
+    }
     hipError_t pipeline_init()
     {
         if (side) return hipSuccess;
         hipError_t e = hipMalloc((void **)&d_bwt2, (size_t)n * rows);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-        hipEvent_t *evs[] = {&ev_in, &ev_sorted[0], &ev_sorted[1], &ev_released[0], &ev_released[1]};
+        hipEvent_t *evs[] = {&ev_in, &ev_sorted[0], &ev_sorted[1], &ev_released[0], &ev_released[1],
+                             &ev_dec_a[0], &ev_dec_a[1], &ev_dec_released[0], &ev_dec_released[1]};
         for (auto pe : evs) if (e == hipSuccess) e = hipEventCreateWithFlags(pe, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreate(&ev_s2);
         return e;
@@ -88,7 +100,8 @@ struct CompressPlan : PlanBase {                 // CUDPPCompressPlan (cudpp_pla
     ~CompressPlan() override
     {
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
-        hipEvent_t evs[] = {ev_in, ev_sorted[0], ev_sorted[1], ev_released[0], ev_released[1], ev_s2};
+        hipEvent_t evs[] = {ev_in, ev_sorted[0], ev_sorted[1], ev_released[0], ev_released[1], ev_s2,
+                            ev_dec_a[0], ev_dec_a[1], ev_dec_released[0], ev_dec_released[1]};
         for (auto e : evs) if (e) (void)hipEventDestroy(e);
         sa_scratch_free(sa); mtf_scratch_free(mtf); huff_scratch_free(huff); decode_scratch_free(dec);
         if (d_bwt) (void)hipFree(d_bwt);
@@ -245,36 +258,37 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     hipError_t e = hipSuccess;
     uint8_t *bwt = p->d_bwt;
     const uint32_t k = p->calls++ & 1u;
+    hipStream_t s2 = st;                                       // stream of the MTF + Huffman stages
     if (p->pipelined) {
-        // sort on the side stream: after the caller's earlier work on `st` (its input) and after the
-        // stage-2 work of two calls ago has released this half of the BWT buffer.  sa_build blocks the
-        // host once per round, so the input is fully consumed when this call returns, exactly as before.
+        // The sort stays on the plan's stream (inputs keep their stream order; sa_build blocks the host
+        // once per round, so the input is consumed when the call returns).  MTF + Huffman move to the
+        // side stream, where they overlap the sort of the NEXT call; the outputs they write are complete
+        // after glcPlanSynchronize / glcCompactStreams / a device synchronize (include/cudpp.h).
         e = p->pipeline_init();
         if (e != hipSuccess) return hip_result(e);
         bwt = k ? p->d_bwt2 : p->d_bwt;
-        (void)hipEventRecord(p->ev_in, st);
-        (void)hipStreamWaitEvent(p->side, p->ev_in, 0);
-        if (p->released_valid[k]) (void)hipStreamWaitEvent(p->side, p->ev_released[k], 0);
-        if (p->timing) (void)hipEventRecord(p->ev[0], p->side);
-        e = sa_build(p->side, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
-        if (p->timing) (void)hipEventRecord(p->ev[1], p->side);
-        (void)hipEventRecord(p->ev_sorted[k], p->side);
-        (void)hipStreamWaitEvent(st, p->ev_sorted[k], 0);        // everything below stays stream-ordered on `st`
-        if (p->timing) (void)hipEventRecord(p->ev_s2, st);
+        if (p->released_valid[k]) (void)hipStreamWaitEvent(st, p->ev_released[k], 0);   // this BWT half is free again
+        tm.mark(0);
+        e = sa_build(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
+        tm.mark(1);
+        (void)hipEventRecord(p->ev_sorted[k], st);
+        s2 = p->side;
+        (void)hipStreamWaitEvent(s2, p->ev_sorted[k], 0);
+        if (p->timing) (void)hipEventRecord(p->ev_s2, s2);
     } else {
         tm.mark(0);
         e = sa_build(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
         tm.mark(1);
     }
-    if (e == hipSuccess) e = mtf_forward(st, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
-    tm.mark(2);
-    if (e == hipSuccess) e = huff_build(st, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
+    if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
+    if (p->timing) (void)hipEventRecord(p->ev[2], s2);
+    if (e == hipSuccess) e = huff_build(s2, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
                                         compressedStrideWords, p->d_status);
-    if (e == hipSuccess) e = huff_pack(st, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
+    if (e == hipSuccess) e = huff_pack(s2, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
                                        d_compressed, compressedStrideWords);
-    tm.mark(3);
+    if (p->timing) (void)hipEventRecord(p->ev[3], s2);
     tm.done();
-    if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], st); p->released_valid[k] = true; }
+    if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], s2); p->released_valid[k] = true; p->side_busy = true; }
     return hip_result(e);
 }
 
@@ -283,10 +297,12 @@ CUDPPResult glcPlanSetPipelining(CUDPPHandle planHandle, int on)
     CompressPlan *p = plan_from<CompressPlan>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     if (p->config.algorithm != CUDPP_COMPRESS) return CUDPP_ERROR_INVALID_PLAN;
+    p->join_side();
     if (p->side) (void)hipStreamSynchronize(p->side);
     (void)hipStreamSynchronize(p->stream);
     p->pipelined = on != 0;
     p->released_valid[0] = p->released_valid[1] = false;
+    p->dec_released_valid[0] = p->dec_released_valid[1] = false;
     return CUDPP_SUCCESS;
 }
 
@@ -331,9 +347,28 @@ CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, co
         hipError_t e = decode_scratch_alloc(p->dec, p->n, p->rows);
         if (e != hipSuccess) return hip_result(e);
     }
-    return hip_result(decode_blocks(p->stream, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compressed,
-                                    compressedStrideWords, d_out, (uint32_t)numElements, (uint32_t)numBlocks,
-                                    p->dec, p->mtf, p->d_status));
+    if (!p->pipelined)
+        return hip_result(decode_blocks(p->stream, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compressed,
+                                        compressedStrideWords, d_out, (uint32_t)numElements, (uint32_t)numBlocks,
+                                        p->dec, p->mtf, p->d_status));
+    // pipelined: Huffman + inverse MTF on the plan's stream (inputs keep their stream order), the inverse
+    // BWT -- a memory-latency-bound walk -- on the side stream, where it overlaps stage A of the next call.
+    // d_out is complete after glcPlanSynchronize / a device synchronize.
+    hipError_t e = p->pipeline_init();
+    if (e != hipSuccess) return hip_result(e);
+    hipStream_t st = p->stream;
+    const uint32_t k = p->dec_calls++ & 1u;
+    uint8_t *bwt = k ? p->dec.bwt2 : p->dec.bwt;
+    if (p->dec_released_valid[k]) (void)hipStreamWaitEvent(st, p->ev_dec_released[k], 0);
+    e = decode_stage_a(st, d_hist, d_encodeOffset, offsetStride, d_compressed, compressedStrideWords,
+                       (uint32_t)numElements, (uint32_t)numBlocks, p->dec, bwt);
+    (void)hipEventRecord(p->ev_dec_a[k], st);
+    (void)hipStreamWaitEvent(p->side, p->ev_dec_a[k], 0);
+    if (e == hipSuccess) e = decode_stage_b(p->side, d_bwtIndex, bwt, d_out, (uint32_t)numElements, (uint32_t)numBlocks, p->dec);
+    (void)hipEventRecord(p->ev_dec_released[k], p->side);
+    p->dec_released_valid[k] = true;
+    p->side_busy = true;
+    return hip_result(e);
 }
 
 // --------------------------------------------------------------------------
@@ -394,6 +429,7 @@ CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm == CUDPP_COMPRESS) static_cast<CompressPlan *>(p)->join_side();
     hipError_t e = hipMemcpyAsync(p->h_status, p->d_status, 4, hipMemcpyDeviceToHost, p->stream);
     if (e == hipSuccess) e = hipMemsetAsync(p->d_status, 0, 4, p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
@@ -456,6 +492,7 @@ CUDPPResult glcCompactStreams(CUDPPHandle planHandle, const unsigned int *d_comp
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     if (!d_compressed || !d_compressedSize || !d_out || !d_outOffsets || numBlocks == 0)
         return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (p->config.algorithm == CUDPP_COMPRESS) static_cast<CompressPlan *>(p)->join_side();
     return hip_result(compact_streams(p->stream, d_compressed, compressedStrideWords, d_compressedSize,
                                       (uint32_t)numBlocks, d_out, d_outOffsets));
 }

@@ -110,6 +110,7 @@ hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride
 struct DecodeScratch {
     uint32_t nmax = 0, rows = 0, max_tiles = 0, max_split = 0, max_chunks = 0;
     uint8_t  *mtf = nullptr, *bwt = nullptr;     // [rows][nmax]
+    uint8_t  *bwt2 = nullptr;                    // second BWT buffer for stage pipelining
     uint8_t  *ilists = nullptr;                  // [rows][max_chunks][256] iMTF chunk permutations / start lists
     uint32_t *lf = nullptr;                      // [rows][nmax+1]  (symbol << 21) | LF(row)
     uint32_t *lut = nullptr;                     // [rows][4096] 12-bit Huffman decode table
@@ -127,6 +128,11 @@ hipError_t tile_hist_scan9(hipStream_t st, uint32_t *tile_hist, uint32_t count, 
                            uint32_t max_tiles, uint32_t nblk, uint32_t tile_elems);
 hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows);
 void       decode_scratch_free(DecodeScratch &s);
+hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t *d_offsets, size_t offset_stride,
+                          const uint32_t *d_comp, size_t comp_stride_words, uint32_t n, uint32_t nblk, DecodeScratch &s,
+                          uint8_t *bwt);
+hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t *bwt, uint8_t *d_out, uint32_t n,
+                          uint32_t nblk, DecodeScratch &s);
 hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist,
                          const uint32_t *d_offsets, size_t offset_stride, const uint32_t *d_comp,
                          size_t comp_stride_words, uint8_t *d_out, uint32_t n, uint32_t nblk,

@@ -184,10 +184,13 @@ CUDPPResult glcPlanSetStream(CUDPPHandle planHandle, void *hipStream);
  * per-4096-symbol capacity of the reference format. */
 CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle);
 
-/* Stage pipelining for batched encode (off by default).  When on, glcCompressBatch / cudppCompress run
- * the suffix sort of a call on an internal stream so that it overlaps the MTF + Huffman stages of the
- * previous call, which stay on the plan's stream.  Nothing changes for the caller: the input is fully
- * consumed when the call returns (as before), and every output is ordered on the plan's stream. */
+/* Stage pipelining across batched calls (off by default).  When on, the second half of a call -- the
+ * MTF + Huffman stages of glcCompressBatch / cudppCompress, the inverse BWT of glcDecompressBatch -- runs
+ * on an internal stream, where it overlaps the first half (suffix sort; Huffman decode + inverse MTF) of
+ * the NEXT call on the plan's stream.  Inputs keep their meaning: they are read in stream order on the
+ * plan's stream.  OUTPUT buffers written by the second half (d_hist, d_encodeOffset, d_compressedSize,
+ * d_compressed; the decoder's d_out) are complete after glcPlanSynchronize, glcCompactStreams, turning
+ * pipelining off, or a device synchronize -- not merely "later on the plan's stream". */
 CUDPPResult glcPlanSetPipelining(CUDPPHandle planHandle, int on);
 
 /* Per-stage device time of the plan's last batched compress, in milliseconds,

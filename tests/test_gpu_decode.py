@@ -93,3 +93,25 @@ def test_batch_round_trip_misaligned_rows(glc, cuda, plan_n, n, nb):
             got = comp["words"][b * comp["stride"]: b * comp["stride"] + int(sizes[b])].cpu().numpy().view(np.uint32)
             assert int(comp["bwt_index"][b].item()) == want["bwt_index"] and int(sizes[b]) == want["size"]
             assert np.array_equal(got, want["words"])
+
+
+def test_pipelined_decode_calls(glc, cuda):
+    """glcPlanSetPipelining on the decode side: Huffman + inverse MTF of call i+1 on the second stream
+    while the inverse BWT of call i runs on the plan's stream; six back-to-back calls, outputs read
+    through the plan's stream."""
+    import torch
+    n, nb, calls = 1 << 17, 4, 6
+    batches = [np.concatenate([datagen.zipf_bytes(n, seed=3000 + 10 * c + b) if (b + c) % 2 else
+                               datagen.text_bytes(n, seed=4000 + 10 * c + b) for b in range(nb)]) for c in range(calls)]
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=nb) as plan:
+        comps = [glc.compress_batch(plan, torch.from_numpy(x).cuda(), n, nb) for x in batches]
+        plan.synchronize()
+        plan.set_pipelining(True)
+        outs = [glc.decompress_batch(plan, c, n, nb) for c in comps]           # no sync in between
+        plan.synchronize()
+        for x, o in zip(batches, outs):
+            assert np.array_equal(o.cpu().numpy(), x)
+        plan.set_pipelining(False)
+        back = glc.decompress_batch(plan, comps[2], n, nb)
+        plan.synchronize()
+        assert np.array_equal(back.cpu().numpy(), batches[2])
