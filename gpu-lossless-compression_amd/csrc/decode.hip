@@ -463,10 +463,21 @@ __global__ __launch_bounds__(256) void k_ibwt_lf(const uint8_t *__restrict__ bwt
 // SLOT-byte slot; a walk that fills its slot before reaching the next splitter row continues in
 // a freshly allocated ("dynamic") segment, so slots are bounded whatever the cycle looks like.
 //   seg_info[id] = len | next << 9 ; ids < nsplit are the static splitters.
+template <int PAD>
 __global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ lf, size_t lf_stride, uint32_t n,
                                                    uint32_t *__restrict__ seg_info, uint32_t max_seg,
                                                    uint32_t *__restrict__ seg_count, uint8_t *__restrict__ tmp)
 {
+    // PAD extra VGPRs are held live across the walk to cap its residency at 4 waves per SIMD (1024 lanes
+    // per CU): a pointer chase gains nothing beyond that, and under stage pipelining every slot it does
+    // not hold goes to the LDS/VALU-bound stage A of the next batch.  Registers, not LDS, are the resource
+    // to spend on the cap, because the kernels it shares the CU with live on LDS.  Measured, 4 GiB
+    // pipelined decode: no cap 25.3 GB/s, 40 KB LDS cap 25.9, 118-VGPR cap 26.6; back to back 22.8 -> 23.5.
+    uint32_t pad[PAD > 0 ? PAD : 1];
+    if (PAD > 0) {
+#pragma unroll
+        for (int i = 0; i < PAD; i++) asm volatile("v_mov_b32 %0, %1" : "=v"(pad[i]) : "v"(threadIdx.x + i));
+    }
     const uint32_t b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
     const uint32_t rows = n + 1, nsplit = (rows + SPLIT - 1) / SPLIT;
     if (s >= nsplit) return;
@@ -494,6 +505,10 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ 
             SI[id] = len | (nid << 9);
             id = nid; len = 0;
         }
+    }
+    if (PAD > 0) {
+#pragma unroll
+        for (int i = 0; i < PAD; i++) asm volatile("; keep %0" :: "v"(pad[i]));
     }
 }
 
@@ -648,15 +663,8 @@ hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t 
     hipLaunchKernelGGL(k_ibwt_lf, dim3(tiles, nblk), dim3(256), 0, st, bwt, (size_t)s.nmax, d_bwt_index, n,
                        s.tile_hist, s.digit_base, s.max_tiles, s.lf, lf_stride);
     hipLaunchKernelGGL(k_ibwt_seg_init, dim3((nblk + 255) / 256), dim3(256), 0, st, s.seg_count, n, nblk);
-    {
-        // the walk is a pointer chase: it gains nothing from more than ~1024 lanes per CU, and every slot it
-        // does not hold is free for the LDS/VALU-bound stage A of the next batch on the other stream.  The
-        // unused dynamic LDS request caps its residency.
-        // Measured (4 GiB, MI355X): 0 KB 22.8 / 25.4 GB/s (plain / pipelined decode), 36-48 KB 23.5 / 25.9, 60 KB 23.1.
-        constexpr size_t WALK_LDS_CAP = 40 * 1024;             // 4 workgroups (1024 lanes) per CU
-        hipLaunchKernelGGL(k_ibwt_walk, dim3((nsplit + 255) / 256, nblk), dim3(256), WALK_LDS_CAP, st, s.lf,
-                           lf_stride, n, s.seg, s.max_seg, s.seg_count, s.slots);
-    }
+    hipLaunchKernelGGL(k_ibwt_walk<100>, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,
+                       s.max_seg, s.seg_count, s.slots);
     hipLaunchKernelGGL(k_ibwt_rank, dim3(nblk), dim3(RANK_NT), 0, st, s.seg, s.max_seg, s.seg_count, s.seg_pos);
     const uint32_t seg_bound = nsplit + rows / SLOT + 1;
     hipLaunchKernelGGL(k_ibwt_emit, dim3((seg_bound + 4 * EMIT_SEGS - 1) / (4 * EMIT_SEGS), nblk), dim3(256), 0, st,
