@@ -28,7 +28,7 @@ def main():
     prof = db_in(os.path.join(out, tag + "_prof"))
     if prof:
         md = os.path.join(HERE, tag + "_kernel_stats.md")
-        open(md, "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --gib 1 --steps 1 --warmup 1 "
+        open(md, "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --gib 4 --steps 1 --warmup 1 "
                             "--no-cpu-baseline  (MI355X, %s)\n\n" % tag)
         subprocess.run([sys.executable, os.path.join(HERE, "summarize_rocpd.py"), prof, md], check=True,
                        capture_output=True)
