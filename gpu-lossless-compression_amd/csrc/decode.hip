@@ -579,16 +579,36 @@ __global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ t
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63;
     const uint32_t nseg = min(seg_count[b], max_seg);
     uint8_t *O = out + (size_t)b * out_stride;
-#pragma unroll 1
+    const uint32_t id0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * EMIT_SEGS;
+    // the records of all EMIT_SEGS segments first, then all of their bytes, then the stores: three
+    // memory round trips per wave instead of three per segment
+    uint32_t len[EMIT_SEGS];
+    int pos[EMIT_SEGS];
+#pragma unroll
     for (uint32_t k = 0; k < EMIT_SEGS; k++) {
-        const uint32_t id = (blockIdx.x * 4 + (threadIdx.x >> 6)) * EMIT_SEGS + k;
-        if (id >= nseg) return;
-        const uint32_t len = seg_info[(size_t)b * max_seg + id] & 511u;
-        const int pos = seg_pos[(size_t)b * max_seg + id];
-        const uint8_t *S = tmp + ((size_t)b * max_seg + id) * SLOT;
-        for (uint32_t i = l; i < len; i += 64) {
-            const uint32_t t = (uint32_t)(pos - (int)i);
-            if (t < n) O[t] = S[i];
+        const uint32_t id = id0 + k;
+        const bool ok = id < nseg;
+        const uint32_t si = seg_info[(size_t)b * max_seg + (ok ? id : 0u)];
+        pos[k] = seg_pos[(size_t)b * max_seg + (ok ? id : 0u)];
+        len[k] = ok ? (si & 511u) : 0u;
+    }
+    uint8_t v[EMIT_SEGS][SLOT / 64];
+#pragma unroll
+    for (uint32_t k = 0; k < EMIT_SEGS; k++) {
+        const uint8_t *S = tmp + ((size_t)b * max_seg + min(id0 + k, max_seg - 1)) * SLOT;
+#pragma unroll
+        for (uint32_t j = 0; j < SLOT / 64; j++) {
+            const uint32_t i = l + 64 * j;
+            v[k][j] = S[i < len[k] ? i : 0u];
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < EMIT_SEGS; k++) {
+#pragma unroll
+        for (uint32_t j = 0; j < SLOT / 64; j++) {
+            const uint32_t i = l + 64 * j;
+            const uint32_t t = (uint32_t)(pos[k] - (int)i);
+            if (i < len[k] && t < n) O[t] = v[k][j];
         }
     }
 }
