@@ -625,6 +625,96 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// Tile-local refinement.  The unresolved list of a round is in SA order, so the members of a group
+// (equal bits >= gshift) are contiguous, and a refinement round only has to order each group by its
+// new key bits [20, gshift).  Groups are tiny (2-10 suffixes on Zipf data, at most a few hundred), so
+// instead of five global radix passes over the list every entry ranks itself inside its group by a
+// direct count -- one read and one write of the list.  A tile owns the groups that START in it and
+// stages RL_HALO more entries for their tails; a group longer than RL_HALO flags its block, and
+// flagged blocks (only those) go through the global radix sort afterwards.
+// ---------------------------------------------------------------------------
+constexpr uint32_t RL_T = 2048, RL_HALO = 2048, RL_NT = 256;
+constexpr uint32_t RL_MAXG = 1024;                              // longest group ranked by direct count
+constexpr uint32_t RL_E = (RL_T + RL_HALO + 1 + RL_NT - 1) / RL_NT;   // staged entries per thread (17)
+
+__global__ __launch_bounds__(RL_NT) void k_refine_local(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                        const uint32_t *__restrict__ cnt, uint32_t nmax,
+                                                        uint32_t gshift, uint32_t *__restrict__ flag)
+{
+    __shared__ uint64_t s_w[RL_NT * RL_E];
+    __shared__ uint16_t s_gs[RL_NT * RL_E], s_end[RL_NT * RL_E];
+    __shared__ uint32_t s_tmp[RL_NT / 64 + 1];
+    const uint32_t b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t m = cnt[b], t0 = blockIdx.x * RL_T;
+    if (t0 >= m) return;
+    const uint64_t *I = in + (size_t)b * nmax;
+    uint64_t *O = out + (size_t)b * nmax;
+    const uint32_t hi = min(m, t0 + RL_T + RL_HALO);            // staged list range [t0 - 1, hi)
+    const uint32_t cntl = hi - t0 + 1;                          // local index j <-> list index t0 - 1 + j
+    {
+        uint64_t q[RL_E];
+#pragma unroll
+        for (int r = 0; r < (int)RL_E; r++) {                   // all loads in flight, coalesced
+            const uint32_t i = r * RL_NT + tid;
+            const int64_t g = (int64_t)t0 - 1 + i;
+            q[r] = (i < cntl && g >= 0) ? I[g] : ~0ull;        // before the list: a group nobody has
+        }
+#pragma unroll
+        for (int r = 0; r < (int)RL_E; r++) s_w[r * RL_NT + tid] = q[r];
+    }
+    __syncthreads();
+    // group start of every staged entry: max-scan of the head positions (thread = RL_E consecutive entries)
+    const uint32_t j0 = tid * RL_E;
+    uint32_t lh = 0;
+    uint32_t headm = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < RL_E; i++) {
+        const uint32_t j = j0 + i;
+        if (j > 0 && j < cntl && (s_w[j] >> gshift) != (s_w[j - 1] >> gshift)) { headm |= 1u << i; lh = j; }
+    }
+    uint32_t run = block_excl_max<RL_NT>(lh, s_tmp);
+#pragma unroll
+    for (uint32_t i = 0; i < RL_E; i++) {
+        const uint32_t j = j0 + i;
+        if (headm & (1u << i)) run = j;
+        if (j < cntl) { s_gs[j] = (uint16_t)run; s_end[j] = 0xFFFFu; }
+    }
+    __syncthreads();
+    // group end, stored at the group's start: the next head, or the end of the LIST (not of the staged range)
+#pragma unroll
+    for (uint32_t i = 0; i < RL_E; i++) {
+        const uint32_t j = j0 + i;
+        if ((headm & (1u << i)) && j > 0) s_end[s_gs[j - 1]] = (uint16_t)j;
+    }
+    if (tid == 0 && t0 - 1 + cntl == m) s_end[s_gs[cntl - 1]] = (uint16_t)cntl;
+    __syncthreads();
+    // owned entries rank themselves inside their group
+    for (uint32_t j = 1 + tid; j < cntl; j += RL_NT) {
+        const uint32_t gs = s_gs[j];
+        if (gs == 0 || gs > RL_T) continue;                     // group started before this tile / starts in the halo
+        const uint32_t ge = s_end[gs];
+        if (ge == 0xFFFFu || ge - gs > RL_MAXG) {               // tail not staged or too long for a direct count
+            if (j == gs) atomicOr(&flag[b], 1u);
+            continue;
+        }
+        const uint64_t w = s_w[j], key = w >> VAL_BITS;
+        uint32_t rank = 0;
+        for (uint32_t f = gs; f < ge; f++) {
+            const uint64_t kf = s_w[f] >> VAL_BITS;
+            rank += (kf < key || (kf == key && f < j)) ? 1u : 0u;
+        }
+        O[t0 - 1 + gs + rank] = w;
+    }
+}
+
+__global__ void k_refine_counts(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ flag,
+                                uint32_t *__restrict__ cnt_flagged, uint32_t nblk)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) cnt_flagged[b] = flag[b] ? cnt[b] : 0u;
+}
+
 // switch from text refinement to prefix doubling: ranks of every suffix in the order
 // established so far.  Resolved suffixes: rank = own SA slot + 1 ...
 __global__ __launch_bounds__(256) void k_isa_init(const uint32_t *__restrict__ sa, uint32_t *__restrict__ isa,
@@ -700,6 +790,8 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.hdA, ne * 4)); GLC_TRY(A((void **)&s.hdB, ne * 4));
     GLC_TRY(A((void **)&s.cntA, (size_t)rows * 4)); GLC_TRY(A((void **)&s.cntB, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.d_max_cnt, 16));
+    GLC_TRY(A((void **)&s.rl_flag, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.rl_cnt, (size_t)rows * 4));
     GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 16, hipHostMallocDefault));
     s.bytes = total;
     return hipSuccess;
@@ -708,7 +800,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 void sa_scratch_free(SaScratch &s)
 {
     void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
-                  s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt};
+                  s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
     for (auto &e : s.prof_ev) if (e) (void)hipEventDestroy(e);
@@ -730,7 +822,7 @@ static void prof_collect(SaScratch &s)
 // one LSD sort = prehist + digitbase + npass onesweep launches; result ends in `*cur`
 static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, const uint32_t *cnt, uint32_t nfixed,
                              const PassPlan &pp, uint32_t tiles, uint32_t nblk, SaScratch &s, double live_total,
-                             const TextSrc *src = nullptr)
+                             const TextSrc *src = nullptr, bool profile = true)
 {
     // `tiles` counts SA_TILE-word tiles (rank kernel); the radix kernels use RS_TILE
     const uint32_t rs_tiles = (tiles * (uint32_t)SA_TILE + RS_TILE - 1) / RS_TILE;
@@ -750,7 +842,7 @@ static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, con
         GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
         // profiled kernel = k_rs_onesweep<8,false> (16 algorithmic bytes per live suffix); the text-sourced
         // first pass of round 0 is a different kernel (1 R + 8 W) and is left out
-        const bool prof = s.prof && pp.bits[p] == 8 && !(p == 0 && src) && s.prof_used < 64;
+        const bool prof = profile && s.prof && pp.bits[p] == 8 && !(p == 0 && src) && s.prof_used < 64;
         if (prof) {
             for (int k = 0; k < 2; k++)
                 if (!s.prof_ev[2 * s.prof_used + k]) GLC_TRY(hipEventCreate(&s.prof_ev[2 * s.prof_used + k]));
@@ -776,6 +868,21 @@ static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, con
         uint64_t *x = cur; cur = alt; alt = x;
     }
     return hipGetLastError();
+}
+
+// order every group of the unresolved list by its new key bits: tile-local for the blocks whose groups
+// all fit, global radix sort for the rest.  Result in `cur` either way.
+static hipError_t refine_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, const uint32_t *cnt, const PassPlan &pp,
+                              uint32_t gshift, uint32_t maxc, uint32_t tiles, uint32_t nblk, SaScratch &s,
+                              double live_total)
+{
+    GLC_TRY(hipMemsetAsync(s.rl_flag, 0, (size_t)nblk * 4, st));
+    hipLaunchKernelGGL(k_refine_local, dim3((maxc + RL_T - 1) / RL_T, nblk), dim3(RL_NT), 0, st, cur, alt, cnt, s.nmax,
+                       gshift, s.rl_flag);
+    hipLaunchKernelGGL(k_refine_counts, dim3((nblk + 255) / 256), dim3(256), 0, st, cnt, s.rl_flag, s.rl_cnt, nblk);
+    // npass is odd: the radix sort leaves its result in what is `alt` now -- where the tile-local kernel wrote
+    // (not profiled: how many suffixes of the flagged blocks it moves is only known on the device)
+    return radix_sort(st, cur, alt, s.rl_cnt, 0, pp, tiles, nblk, s, live_total, nullptr, false);
 }
 
 hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
@@ -857,7 +964,7 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         if (mode == MODE_TEXT) {
             // 44 key bits at [20, 64): 8+9+9+9+9
             PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 17, VAL_BITS + 26, VAL_BITS + 35}, {8, 9, 9, 9, 9}};
-            GLC_TRY(radix_sort(st, cur, alt, cnt_cur, 0, pp, tiles, nblk, s, live_total));
+            GLC_TRY(refine_sort(st, cur, alt, cnt_cur, pp, TXT_GRP_SHIFT, maxc, tiles, nblk, s, live_total));
             depth += 3;
             text_rounds++;
         } else {
@@ -865,7 +972,7 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                                n, depth, s.nmax);
             // 42 key bits at [20, 62): 8+8+8+9+9
             PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 16, VAL_BITS + 24, VAL_BITS + 33}, {8, 8, 8, 9, 9}};
-            GLC_TRY(radix_sort(st, cur, alt, cnt_cur, 0, pp, tiles, nblk, s, live_total));
+            GLC_TRY(refine_sort(st, cur, alt, cnt_cur, pp, R1_SHIFT, maxc, tiles, nblk, s, live_total));
             depth *= 2;
         }
     }

@@ -34,6 +34,7 @@ struct SaScratch {
     uint32_t *ticket = nullptr;                  // [rows] tile tickets of the single-pass rank kernel
     uint32_t *hdA = nullptr, *hdB = nullptr;     // [rows][nmax] SA slot of the group head of each unresolved entry
     uint32_t *cntA = nullptr, *cntB = nullptr;   // [rows] unresolved counts
+    uint32_t *rl_flag = nullptr, *rl_cnt = nullptr;   // [rows] tile-local refinement: block needs the global sort / its count
     uint32_t *d_max_cnt = nullptr;               // [2] max and sum of the unresolved counts
     uint32_t *h_max_cnt = nullptr;               // pinned [2]
     size_t    bytes = 0;
