@@ -709,10 +709,14 @@ __global__ __launch_bounds__(RL_NT) void k_refine_local(const uint64_t *__restri
 }
 
 __global__ void k_refine_counts(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ flag,
-                                uint32_t *__restrict__ cnt_flagged, uint32_t nblk)
+                                uint32_t *__restrict__ cnt_flagged, uint32_t nblk, uint32_t *__restrict__ total)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nblk) cnt_flagged[b] = flag[b] ? cnt[b] : 0u;
+    if (b < nblk) {
+        const uint32_t c = flag[b] ? cnt[b] : 0u;
+        cnt_flagged[b] = c;
+        if (c) atomicAdd(total, c);
+    }
 }
 
 // switch from text refinement to prefix doubling: ranks of every suffix in the order
@@ -879,10 +883,16 @@ static hipError_t refine_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, co
     GLC_TRY(hipMemsetAsync(s.rl_flag, 0, (size_t)nblk * 4, st));
     hipLaunchKernelGGL(k_refine_local, dim3((maxc + RL_T - 1) / RL_T, nblk), dim3(RL_NT), 0, st, cur, alt, cnt, s.nmax,
                        gshift, s.rl_flag);
-    hipLaunchKernelGGL(k_refine_counts, dim3((nblk + 255) / 256), dim3(256), 0, st, cnt, s.rl_flag, s.rl_cnt, nblk);
+    GLC_TRY(hipMemsetAsync(s.d_max_cnt + 3, 0, 4, st));
+    hipLaunchKernelGGL(k_refine_counts, dim3((nblk + 255) / 256), dim3(256), 0, st, cnt, s.rl_flag, s.rl_cnt, nblk,
+                       s.d_max_cnt + 3);
+    GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 3, s.d_max_cnt + 3, 4, hipMemcpyDeviceToHost, st));
+    GLC_TRY(hipStreamSynchronize(st));                         // one more host round trip per refinement round
+    (void)live_total;
+    const uint32_t flagged_live = s.h_max_cnt[3];
+    if (flagged_live == 0) { uint64_t *x = cur; cur = alt; alt = x; return hipSuccess; }   // every group was local
     // npass is odd: the radix sort leaves its result in what is `alt` now -- where the tile-local kernel wrote
-    // (not profiled: how many suffixes of the flagged blocks it moves is only known on the device)
-    return radix_sort(st, cur, alt, s.rl_cnt, 0, pp, tiles, nblk, s, live_total, nullptr, false);
+    return radix_sort(st, cur, alt, s.rl_cnt, 0, pp, tiles, nblk, s, (double)flagged_live);
 }
 
 hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
@@ -935,9 +945,6 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         const uint32_t maxc = s.h_max_cnt[0];
         live_total = (double)s.h_max_cnt[1];
         if (s.h_max_cnt[2]) return hipErrorUnknown;               // a look-back spin hit its bound
-#ifdef GLC_EXP_COUNT
-        fprintf(stderr, "[lb] round %d: count %u (mode %d) live %.0f\n", rounds, s.h_max_cnt[3], GLC_EXP_COUNT, live_total);
-#endif
         if (maxc == 0) break;
         if (depth >= 2u * n + 16u) return hipErrorUnknown;        // cannot happen: depth >= n resolves everything
         // next round works on the compacted list that k_sa_rank<true> wrote into `alt`
