@@ -13,6 +13,11 @@ per-GPU input is fixed).  The one exchange step of SURVEY.md 8(e) -- gathering t
 compacted bitstreams on rank 0 over RCCL -- runs once after the timed region and is
 reported as `gather_to_rank0` (--with-gather moves it into every timed step).
 
+The timed encode leg uses one plan with its stages back to back, so that the launch time of the
+dominant kernel reported under `roofline` is the kernel's own (--enc-pipeline and --enc-threads 2
+--rows 128 overlap stages / plans for +5-10 % throughput).  The decode leg, reported beside it, uses
+--plans host threads with stage pipelining.
+
 Prints ONE JSON line on rank 0; `value` = whole-job input GB/s of the encode.
 """
 import argparse
