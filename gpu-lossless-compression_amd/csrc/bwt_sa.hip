@@ -395,6 +395,101 @@ __device__ __forceinline__ uint64_t lb_combine(uint64_t earlier, uint64_t later)
     return ((he > hl ? he : hl) << 41) | cnts;
 }
 
+// Tile aggregates ahead of the rank kernel.  A decoupled look-back inside k_sa_rank1 (all 512 tiles of a
+// block are in flight together, so every tile waits for up to 511 predecessors) cost 1.2 of its 2.9 ms;
+// reading the sorted words once more (0.45 ms) and scanning the 512 aggregates of a block in one
+// workgroup gives every tile its exclusive prefix before the rank kernel starts -- no tickets, no spinning.
+__global__ __launch_bounds__(SA_THREADS) void k_rank_pre(const uint64_t *__restrict__ key, const uint32_t *__restrict__ cnt,
+                                                         uint32_t nfixed, unsigned long long *__restrict__ tile_agg,
+                                                         uint32_t nmax, uint32_t max_tiles)
+{
+    __shared__ uint32_t s_r[3][SA_THREADS / 64];
+    const uint32_t tid = threadIdx.x, b = blockIdx.y, t = blockIdx.x;
+    const uint32_t m = live_count(cnt, nfixed, b), base = t * SA_TILE;
+    if (base >= m) return;
+    const uint64_t *K = key + (size_t)b * nmax;
+    // coalesced: row r of the tile is 256 consecutive elements, one per thread; the neighbours come from
+    // the adjacent lanes (DPP wave_shr:1 / wave_shl:1), the two edge lanes of a wave load theirs
+    const uint32_t l = tid & 63;
+    uint64_t c[SA_ITEMS], edge[SA_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        const uint32_t e = base + r * SA_THREADS + tid;
+        c[r] = K[e < m ? e : 0u];
+    }
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        const uint32_t e = base + r * SA_THREADS + tid;
+        const uint32_t ei = (l == 0) ? e - 1 : e + 1;           // (e = 0 wraps to 0xFFFFFFFF: fails the bound test)
+        const bool ed = (l == 0 || l == 63) && ei < m;
+        edge[r] = K[ed ? ei : (e < m ? e : 0u)];                // unconditional (interior lanes re-read their own word:
+                                                                 // an L1 hit) so the loads of all rows stay in flight
+    }
+    uint32_t lh = 0, uc = 0, uh = 0;
+#pragma unroll
+    for (int r = 0; r < SA_ITEMS; r++) {
+        const uint32_t e = base + r * SA_THREADS + tid;
+        const uint32_t ei = (l == 0) ? e - 1 : e + 1;
+        const bool ed = (l == 0 || l == 63) && ei < m;
+        const uint64_t kc = c[r] >> VAL_BITS, ke = ed ? edge[r] >> VAL_BITS : 0ull;
+        const uint32_t clo = (uint32_t)kc, chi = (uint32_t)(kc >> 32);
+        uint64_t kp = ((uint64_t)GLC_DPP(chi, 0x138, 0xf) << 32) | GLC_DPP(clo, 0x138, 0xf);      // lane - 1
+        uint64_t kn = ((uint64_t)GLC_DPP(chi, 0x130, 0xf) << 32) | GLC_DPP(clo, 0x130, 0xf);      // lane + 1
+        if (l == 0) kp = ke;
+        if (l == 63) kn = ke;
+        if (e < m) {
+            const bool head = (e == 0) || (kc != kp);
+            const bool nhead = (e + 1 >= m) || (kn != kc);
+            if (head) lh = max(lh, e);
+            if (!(head && nhead)) { uc++; if (head) uh++; }
+        }
+    }
+    lh = wave_max(lh); uc = wave_sum(uc); uh = wave_sum(uh);
+    if ((tid & 63) == 0) { s_r[0][tid >> 6] = lh; s_r[1][tid >> 6] = uc; s_r[2][tid >> 6] = uh; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0, c = 0, h = 0;
+#pragma unroll
+        for (int q = 0; q < SA_THREADS / 64; q++) { a = max(a, s_r[0][q]); c += s_r[1][q]; h += s_r[2][q]; }
+        tile_agg[(size_t)b * max_tiles + t] = lb_pack(a, c, h);
+    }
+}
+
+// exclusive scan of the tile aggregates of a block (in place) + the block's unresolved total
+__global__ __launch_bounds__(256) void k_rank_scan(unsigned long long *__restrict__ tile_agg,
+                                                   const uint32_t *__restrict__ cnt, uint32_t nfixed,
+                                                   uint32_t max_tiles, uint32_t *__restrict__ cnt_next,
+                                                   uint32_t *__restrict__ d_max_cnt)
+{
+    __shared__ uint32_t s_tmp[8];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t m = live_count(cnt, nfixed, b);
+    const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
+    unsigned long long *A = tile_agg + (size_t)b * max_tiles;
+    uint32_t run_h = 0, run_c = 0, run_u = 0;                   // carried over 256-tile rounds
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 256) {
+        const uint32_t t = t0 + tid;
+        const uint64_t a = t < ntiles ? A[t] : 0ull;
+        const uint32_t h = (uint32_t)(a >> 41), c = (uint32_t)((a >> 20) & 0x1FFFFF), u = (uint32_t)(a & 0xFFFFF);
+        uint32_t tc = 0, tu = 0;
+        const uint32_t eh = block_excl_max<256>(h, s_tmp);
+        const uint32_t ec = block_excl_add<256>(c, s_tmp, &tc);
+        const uint32_t eu = block_excl_add<256>(u, s_tmp, &tu);
+        uint32_t th = wave_max(h);
+        __syncthreads();
+        if ((tid & 63) == 0) s_tmp[tid >> 6] = th;
+        __syncthreads();
+        th = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
+        __syncthreads();
+        if (t < ntiles) A[t] = lb_pack(max(run_h, eh), run_c + ec, run_u + eu);
+        run_h = max(run_h, th); run_c += tc; run_u += tu;
+    }
+    if (tid == 0) {
+        cnt_next[b] = run_c;
+        if (run_c) { atomicMax(d_max_cnt, run_c); atomicAdd(d_max_cnt + 1, run_c); }
+    }
+}
+
 template <bool ROUND0>
 __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restrict__ key,
                                                          const uint32_t *__restrict__ pos,
@@ -418,18 +513,14 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
 #define LK(j) s_k[(j) + ((j) >> 3)]
     __shared__ uint64_t s_k[SA_TILE + 2 + (SA_TILE + 2) / 8 + 1];
     __shared__ uint32_t s_tmp[12];
-    __shared__ uint32_t s_tile;
-    __shared__ uint64_t s_excl;
     const uint32_t tid = threadIdx.x;
     // (an XCD-aware remap -- all tiles of a block on one XCD so its text stays in that L2 -- was
     //  measured slower on MI355X: 17.5 vs 16.3 ms per 256 blocks; plain dispatch order is kept)
     const uint32_t b = blockIdx.y;
     const uint32_t m = live_count(cnt, nfixed, b);
-    if (tid == 0) s_tile = atomicAdd(&ticket[b], 1u);
-    __syncthreads();
-    const uint32_t t = s_tile, base = t * SA_TILE;
+    const uint32_t t = blockIdx.x, base = t * SA_TILE;
     if (base >= m) return;
-    const uint32_t ntiles = (m + SA_TILE - 1) / SA_TILE;
+    const uint64_t excl = tile_state[(size_t)b * max_tiles + t];   // exclusive prefix from k_rank_pre + k_rank_scan
     const uint64_t *K = key + (size_t)b * nmax;
     const uint32_t *P = pos ? pos + (size_t)b * nmax : nullptr;
     {   // SA_ITEMS + 1 loads per thread, all in flight before the first LDS store
@@ -465,62 +556,6 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
     uint32_t tile_uc = 0, tile_uh = 0;
     const uint32_t off_t = block_excl_add<SA_THREADS>(uc, s_tmp, &tile_uc);
     const uint32_t goff_t = block_excl_add<SA_THREADS>(uh, s_tmp, &tile_uh);
-    uint32_t mx = wave_max(lh);
-    __syncthreads();
-    if ((tid & 63) == 0) s_tmp[tid >> 6] = mx;
-    __syncthreads();
-    uint32_t tile_lh = 0;
-#pragma unroll
-    for (int q = 0; q < SA_THREADS / 64; q++) tile_lh = max(tile_lh, s_tmp[q]);
-
-    // ---- decoupled look-back over the tiles of this block (wave 0) ----
-    unsigned long long *ST = tile_state + (size_t)b * max_tiles;
-    if (tid < 64) {
-        const uint64_t agg = lb_pack(tile_lh, tile_uc, tile_uh);
-        uint64_t excl = 0;
-        if (t == 0) {
-            if (tid == 0) __hip_atomic_store(&ST[0], LB_PFX | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (tid == 0) __hip_atomic_store(&ST[t], LB_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int look = (int)t - 1;
-            uint32_t spins = 0;
-            bool bad = false;
-            for (;;) {
-                const int idx = look - (int)tid;
-                uint64_t g = LB_PFX;                                      // lanes past tile 0: identity prefix
-                if (idx >= 0) g = __hip_atomic_load(&ST[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__any((g & LB_FLAGS) == 0)) {                         // a predecessor has not published yet
-                    if (++spins > (1u << 24)) { bad = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                const uint64_t pm = __ballot((g & LB_FLAGS) == LB_PFX);
-                const uint32_t first = pm ? (uint32_t)__builtin_ctzll(pm) : 63u;   // nearest lane holding a full prefix
-                uint64_t val = (tid <= first) ? (g & ~LB_FLAGS) : 0ull;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const uint32_t lo = __shfl_xor((uint32_t)val, o, 64), hi = __shfl_xor((uint32_t)(val >> 32), o, 64);
-                    val = lb_combine(val, ((uint64_t)hi << 32) | lo);
-                }
-                excl = lb_combine(val, excl);
-                if (pm) break;
-                look -= 64;
-            }
-            if (bad && tid == 0) atomicOr(d_err, 4u);
-            if (tid == 0)
-                __hip_atomic_store(&ST[t], LB_PFX | lb_combine(excl, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid == 0) {
-            s_excl = excl;
-            if (t + 1 == ntiles) {                                        // inclusive total of the block
-                const uint32_t total = (uint32_t)((lb_combine(excl, agg) >> 20) & 0x1FFFFF);
-                cnt_next[b] = total;
-                if (total) { atomicMax(d_max_cnt, total); atomicAdd(d_max_cnt + 1, total); }
-            }
-        }
-    }
-    __syncthreads();
-    const uint64_t excl = s_excl;
     const uint32_t carry = max(carry_t, (uint32_t)(excl >> 41));
     uint32_t off = (uint32_t)((excl >> 20) & 0x1FFFFF) + off_t;
     uint32_t gcount = (uint32_t)(excl & 0xFFFFF) + goff_t;
@@ -924,9 +959,10 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     for (;;) {
         dim3 g(tiles, nblk);
         GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 8, st));
-        GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
-        GLC_TRY(hipMemsetAsync(cnt_next, 0, (size_t)nblk * 4, st));   // blocks with nothing left launch no tile
-        GLC_TRY(hipMemsetAsync(s.tile_state, 0, (size_t)nblk * s.max_tiles * 8, st));
+        hipLaunchKernelGGL(k_rank_pre, g, dim3(SA_THREADS), 0, st, cur, cnt_cur, live, (unsigned long long *)s.tile_state,
+                           s.nmax, s.max_tiles);
+        hipLaunchKernelGGL(k_rank_scan, dim3(nblk), dim3(256), 0, st, (unsigned long long *)s.tile_state, cnt_cur, live,
+                           s.max_tiles, cnt_next, s.d_max_cnt);
         if (!pos_cur)
             hipLaunchKernelGGL(k_sa_rank1<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
                                (unsigned long long *)s.tile_state, s.ticket, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
