@@ -124,11 +124,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
+    # GLC_BENCH_ONE_DEVICE=1: dry run of the N > 1 code path on a one-GPU box (all ranks share device 0 and
+    # talk over gloo; RCCL refuses two ranks on one device).  Not a measurement.
+    one_device = os.environ.get("GLC_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     glc = _load("glc_binding", os.path.join(PKG, "glc_binding.py"))
     glc.lib()                                             # fails loudly if the HIP library is missing

@@ -17,6 +17,12 @@ def gather_streams(dist, torch, compact, compact_off, dst=0):
     Returns on dst: dict(total_words, per_rank_words, buffers=[tensor per rank]); None elsewhere."""
     world = dist.get_world_size()
     rank = dist.get_rank()
+    if dist.get_backend() == "gloo" and compact.is_cuda:
+        # gloo has no device-side gather: stage through the host (single-box dry runs of the N > 1 path)
+        res = gather_streams(dist, torch, compact.cpu(), compact_off.cpu(), dst)
+        if res is not None:
+            res["buffers"] = [b.to(compact.device) for b in res["buffers"]]
+        return res
     my_total = compact_off[-1:].clone()
     totals = [torch.empty_like(my_total) for _ in range(world)]
     dist.all_gather(totals, my_total)
