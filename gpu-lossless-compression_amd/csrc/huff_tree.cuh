@@ -22,15 +22,25 @@ struct HuffTreeLds {
     int      nl, head;
 };
 
+// wave-wide minimum of a 64-bit key, broadcast to every lane: inclusive min-scan on DPP (row_shr within
+// rows of 16, row_bcast:15 / :31 across rows; lanes without a source see the identity ~0), lane 63 holds
+// the result.  (The xor-shuffle butterfly it replaces is 12 ds_bpermute round trips per reduction, and
+// the tree build does up to 512 reductions back to back.)
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t k)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t lo = __shfl_xor((uint32_t)k, o, 64), hi = __shfl_xor((uint32_t)(k >> 32), o, 64);
-        uint64_t other = ((uint64_t)hi << 32) | lo;
-        k = other < k ? other : k;
+#define GLC_MIN_STEP(ctrl, rowmask)                                                                         \
+    {                                                                                                       \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)k, ctrl, rowmask, 0xf, false);          \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(k >> 32), ctrl, rowmask, 0xf, false);  \
+        const uint64_t other = ((uint64_t)hi << 32) | lo;                                                   \
+        k = other < k ? other : k;                                                                          \
     }
-    return k;
+    GLC_MIN_STEP(0x111, 0xf) GLC_MIN_STEP(0x112, 0xf) GLC_MIN_STEP(0x114, 0xf) GLC_MIN_STEP(0x118, 0xf)
+    GLC_MIN_STEP(0x142, 0xa) GLC_MIN_STEP(0x143, 0xc)
+#undef GLC_MIN_STEP
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)k, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(k >> 32), 63);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // Called by ONE full wave (l = lane).  hist257[256] must already hold the EOF count 1.
