@@ -1,0 +1,63 @@
+"""The boundary is a C ABI: a plain-C program (gcc, not hipcc) shaped like the reference's own compress
+test calls include/cudpp.h and must print the known answers of the reference vector."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "c_caller", "cudpp_rig.c")
+PKG = os.path.join(ROOT, "gpu-lossless-compression_amd")
+
+
+ORACLE = os.path.join(ROOT, "oracle")
+
+
+def _build(tmp_path, src=SRC, name="cudpp_rig", with_oracle=False):
+    exe = str(tmp_path / name)
+    cmd = ["gcc", "-O1", "-std=gnu99", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", src, "-o", exe,
+           "-L", PKG, "-lglc_amd", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    if with_oracle:
+        cmd += ["-L", ORACLE, "-lglc_oracle", "-Wl,-rpath," + ORACLE]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_caller_compiles_and_links_with_gcc(glc, tmp_path):
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    glc.lib()                                                  # builds libglc_amd.so if needed
+    assert os.path.exists(_build(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_caller_reproduces_the_reference_known_answers(glc, tmp_path):
+    glc.lib()
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(kv.split("=") for kv in r.stdout.split())
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_gold_1m.json")))
+    ct, st = want["compressTest"], want["compressTest_stream_restatement"]
+    assert out["in_crc"] == ct["crc_in"]                       # the generator matches the reference's (glibc rand)
+    assert int(out["bwt_index"]) == ct["bwt_index"] == 296638
+    assert int(out["size_words"]) == st["size_words"] == 262491
+    assert out["crc_words"] == st["crc_words"] == "e12686dc"
+    assert out["crc_offsets"] == st["crc_offsets"] == "62c9b10a"
+    assert out["crc_hist"] == "aaaaa264"
+
+
+@pytest.mark.gpu
+def test_c_caller_culzss_pipeline_sequence(glc, tmp_path):
+    """the reference pipeline's call sequence (culzss.c / deculzss.c) from plain C, four ring slots:
+    candidates and packed bytes equal the oracle's, in-place decompression restores the input"""
+    import oracle_lib as O
+    glc.lib()
+    O.lib()                                                    # builds liboracle if needed
+    exe = _build(tmp_path, os.path.join(ROOT, "tests", "c_caller", "culzss_rig.c"), "culzss_rig", with_oracle=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("packed_equal=1") == 4 and r.stdout.count("candidates_equal=1") == 4
