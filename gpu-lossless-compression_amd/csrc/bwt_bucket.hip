@@ -1,0 +1,413 @@
+// bwt_bucket.hip -- the fast suffix sorter: ONE bucketing pass over HBM, then every bucket is
+// sorted to the end inside LDS.  gfx950 / wave64.
+//
+// Replaces (result-for-result, same SA / BWT bytes / index) the reference's
+//   cudppSuffixArrayDispatch / ComputeSA     (cudpp-inpar/src/cudpp/app/sa_app.cu:125-298,365-391)
+//   bwt_compute_final_kernel                 (kernel/compress_kernel.cuh:55-74)
+// for data whose suffixes separate within a few dozen symbols (i.i.d. bytes, float data: configs 2 and 4).
+// Blocks it cannot finish are flagged and go through the general sorter in bwt_sa.hip.
+//
+// Idea.  A suffix is mapped to X = the arithmetic code of its first 6 symbols under the block's own
+// order-0 symbol statistics:
+//      y5 = C[s5];   y_d = C[s_d] + floor(p[s_d] * y_{d+1} / 2^32)  (d = 4..1);   X = C[s0] * 2^32 + p[s0] * y1
+// (C = exclusive cumulative frequency, p = frequency, both scaled to 2^32; symbols past the end of the
+// block contribute C = p = 0).  Two properties carry the whole design:
+//   * X is monotone: suffix a < suffix b lexicographically  =>  X(a) <= X(b)   (each step maps the
+//     sub-intervals of smaller symbols below those of larger ones, and floor() is monotone), so
+//     DIFFERENT codes are always in the right order and only EQUAL codes need a look at the text;
+//   * for i.i.d. data X is uniformly distributed whatever the symbol distribution is (Zipf included),
+//     so "top 9 bits of X" cuts a 1 MiB block into 512 buckets of 2048 +- 7 % suffixes WITHOUT any
+//     histogram of the buckets, and "next 12 bits" cuts a bucket into bins of ~0.5 suffixes.
+// One word per suffix = [top 36 bits of X | suffix index : 20 | T[i-1] : 8]: the BWT byte rides along, so
+// nothing is gathered afterwards.
+//
+//   k_fs_hist / k_fs_tables   symbol histogram of the block -> {C, p} table                 1 B read / suffix
+//   k_fs_part                 text tile -> words -> bucketed in LDS -> appended to the bucket's slot
+//                             (space reserved with one global atomic per (tile, bucket))      1 B R + 8 B W
+//   k_fs_scan                 bucket fill -> rank base of every bucket, overflow -> flag
+//   k_fs_sort                 one workgroup per bucket: counting sort on 12 more bits with LDS atomics
+//                             (no stability needed: the index is not a tie-breaker), direct ranking inside
+//                             the tiny bins, equal codes refined 4 text symbols at a time in place;
+//                             writes BWT bytes (+ SA) straight to their final rows              8 B R + 1 B W
+// = 19 B of HBM traffic per input byte (23 with the suffix array) where the 5-pass LSD sorter moves ~105.
+#include "glc_device.h"
+#include "glc_internal.h"
+
+namespace glc {
+
+constexpr int      FSP_NT    = 512;                 // k_fs_part: threads
+constexpr int      FSP_ITEMS = 8;
+constexpr int      FSP_TILE  = FSP_NT * FSP_ITEMS;  // suffixes per tile
+constexpr int      FSS_NT    = 512;                 // k_fs_sort: threads
+constexpr int      FSS_ITEMS = FS_CAP / FSS_NT;     // slots per thread
+constexpr uint32_t FS_BIN_BITS = 12, FS_BINS = 1u << FS_BIN_BITS;
+constexpr uint32_t FS_MAX_GROUP = 512;              // longest run of equal codes ranked by direct count
+constexpr uint32_t FS_MAX_DEPTH = 48;               // symbols compared before a block is declared deep
+constexpr uint64_t FS_LOW_MASK = (1ull << 28) - 1;  // [index : 20 | bwt : 8]
+
+uint32_t fs_bucket_log2(uint32_t n)
+{
+    uint32_t l = 0;
+    while (((uint64_t)FS_AVG << l) < n && l < 9) l++;
+    return l;
+}
+
+// ---------------------------------------------------------------------------
+// symbol histogram: 8 copies per workgroup (copy = lane & 7, stride 257 words so equal symbols of
+// different copies sit in different banks): equal symbols inside a wave serialise on an LDS atomic,
+// and Zipf data puts 10 lanes of 64 on the same symbol
+// ---------------------------------------------------------------------------
+constexpr uint32_t FSH_SLICE = 32768;
+
+__global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                 uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t s_h[8 * 257];
+    const uint32_t b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t lo = blockIdx.x * FSH_SLICE;
+    if (lo >= n) return;
+    const uint32_t hi = min(n, lo + FSH_SLICE);
+    for (uint32_t i = tid; i < 8 * 257; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const uint8_t *T = text + (size_t)b * stride;
+    uint32_t *H = s_h + (tid & 7) * 257;
+    uint32_t done = lo;
+    if ((reinterpret_cast<uintptr_t>(T + lo) & 15) == 0) {
+        const uint32_t nvec = (hi - lo) / 16;                       // <= 2048 = 8 per thread
+        const uint4 *V = reinterpret_cast<const uint4 *>(T + lo);
+        uint4 q[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t i = r * 256 + tid;
+            q[r] = i < nvec ? V[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (r * 256 + tid < nvec) {
+                const uint32_t wd[4] = {q[r].x, q[r].y, q[r].z, q[r].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    atomicAdd(&H[wd[k] & 0xFF], 1u);
+                    atomicAdd(&H[(wd[k] >> 8) & 0xFF], 1u);
+                    atomicAdd(&H[(wd[k] >> 16) & 0xFF], 1u);
+                    atomicAdd(&H[wd[k] >> 24], 1u);
+                }
+            }
+        }
+        done = lo + nvec * 16;
+    }
+    for (uint32_t i = done + tid; i < hi; i += 256) atomicAdd(&H[T[i]], 1u);
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c += s_h[k * 257 + tid];
+    if (c) atomicAdd(&hist[(size_t)b * 256 + tid], c);
+}
+
+// {C, p} scaled to 2^32.  floor() on both keeps C[s] + p[s] <= C[s+1], which is what makes the code monotone.
+__global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ hist, uint32_t n,
+                                                   uint2 *__restrict__ tab)
+{
+    __shared__ uint32_t s_tmp[5];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t h = hist[(size_t)b * 256 + tid];
+    const uint32_t c = block_excl_add<256>(h, s_tmp);
+    const uint64_t C32 = ((uint64_t)c << 32) / n, P32 = ((uint64_t)h << 32) / n;
+    tab[(size_t)b * 256 + tid] = make_uint2((uint32_t)(C32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : C32),
+                                            (uint32_t)(P32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : P32));
+}
+
+// ---------------------------------------------------------------------------
+// bucketing pass
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                    uint32_t nbl, const uint2 *__restrict__ tab,
+                                                    uint64_t *__restrict__ keys, size_t kstride,
+                                                    uint32_t *__restrict__ fill, uint32_t *__restrict__ flag)
+{
+    __shared__ uint2 s_tab[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_txt[FSP_TILE + 16];      // s_txt[k] = T[base - 1 + k]
+    __shared__ uint32_t s_cnt[FS_MAXNB], s_start[FS_MAXNB], s_gbase[FS_MAXNB];
+    __shared__ uint64_t s_w[FSP_TILE];
+    __shared__ uint32_t s_tmp[FSP_NT / 64 + 1];
+    const uint32_t b = blockIdx.y, tid = threadIdx.x, base = blockIdx.x * FSP_TILE;
+    if (base >= n) return;
+    const uint8_t *T = text + (size_t)b * stride;
+    if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
+    s_cnt[tid] = 0;
+    const bool edge = base + FSP_TILE + 16 > n;
+    if (base > 0 && !edge && (reinterpret_cast<uintptr_t>(T) & 3) == 0) {
+        // aligned dwords of T[base - 4 ...], shifted by 3 bytes on the way into LDS
+        const uint32_t *D = reinterpret_cast<const uint32_t *>(T + base - 4);
+        uint32_t lo[3], hi[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint32_t q = r * FSP_NT + tid;
+            const bool in = q < (FSP_TILE + 16) / 4;
+            lo[r] = in ? D[q] : 0u; hi[r] = in ? D[q + 1] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint32_t q = r * FSP_NT + tid;
+            if (q < (FSP_TILE + 16) / 4)
+                reinterpret_cast<uint32_t *>(s_txt)[q] = __builtin_amdgcn_alignbyte(hi[r], lo[r], 3);
+        }
+    } else {
+        for (uint32_t k = tid; k < FSP_TILE + 16; k += FSP_NT) {
+            const int64_t g = (int64_t)base - 1 + k;
+            s_txt[k] = g < 0 ? T[n - 1] : (g < (int64_t)n ? T[g] : (uint8_t)0);
+        }
+    }
+    __syncthreads();
+    // thread = 8 consecutive suffixes gi0 .. gi0+7; byte j of its 16 staged bytes is T[gi0 - 1 + j]
+    const uint32_t k0 = tid * FSP_ITEMS, gi0 = base + k0;
+    const uint2 qa = *reinterpret_cast<const uint2 *>(s_txt + k0), qb = *reinterpret_cast<const uint2 *>(s_txt + k0 + 8);
+    const uint32_t by4[4] = {qa.x, qa.y, qb.x, qb.y};
+#define FS_BYTE(j) ((by4[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
+    uint2 e[FSP_ITEMS + 5];                                    // table entries of the 13 symbols the 8 codes share
+#pragma unroll
+    for (int k = 0; k < FSP_ITEMS + 5; k++) {
+        const uint2 t = s_tab[FS_BYTE(1 + k)];
+        e[k] = (edge && gi0 + k >= n) ? make_uint2(0u, 0u) : t;
+    }
+    uint64_t w[FSP_ITEMS];
+    uint32_t br[FSP_ITEMS];                                    // bucket << 16 | rank inside (tile, bucket)
+#pragma unroll
+    for (int j = 0; j < FSP_ITEMS; j++) {
+        uint32_t y = e[j + 5].x;
+#pragma unroll
+        for (int d = 4; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
+        const uint64_t X = ((uint64_t)e[j].x << 32) + (uint64_t)e[j].y * y;
+        const uint32_t gi = gi0 + j;
+        w[j] = (X & ~FS_LOW_MASK) | ((uint64_t)gi << 8) | FS_BYTE(j);
+        const uint32_t bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
+        br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
+    }
+#undef FS_BYTE
+    __syncthreads();
+    {
+        const uint32_t c = s_cnt[tid];
+        const uint32_t start = block_excl_add<FSP_NT>(c, s_tmp);
+        uint32_t g = 0;
+        if (c) {
+            g = atomicAdd(&fill[(size_t)b * FS_MAXNB + tid], c);
+            if (g + c > FS_CAP) atomicOr(&flag[b], 1u);
+        }
+        s_start[tid] = start; s_gbase[tid] = g;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FSP_ITEMS; j++)
+        if (gi0 + j < n) s_w[s_start[br[j] >> 16] + (br[j] & 0xFFFFu)] = w[j];
+    __syncthreads();
+    const uint32_t tile_n = min((uint32_t)FSP_TILE, n - base);
+    uint64_t *K = keys + (size_t)b * kstride;
+#pragma unroll
+    for (int r = 0; r < FSP_ITEMS; r++) {
+        const uint32_t p = r * FSP_NT + tid;
+        if (p < tile_n) {
+            const uint64_t ww = s_w[p];
+            const uint32_t d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
+            const uint32_t off = s_gbase[d] + (p - s_start[d]);
+            if (off < FS_CAP) K[(size_t)d * FS_CAP + off] = ww;
+        }
+    }
+}
+
+// rank base of every bucket (exclusive scan of the fills); a bucket past its slot flags the block
+__global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict__ fill, uint32_t *__restrict__ fbase,
+                                                      uint32_t *__restrict__ flag)
+{
+    __shared__ uint32_t s_tmp[FS_MAXNB / 64 + 1];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t f = fill[(size_t)b * FS_MAXNB + tid];
+    if (f > FS_CAP) atomicOr(&flag[b], 1u);
+    fbase[(size_t)b * FS_MAXNB + tid] = block_excl_add<FS_MAXNB>(f, s_tmp);
+}
+
+// ---------------------------------------------------------------------------
+// one workgroup sorts one bucket in LDS and writes its rows of the result
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(FSS_NT) void k_fs_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                    uint32_t nbl, const uint64_t *__restrict__ keys, size_t kstride,
+                                                    const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
+                                                    uint32_t *__restrict__ flag, uint8_t *__restrict__ bwt_out,
+                                                    size_t bwt_stride, int *__restrict__ d_index,
+                                                    uint32_t *__restrict__ sa_out, size_t sa_stride)
+{
+    __shared__ uint64_t s_w[FS_CAP];
+    __shared__ uint32_t s_cnt[FS_BINS + 1];
+    __shared__ uint32_t s_tmp[FSS_NT / 64 + 1];
+    __shared__ uint32_t s_deep;
+    const uint32_t b = blockIdx.y, bk = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_deep = flag[b];                            // (one read: another bucket may flag the block meanwhile)
+    __syncthreads();
+    if (s_deep) return;                                        // the block goes through the general sorter
+    const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
+    if (c == 0) return;
+    const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
+    const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+    const uint8_t *T = text + (size_t)b * stride;
+    uint64_t w[FSS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) {
+        const uint32_t i = r * FSS_NT + tid;
+        w[r] = i < c ? K[i] : ~0ull;
+    }
+    for (uint32_t i = tid; i < FS_BINS + 1; i += FSS_NT) s_cnt[i] = 0;
+    __syncthreads();
+    // 1. counting sort on the 12 bits below the bucket number (arrival order inside a bin: any order will do)
+    const uint32_t bshift = 64 - nbl - FS_BIN_BITS;
+    uint32_t rk[FSS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) {
+        const uint32_t i = r * FSS_NT + tid;
+        rk[r] = i < c ? atomicAdd(&s_cnt[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)], 1u) : 0u;
+    }
+    __syncthreads();
+    {
+        constexpr int PER = FS_BINS / FSS_NT;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { v[k] = s_cnt[tid * PER + k]; sum += v[k]; }
+        uint32_t run = block_excl_add<FSS_NT>(sum, s_tmp);
+#pragma unroll
+        for (int k = 0; k < PER; k++) { s_cnt[tid * PER + k] = run; run += v[k]; }
+        if (tid == FSS_NT - 1) s_cnt[FS_BINS] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) {
+        const uint32_t i = r * FSS_NT + tid;
+        if (i < c) s_w[s_cnt[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] = w[r];
+    }
+    __syncthreads();
+    // 2. order every bin by the full 36-bit code: each element counts the smaller ones of its bin.
+    //    Elements with equal codes form a group [gp, gp + gs): their relative order is not known yet.
+    uint32_t pos[FSS_ITEMS], grp[FSS_ITEMS];                   // grp = group start << 16 | group size
+    uint32_t tied = 0;
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) {
+        const uint32_t p = r * FSS_NT + tid;
+        pos[r] = 0; grp[r] = 0;
+        if (p < c) {
+            const uint64_t wv = s_w[p], key = wv >> 28;
+            const uint32_t bin = (uint32_t)(wv >> bshift) & (FS_BINS - 1);
+            const uint32_t gs = s_cnt[bin], ge = s_cnt[bin + 1];
+            if (ge - gs > FS_MAX_GROUP) { s_deep = 1; }
+            else {
+                uint32_t less = 0, eqb = 0, eqt = 0;
+                for (uint32_t q = gs; q < ge; q++) {
+                    const uint64_t kq = s_w[q] >> 28;
+                    less += kq < key; eqt += kq == key; eqb += (kq == key) & (q < p);
+                }
+                pos[r] = gs + less + eqb; grp[r] = ((gs + less) << 16) | eqt;
+                if (eqt > 1) tied |= 1u << r;
+            }
+            w[r] = wv;
+        }
+    }
+    __syncthreads();
+    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++)
+        if (r * FSS_NT + tid < c) s_w[pos[r]] = w[r];
+    // 3. groups of equal codes: replace the code by the next 4 text symbols (9 bits each: byte + 1, 0 past
+    //    the end) and rank inside the group, until every group is a singleton.  Equal codes do not certify
+    //    equal symbols, so the first round starts at depth 0.
+    for (uint32_t depth = 0; ; depth += 4) {
+        if (!__syncthreads_or((int)tied)) break;
+        if (depth >= FS_MAX_DEPTH) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+        const uint32_t act = tied;
+#pragma unroll
+        for (int r = 0; r < FSS_ITEMS; r++) {
+            if (act & (1u << r)) {
+                const uint32_t i0 = (uint32_t)((w[r] >> 8) & 0xFFFFFu) + depth;
+                uint64_t key = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) key = (key << 9) | (i0 + j < n ? (uint32_t)T[i0 + j] + 1u : 0u);
+                w[r] = (key << 28) | (w[r] & FS_LOW_MASK);
+                s_w[pos[r]] = w[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < FSS_ITEMS; r++) {
+            if (act & (1u << r)) {
+                const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, p = pos[r];
+                const uint64_t key = w[r] >> 28;
+                uint32_t less = 0, eqb = 0, eqt = 0;
+                for (uint32_t q = gp; q < gp + gs; q++) {
+                    const uint64_t kq = s_w[q] >> 28;
+                    less += kq < key; eqt += kq == key; eqb += (kq == key) & (q < p);
+                }
+                pos[r] = gp + less + eqb; grp[r] = ((gp + less) << 16) | eqt;
+                if (eqt == 1) tied &= ~(1u << r);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < FSS_ITEMS; r++)
+            if (act & (1u << r)) s_w[pos[r]] = w[r];
+    }
+    __syncthreads();
+    // 4. rows R0 .. R0 + c of the block's result
+    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
+    uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
+    const uint32_t head = O ? min(c, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u)) & 3u)) : 0u;
+    for (uint32_t p = tid; p < c; p += FSS_NT) {
+        const uint64_t wv = s_w[p];
+        const uint32_t idx = (uint32_t)(wv >> 8) & 0xFFFFFu;
+        if (SAo) SAo[p] = idx;
+        if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
+        if (O && (p < head || p >= head + ((c - head) & ~3u))) O[p] = (uint8_t)wv;
+    }
+    if (O) {
+        const uint32_t nq = (c - head) / 4;
+        for (uint32_t q = tid; q < nq; q += FSS_NT) {
+            const uint32_t p = head + 4 * q;
+            const uint32_t v = (uint32_t)(uint8_t)s_w[p] | ((uint32_t)(uint8_t)s_w[p + 1] << 8) |
+                               ((uint32_t)(uint8_t)s_w[p + 2] << 16) | ((uint32_t)(uint8_t)s_w[p + 3] << 24);
+            *reinterpret_cast<uint32_t *>(O + p) = v;
+        }
+    }
+}
+
+// blocks the fast path gave up on -> live counts for the general sorter
+__global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint32_t nblk, uint32_t *__restrict__ lcnt,
+                            uint32_t *__restrict__ nflag)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) {
+        const uint32_t f = flag[b] ? n : 0u;
+        lcnt[b] = f;
+        if (f) atomicAdd(nflag, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+#define GLC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk, SaScratch &s,
+                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out)
+{
+    const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
+    GLC_TRY(hipMemsetAsync(s.fs_hist, 0, (size_t)nblk * 256 * 4, st));
+    GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)nblk * FS_MAXNB * 4, st));
+    GLC_TRY(hipMemsetAsync(s.fs_flag, 0, (size_t)nblk * 4, st));
+    GLC_TRY(hipMemsetAsync(s.fs_nflag, 0, 4, st));
+    hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
+                       s.fs_hist);
+    hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab);
+    hipLaunchKernelGGL(k_fs_part, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
+                       nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag);
+    hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag);
+    hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
+                       s.fs_fill, s.fs_base, s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+    hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag);
+    return hipGetLastError();
+}
+
+} // namespace glc

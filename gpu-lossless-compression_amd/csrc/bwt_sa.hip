@@ -757,11 +757,11 @@ __global__ void k_refine_counts(const uint32_t *__restrict__ cnt, const uint32_t
 // switch from text refinement to prefix doubling: ranks of every suffix in the order
 // established so far.  Resolved suffixes: rank = own SA slot + 1 ...
 __global__ __launch_bounds__(256) void k_isa_init(const uint32_t *__restrict__ sa, uint32_t *__restrict__ isa,
-                                                  uint32_t n, uint32_t nmax)
+                                                  uint32_t n, uint32_t nmax, const uint32_t *__restrict__ cnt0)
 {
     const uint32_t b = blockIdx.y;
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j < n) isa[(size_t)b * nmax + sa[(size_t)b * nmax + j]] = j + 1;
+    if (j < live_count(cnt0, n, b)) isa[(size_t)b * nmax + sa[(size_t)b * nmax + j]] = j + 1;
 }
 
 // ... unresolved suffixes: rank = SA slot of their group head + 1; also rewrite their words
@@ -818,7 +818,19 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     const size_t ne = (size_t)nmax * rows;
     size_t total = 0;
     auto A = [&](void **p, size_t bytes) -> hipError_t { total += bytes; return hipMalloc(p, bytes); };
-    GLC_TRY(A((void **)&s.keyA, ne * 8)); GLC_TRY(A((void **)&s.keyB, ne * 8));
+    {   // keyA | keyB in one allocation: the bucket sorter uses it as [rows][buckets][FS_CAP]
+        s.fs_kstride = ((size_t)1 << fs_bucket_log2(nmax)) * FS_CAP;
+        const size_t words = s.fs_kstride * rows > 2 * ne ? s.fs_kstride * rows : 2 * ne;
+        GLC_TRY(A((void **)&s.keyA, words * 8));
+        s.keyB = s.keyA + ne;
+    }
+    GLC_TRY(A((void **)&s.fs_hist, (size_t)rows * 256 * 4));
+    GLC_TRY(A((void **)&s.fs_tab, (size_t)rows * 256 * 8));
+    GLC_TRY(A((void **)&s.fs_fill, (size_t)rows * FS_MAXNB * 4));
+    GLC_TRY(A((void **)&s.fs_base, (size_t)rows * FS_MAXNB * 4));
+    GLC_TRY(A((void **)&s.fs_flag, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.fs_lcnt, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.fs_nflag, 4));
     GLC_TRY(A((void **)&s.posA, ne * 4)); GLC_TRY(A((void **)&s.posB, ne * 4));
     GLC_TRY(A((void **)&s.isa, ne * 4));  GLC_TRY(A((void **)&s.sa, ne * 4));
     GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.rs_tiles * SA_MAXRADIX * 4));
@@ -831,14 +843,14 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.d_max_cnt, 16));
     GLC_TRY(A((void **)&s.rl_flag, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.rl_cnt, (size_t)rows * 4));
-    GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 16, hipHostMallocDefault));
+    GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 32, hipHostMallocDefault));
     s.bytes = total;
     return hipSuccess;
 }
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.keyB, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
+    void *ps[] = {s.keyA, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_nflag, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
@@ -930,21 +942,23 @@ static hipError_t refine_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, co
     return radix_sort(st, cur, alt, s.rl_cnt, 0, pp, tiles, nblk, s, (double)flagged_live);
 }
 
-hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
-                    SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out)
+// the general sorter; cnt0 (optional) = per-block element counts: n for the blocks to sort, 0 for the others
+static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                                   SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out,
+                                   const uint32_t *cnt0, uint32_t nsorted)
 {
-    if (n == 0 || n > s.nmax || n > MAX_BLOCK_ELEMS || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     uint32_t tiles = (n + SA_TILE - 1) / SA_TILE;
     uint64_t *cur = s.keyA, *alt = s.keyB;
-    double live_total = (double)n * nblk;
+    double live_total = (double)n * nsorted;
     GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 16, st));          // [2] doubles as the device error word of the sort
     {   // 41 key bits at [20, 61): 8+8+8+8+9
         PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 16, VAL_BITS + 24, VAL_BITS + 32}, {8, 8, 8, 8, 9}};
         const TextSrc src{text, text_stride, n};               // pass 0 and the histograms read the text itself
-        GLC_TRY(radix_sort(st, cur, alt, nullptr, n, pp, tiles, nblk, s, live_total, &src));
+        GLC_TRY(radix_sort(st, cur, alt, cnt0, n, pp, tiles, nblk, s, live_total, &src));
     }
 
-    uint32_t *cnt_cur = nullptr, *cnt_next = s.cntA, *cnt_spare = s.cntB;
+    const uint32_t *cnt_cur = cnt0;
+    uint32_t *cnt_next = s.cntA;
     uint32_t *pos_cur = nullptr, *pos_next = s.posA, *pos_spare = s.posB;
     uint32_t *hd_cur = nullptr, *hd_next = s.hdA, *hd_spare = s.hdB;
     // `depth` = symbols the current order is exact for; text refinement adds 3 per round,
@@ -985,8 +999,7 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         if (depth >= 2u * n + 16u) return hipErrorUnknown;        // cannot happen: depth >= n resolves everything
         // next round works on the compacted list that k_sa_rank<true> wrote into `alt`
         { uint64_t *x = cur; cur = alt; alt = x; }
-        if (cnt_cur == nullptr) { cnt_cur = cnt_next; cnt_next = cnt_spare; }
-        else { uint32_t *x = cnt_cur; cnt_cur = cnt_next; cnt_next = x; }
+        cnt_cur = cnt_next; cnt_next = (cnt_next == s.cntA) ? s.cntB : s.cntA;
         if (pos_cur == nullptr) { pos_cur = pos_next; pos_next = pos_spare; }
         else { uint32_t *x = pos_cur; pos_cur = pos_next; pos_next = x; }
         if (hd_cur == nullptr) { hd_cur = hd_next; hd_next = hd_spare; }
@@ -996,9 +1009,9 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         const uint32_t fill_blocks = (maxc + SA_THREADS * 4 - 1) / (SA_THREADS * 4);
         if (mode == MODE_TEXT) {
             // deep data (text, long repeats): 3 symbols per round is too slow -> prefix doubling
-            const bool deep = (rounds == 1 && live_total > 0.25 * (double)n * nblk) || text_rounds >= 3;
+            const bool deep = (rounds == 1 && live_total > 0.25 * (double)n * nsorted) || text_rounds >= 3;
             if (deep) {
-                hipLaunchKernelGGL(k_isa_init, dim3((n + 255) / 256, nblk), dim3(256), 0, st, s.sa, s.isa, n, s.nmax);
+                hipLaunchKernelGGL(k_isa_init, dim3((n + 255) / 256, nblk), dim3(256), 0, st, s.sa, s.isa, n, s.nmax, cnt0);
                 hipLaunchKernelGGL(k_isa_fix, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur, hd_cur,
                                    s.isa, s.nmax);
                 mode = MODE_ISA;
@@ -1021,6 +1034,30 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     }
     if (rounds_out) *rounds_out = rounds;
     return hipSuccess;
+}
+
+hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                    SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out)
+{
+    if (n == 0 || n > s.nmax || n > MAX_BLOCK_ELEMS || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
+    if (rounds_out) *rounds_out = 0;
+    s.last_flagged = nblk;
+    if (s.sorter != 0) {
+        const bool isa = s.force_isa;
+        s.force_isa = isa || s.sorter == 2;
+        const hipError_t e = sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, rounds_out,
+                                              nullptr, nblk);
+        s.force_isa = isa;
+        return e;
+    }
+    // bucket sorter first; the suffix array itself is only written when it is the result asked for
+    GLC_TRY(fs_build(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa));
+    GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 4, s.fs_nflag, 4, hipMemcpyDeviceToHost, st));
+    GLC_TRY(hipStreamSynchronize(st));
+    const uint32_t nflag = s.h_max_cnt[4];
+    s.last_flagged = nflag;
+    if (nflag == 0) return hipSuccess;
+    return sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, rounds_out, s.fs_lcnt, nflag);
 }
 
 // per-block exclusive scan of [tile][512] histograms (used by the decoder's LF construction)

@@ -480,6 +480,27 @@ CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable)
     return CUDPP_SUCCESS;
 }
 
+CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    if (mode < 0 || mode > 2) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    s->sorter = mode;
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcPlanLastSortStats(CUDPPHandle planHandle, unsigned int *flaggedBlocks)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !flaggedBlocks) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    *flaggedBlocks = s->last_flagged;
+    return CUDPP_SUCCESS;
+}
+
 CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);

@@ -13,6 +13,11 @@ constexpr uint32_t HUFF_SYMS       = 257;        // HUFF_NUM_CHARS (cudpp_global
 constexpr uint32_t HUFF_MAX_WORDS  = 1536;       // HUFF_CODE_BYTES (cudpp_globals.h:66)
 constexpr uint32_t MTF_CHUNK       = 4096;       // bytes of BWT output per wave in the MTF kernels
 
+// fast suffix sorter (bwt_bucket.hip): buckets of FS_AVG suffixes on average, FS_CAP words of slot each
+constexpr uint32_t FS_AVG   = 2048;
+constexpr uint32_t FS_CAP   = 4096;
+constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20
+
 // status bits accumulated on the device (PlanBase::d_status)
 constexpr uint32_t ST_BLOCK_OVERFLOW = 1u;       // a 4096-symbol block needs > 1536 words
 constexpr uint32_t ST_CAPACITY       = 2u;       // compressed stream would not fit its stride
@@ -39,6 +44,17 @@ struct SaScratch {
     uint32_t *h_max_cnt = nullptr;               // pinned [2]
     size_t    bytes = 0;
     bool      force_isa = false;                 // tests: skip text refinement, prefix doubling from round 1
+    // fast path (bwt_bucket.hip); its words live in keyA/keyB (one allocation, fs_kstride words per block)
+    int       sorter = 0;                        // 0 = bucket sorter, general sorter for the blocks it flags;
+                                                 // 1 = general sorter only; 2 = general sorter, prefix doubling only
+    size_t    fs_kstride = 0;
+    uint32_t *fs_hist = nullptr;                 // [rows][256] symbol counts
+    uint2    *fs_tab = nullptr;                  // [rows][256] {C, p} scaled to 2^32
+    uint32_t *fs_fill = nullptr, *fs_base = nullptr;   // [rows][FS_MAXNB] bucket fill / rank base
+    uint32_t *fs_flag = nullptr;                 // [rows] 1 = a bucket overflowed, 2 = deep (equal codes beyond the depth cap)
+    uint32_t *fs_lcnt = nullptr;                 // [rows] n for flagged blocks, 0 otherwise
+    uint32_t *fs_nflag = nullptr;                // [1] number of flagged blocks
+    uint32_t  last_flagged = 0;                  // blocks of the last sa_build that took the general sorter
     // optional live profile of the dominant kernel (k_rs_scatter<8>): HIP events on
     // the launch stream around every launch, accumulated across sa_build calls
     bool       prof = false;
@@ -59,6 +75,11 @@ void       sa_scratch_free(SaScratch &s);
 hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
                     SaScratch &s, uint8_t *bwt_out = nullptr, size_t bwt_stride = 0, int *d_index = nullptr,
                     int *rounds_out = nullptr);
+
+// the fast path alone (bwt_bucket.hip): enqueues only; flagged blocks are reported in s.fs_lcnt / s.fs_nflag
+hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk, SaScratch &s,
+                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out);
+uint32_t   fs_bucket_log2(uint32_t n);
 
 // copy SA to the cudppSuffixArray layout (out[0]=n, out[1..n]=SA)
 hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out);

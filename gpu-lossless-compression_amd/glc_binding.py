@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
@@ -93,6 +93,8 @@ def lib():
     L.glcPlanSetStream.argtypes = [sz, vp]
     L.glcPlanSynchronize.argtypes = [sz]
     L.glcPlanSetPipelining.argtypes = [sz, C.c_int]
+    L.glcPlanSetSorter.argtypes = [sz, C.c_int]
+    L.glcPlanLastSortStats.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
     L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
     L.glcPlanKernelProfile.argtypes = [sz, C.POINTER(C.c_double)]
@@ -221,6 +223,15 @@ class Plan:
     def set_pipelining(self, on=True):
         """overlap the suffix sort of a batch with the MTF + Huffman stages of the previous one"""
         _chk("glcPlanSetPipelining", lib().glcPlanSetPipelining(self.handle, 1 if on else 0))
+
+    def set_sorter(self, mode):
+        """0 bucket sorter + general sorter for flagged blocks (default), 1 general only, 2 general, prefix doubling only"""
+        _chk("glcPlanSetSorter", lib().glcPlanSetSorter(self.handle, int(mode)))
+
+    def last_flagged_blocks(self):
+        a = C.c_uint(0)
+        _chk("glcPlanLastSortStats", lib().glcPlanLastSortStats(self.handle, C.byref(a)))
+        return a.value
 
     def enable_timing(self, mode=1):
         """0 off, 1 stage events, 3 stage events + dominant-kernel events"""

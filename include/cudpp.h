@@ -206,6 +206,14 @@ CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4);
  * suffix)}; reading resets the accumulators. */
 CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3);
 
+/* Suffix sorter selection (plans of CUDPP_COMPRESS / CUDPP_BWT / CUDPP_SA).  0 (default): the bucket sorter
+ * (one bucketing pass + in-LDS sort), with the general sorter for the blocks it flags as too repetitive;
+ * 1: general sorter only; 2: general sorter, prefix doubling from the first refinement round.  All three
+ * produce the same bytes (the suffix array of a block is unique); the knob exists for tests and A/B timing. */
+CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode);
+/* number of blocks of the plan's last call that went through the general sorter */
+CUDPPResult glcPlanLastSortStats(CUDPPHandle planHandle, unsigned int *flaggedBlocks);
+
 /* Result collection: packs the strided per-block streams of a batched compress
  * back to back.  d_outOffsets has numBlocks+1 entries (word offsets; the last is
  * the total).  d_out must hold sum(d_compressedSize) words. */
