@@ -27,11 +27,14 @@
 //   k_fs_scan                 bucket fill -> rank base of every bucket, overflow -> flag
 //   k_fs_sort                 one workgroup per bucket: counting sort on 12 more bits with LDS atomics
 //                             (no stability needed: the index is not a tie-breaker), direct ranking inside
-//                             the tiny bins, equal codes refined 4 text symbols at a time in place;
-//                             writes BWT bytes (+ SA) straight to their final rows              8 B R + 1 B W
+//                             the tiny bins; writes BWT bytes (+ SA) straight to their final rows;
+//                             runs of equal codes go to a work list                             8 B R + 1 B W
+//   k_fs_ties                 one thread per member of such a run: rank by comparing the suffixes in the
+//                             text (0.4 % of the suffixes of a Zipf block)
 // = 19 B of HBM traffic per input byte (23 with the suffix array) where the 5-pass LSD sorter moves ~105.
 #include "glc_device.h"
 #include "glc_internal.h"
+#include <stdlib.h>
 
 namespace glc {
 
@@ -42,7 +45,6 @@ constexpr int      FSS_NT    = 512;                 // k_fs_sort: threads
 constexpr int      FSS_ITEMS = FS_CAP / FSS_NT;     // slots per thread
 constexpr uint32_t FS_BIN_BITS = 12, FS_BINS = 1u << FS_BIN_BITS;
 constexpr uint32_t FS_MAX_GROUP = 512;              // longest run of equal codes ranked by direct count
-constexpr uint32_t FS_MAX_DEPTH = 48;               // symbols compared before a block is declared deep
 constexpr uint64_t FS_LOW_MASK = (1ull << 28) - 1;  // [index : 20 | bwt : 8]
 
 uint32_t fs_bucket_log2(uint32_t n)
@@ -226,36 +228,39 @@ __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict
 }
 
 // ---------------------------------------------------------------------------
-// one workgroup sorts one bucket in LDS and writes its rows of the result
+// one workgroup sorts one bucket in LDS and writes its rows of the result.  Runs of equal codes (a few
+// per bucket on Zipf data) are not resolved here -- that needs the text, and a global-memory round trip on
+// the critical path of every workgroup cost more than the whole sort -- but appended to a work list that
+// k_fs_ties resolves with one thread per member afterwards.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(FSS_NT) void k_fs_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
-                                                    uint32_t nbl, const uint64_t *__restrict__ keys, size_t kstride,
-                                                    const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
-                                                    uint32_t *__restrict__ flag, uint8_t *__restrict__ bwt_out,
-                                                    size_t bwt_stride, int *__restrict__ d_index,
-                                                    uint32_t *__restrict__ sa_out, size_t sa_stride)
+__global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, const uint64_t *__restrict__ keys,
+                                                    size_t kstride, const uint32_t *__restrict__ fill,
+                                                    const uint32_t *__restrict__ fbase, uint32_t *__restrict__ flag,
+                                                    uint8_t *__restrict__ bwt_out, size_t bwt_stride,
+                                                    int *__restrict__ d_index, uint32_t *__restrict__ sa_out,
+                                                    size_t sa_stride, uint4 *__restrict__ wl, uint32_t wl_cap,
+                                                    uint32_t *__restrict__ wl_count, int stop)
 {
     __shared__ uint64_t s_w[FS_CAP];
     __shared__ uint32_t s_cnt[FS_BINS + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t s_bwt[FS_CAP];
     __shared__ uint32_t s_tmp[FSS_NT / 64 + 1];
-    __shared__ uint32_t s_deep;
+    __shared__ uint32_t s_deep, s_wl;
     const uint32_t b = blockIdx.y, bk = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) s_deep = flag[b];                            // (one read: another bucket may flag the block meanwhile)
-    __syncthreads();
-    if (s_deep) return;                                        // the block goes through the general sorter
+    if (tid == 0) { s_deep = flag[b]; s_wl = 0; }              // (one read: another bucket may flag the block meanwhile)
+    for (uint32_t i = tid; i < FS_BINS + 1; i += FSS_NT) s_cnt[i] = 0;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
-    if (c == 0) return;
     const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
     const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
-    const uint8_t *T = text + (size_t)b * stride;
     uint64_t w[FSS_ITEMS];
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
         const uint32_t i = r * FSS_NT + tid;
-        w[r] = i < c ? K[i] : ~0ull;
+        w[r] = (i < c && c <= FS_CAP) ? K[i] : ~0ull;
     }
-    for (uint32_t i = tid; i < FS_BINS + 1; i += FSS_NT) s_cnt[i] = 0;
     __syncthreads();
+    if (s_deep || c == 0) return;                              // flagged: the block goes through the general sorter
+    if (stop == 0) return;
     // 1. counting sort on the 12 bits below the bucket number (arrival order inside a bin: any order will do)
     const uint32_t bshift = 64 - nbl - FS_BIN_BITS;
     uint32_t rk[FSS_ITEMS];
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(const uint8_t *__restrict__ 
         rk[r] = i < c ? atomicAdd(&s_cnt[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)], 1u) : 0u;
     }
     __syncthreads();
+    if (stop == 1) { if (rk[0] == 77777) flag[b] = 1; return; }
     {
         constexpr int PER = FS_BINS / FSS_NT;
         uint32_t v[PER], sum = 0;
@@ -276,16 +282,19 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(const uint8_t *__restrict__ 
         if (tid == FSS_NT - 1) s_cnt[FS_BINS] = run;
     }
     __syncthreads();
+    if (stop == 2) { if (s_cnt[tid] == 77777) flag[b] = 1; return; }
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
         const uint32_t i = r * FSS_NT + tid;
         if (i < c) s_w[s_cnt[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] = w[r];
     }
     __syncthreads();
-    // 2. order every bin by the full 36-bit code: each element counts the smaller ones of its bin.
-    //    Elements with equal codes form a group [gp, gp + gs): their relative order is not known yet.
-    uint32_t pos[FSS_ITEMS], grp[FSS_ITEMS];                   // grp = group start << 16 | group size
-    uint32_t tied = 0;
+    if (stop == 3) { if (s_w[tid] == 77777) flag[b] = 1; return; }
+    // 2. final position = bin start + number of smaller codes in the bin.  Elements with equal codes form a
+    //    group [gp, gp + gs) whose internal order is not known yet.
+    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
+    uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
+    uint32_t pos[FSS_ITEMS], grp[FSS_ITEMS];                   // grp = group start << 16 | group size (0: not tied)
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
         const uint32_t p = r * FSS_NT + tid;
@@ -301,75 +310,129 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(const uint8_t *__restrict__ 
                     const uint64_t kq = s_w[q] >> 28;
                     less += kq < key; eqt += kq == key; eqb += (kq == key) & (q < p);
                 }
-                pos[r] = gs + less + eqb; grp[r] = ((gs + less) << 16) | eqt;
-                if (eqt > 1) tied |= 1u << r;
+                pos[r] = gs + less + eqb;
+                const uint32_t idx = (uint32_t)(wv >> 8) & 0xFFFFFu;
+                if (eqt > 1) grp[r] = ((gs + less) << 16) | eqt;
+                else {
+                    s_bwt[pos[r]] = (uint8_t)wv;
+                    if (SAo) SAo[pos[r]] = idx;
+                    if (idx == 0 && d_index) d_index[b] = (int)(R0 + pos[r]);
+                }
             }
             w[r] = wv;
         }
     }
-    __syncthreads();
+    __syncthreads();                                           // s_cnt (bin starts) is dead from here
     if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    if (stop == 4) { if (pos[0] == 77777) flag[b] = 1; return; }
+    // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup
+    //    (an atomic per group on a shared counter serialised the whole kernel: +2.4 ms per 256 blocks).
+    bool any = false;
 #pragma unroll
-    for (int r = 0; r < FSS_ITEMS; r++)
-        if (r * FSS_NT + tid < c) s_w[pos[r]] = w[r];
-    // 3. groups of equal codes: replace the code by the next 4 text symbols (9 bits each: byte + 1, 0 past
-    //    the end) and rank inside the group, until every group is a singleton.  Equal codes do not certify
-    //    equal symbols, so the first round starts at depth 0.
-    for (uint32_t depth = 0; ; depth += 4) {
-        if (!__syncthreads_or((int)tied)) break;
-        if (depth >= FS_MAX_DEPTH) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-        const uint32_t act = tied;
-#pragma unroll
-        for (int r = 0; r < FSS_ITEMS; r++) {
-            if (act & (1u << r)) {
-                const uint32_t i0 = (uint32_t)((w[r] >> 8) & 0xFFFFFu) + depth;
-                uint64_t key = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) key = (key << 9) | (i0 + j < n ? (uint32_t)T[i0 + j] + 1u : 0u);
-                w[r] = (key << 28) | (w[r] & FS_LOW_MASK);
-                s_w[pos[r]] = w[r];
-            }
+    for (int r = 0; r < FSS_ITEMS; r++) {
+        if (grp[r]) {
+            any = true;
+            const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu;
+            if (pos[r] == gp) s_cnt[gp] = atomicAdd(&s_wl, gs);
+        }
+    }
+    if (__syncthreads_or((int)any)) {
+        if (tid == 0) {
+            const uint32_t tot = s_wl;
+            uint32_t base = atomicAdd(&wl_count[b], tot);
+            if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
+            s_deep = base;
         }
         __syncthreads();
+        const uint32_t base = s_deep;
+        uint4 *WL = wl + (size_t)b * wl_cap;
+        if (base != 0xFFFFFFFFu) {
 #pragma unroll
-        for (int r = 0; r < FSS_ITEMS; r++) {
-            if (act & (1u << r)) {
-                const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, p = pos[r];
-                const uint64_t key = w[r] >> 28;
-                uint32_t less = 0, eqb = 0, eqt = 0;
-                for (uint32_t q = gp; q < gp + gs; q++) {
-                    const uint64_t kq = s_w[q] >> 28;
-                    less += kq < key; eqt += kq == key; eqb += (kq == key) & (q < p);
+            for (int r = 0; r < FSS_ITEMS; r++) {
+                if (grp[r]) {
+                    const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, slot0 = base + s_cnt[gp];
+                    WL[slot0 + (pos[r] - gp)] = make_uint4((uint32_t)(w[r] & FS_LOW_MASK), R0 + gp, slot0, gs);
                 }
-                pos[r] = gp + less + eqb; grp[r] = ((gp + less) << 16) | eqt;
-                if (eqt == 1) tied &= ~(1u << r);
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < FSS_ITEMS; r++)
-            if (act & (1u << r)) s_w[pos[r]] = w[r];
     }
-    __syncthreads();
-    // 4. rows R0 .. R0 + c of the block's result
-    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
-    uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
-    const uint32_t head = O ? min(c, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u)) & 3u)) : 0u;
-    for (uint32_t p = tid; p < c; p += FSS_NT) {
-        const uint64_t wv = s_w[p];
-        const uint32_t idx = (uint32_t)(wv >> 8) & 0xFFFFFu;
-        if (SAo) SAo[p] = idx;
-        if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
-        if (O && (p < head || p >= head + ((c - head) & ~3u))) O[p] = (uint8_t)wv;
-    }
+    if (stop == 5) return;
+    // 4. rows R0 .. R0 + c of the block's BWT (rows of tied groups are rewritten by k_fs_ties)
     if (O) {
+        const uint32_t head = min(c, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u)) & 3u));
         const uint32_t nq = (c - head) / 4;
+        if (tid < head) O[tid] = s_bwt[tid];
+        for (uint32_t p = head + 4 * nq + tid; p < c; p += FSS_NT) O[p] = s_bwt[p];
         for (uint32_t q = tid; q < nq; q += FSS_NT) {
             const uint32_t p = head + 4 * q;
-            const uint32_t v = (uint32_t)(uint8_t)s_w[p] | ((uint32_t)(uint8_t)s_w[p + 1] << 8) |
-                               ((uint32_t)(uint8_t)s_w[p + 2] << 16) | ((uint32_t)(uint8_t)s_w[p + 3] << 24);
+            const uint32_t v = (uint32_t)s_bwt[p] | ((uint32_t)s_bwt[p + 1] << 8) | ((uint32_t)s_bwt[p + 2] << 16) |
+                               ((uint32_t)s_bwt[p + 3] << 24);
             *reinterpret_cast<uint32_t *>(O + p) = v;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// groups of equal codes: one thread per member counts the members whose suffix is smaller (text comparison,
+// 8 bytes at a time) and writes its row.  Equal codes do not certify equal symbols: the comparison starts at
+// the first symbol.
+// ---------------------------------------------------------------------------
+constexpr uint32_t FS_LCP_CAP = 512;                           // a longer common prefix flags the block as deep
+
+__device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3) * 8;
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+    return ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
+}
+
+// suffix a < suffix b ?  (a != b; the shorter of two suffixes that agree to the end of one is the smaller)
+__device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep)
+{
+    uint32_t k = 0;
+    for (;;) {
+        const uint32_t m = max(a, b) + k;
+        if (m + 12 <= n) {
+            const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
+            if (va != vb) return va < vb;
+            k += 8;
+        } else {
+            if (a + k >= n) return true;
+            if (b + k >= n) return false;
+            const uint32_t ca = T[a + k], cb = T[b + k];
+            if (ca != cb) return ca < cb;
+            k++;
+        }
+        if (k > FS_LCP_CAP) { *deep = true; return false; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                 const uint4 *__restrict__ wl, uint32_t wl_cap,
+                                                 const uint32_t *__restrict__ wl_count, uint32_t *__restrict__ flag,
+                                                 uint8_t *__restrict__ bwt_out, size_t bwt_stride,
+                                                 int *__restrict__ d_index, uint32_t *__restrict__ sa_out, size_t sa_stride)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t total = wl_count[b];
+    if (total == 0 || total > wl_cap || flag[b]) return;       // (flags of this pass are all set before it starts)
+    const uint4 *WL = wl + (size_t)b * wl_cap;
+    const uint8_t *T = text + (size_t)b * stride;
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const uint4 me = WL[e];
+        const uint32_t gs = me.w, idx = me.x >> 8;
+        uint32_t rank = 0;
+        bool deep = false;
+        for (uint32_t f = me.z; f < me.z + gs && !deep; f++)
+            if (f != e) rank += fs_suffix_less(T, n, WL[f].x >> 8, idx, &deep) ? 1u : 0u;
+        if (deep) { atomicOr(&flag[b], 2u); continue; }
+        const uint32_t row = me.y + rank;
+        if (bwt_out) bwt_out[(size_t)b * bwt_stride + row] = (uint8_t)me.x;
+        if (sa_out) sa_out[(size_t)b * sa_stride + row] = idx;
+        if (idx == 0 && d_index) d_index[b] = (int)row;
     }
 }
 
@@ -394,18 +457,22 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out)
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
+    static const int fs_stop = getenv("GLC_FS_STOP") ? atoi(getenv("GLC_FS_STOP")) : 99;
     GLC_TRY(hipMemsetAsync(s.fs_hist, 0, (size_t)nblk * 256 * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)nblk * FS_MAXNB * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_flag, 0, (size_t)nblk * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_nflag, 0, 4, st));
+    GLC_TRY(hipMemsetAsync(s.fs_wlcnt, 0, (size_t)nblk * 4, st));
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
                        s.fs_hist);
     hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab);
     hipLaunchKernelGGL(k_fs_part, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
                        nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag);
     hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag);
-    hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.fs_base, s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+    hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, n, nbl, s.keyA, s.fs_kstride, s.fs_fill, s.fs_base,
+                       s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt, fs_stop);
+    hipLaunchKernelGGL(k_fs_ties, dim3(8, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
+                       s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag);
     return hipGetLastError();
 }

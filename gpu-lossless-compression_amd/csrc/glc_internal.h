@@ -54,6 +54,9 @@ struct SaScratch {
     uint32_t *fs_flag = nullptr;                 // [rows] 1 = a bucket overflowed, 2 = deep (equal codes beyond the depth cap)
     uint32_t *fs_lcnt = nullptr;                 // [rows] n for flagged blocks, 0 otherwise
     uint32_t *fs_nflag = nullptr;                // [1] number of flagged blocks
+    uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
+    uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
+    uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build that took the general sorter
     // optional live profile of the dominant kernel (k_rs_scatter<8>): HIP events on
     // the launch stream around every launch, accumulated across sa_build calls
