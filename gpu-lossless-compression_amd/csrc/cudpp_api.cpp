@@ -368,10 +368,10 @@ CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, co
     uint8_t *bwt = k ? p->dec.bwt2 : p->dec.bwt;
     if (p->dec_released_valid[k]) (void)hipStreamWaitEvent(st, p->ev_dec_released[k], 0);
     e = decode_stage_a(st, d_hist, d_encodeOffset, offsetStride, d_compressed, compressedStrideWords,
-                       (uint32_t)numElements, (uint32_t)numBlocks, p->dec, bwt);
+                       (uint32_t)numElements, (uint32_t)numBlocks, p->dec, bwt, p->d_status);
     (void)hipEventRecord(p->ev_dec_a[k], st);
     (void)hipStreamWaitEvent(p->side, p->ev_dec_a[k], 0);
-    if (e == hipSuccess) e = decode_stage_b(p->side, d_bwtIndex, bwt, d_out, (uint32_t)numElements, (uint32_t)numBlocks, p->dec);
+    if (e == hipSuccess) e = decode_stage_b(p->side, d_bwtIndex, bwt, d_out, (uint32_t)numElements, (uint32_t)numBlocks, p->dec, p->d_status);
     (void)hipEventRecord(p->ev_dec_released[k], p->side);
     p->dec_released_valid[k] = true;
     p->side_busy = true;

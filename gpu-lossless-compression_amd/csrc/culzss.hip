@@ -242,7 +242,10 @@ __global__ __launch_bounds__(256) void k_lzss_layout(const uint2 *__restrict__ m
     const uint32_t total = s_run;
     // aftercomp aborts when the bytes flushed BEFORE the last token iteration exceed
     // buf_length (gpu_compress.cu:492-497): everything but the last group of the last packet
-    const bool ok = (total - M[npk - 1].y) <= (uint32_t)buf_length;
+    // ... and (not in the reference, which then writes its trailer past the end of the caller's buffer,
+    // gpu_compress.cu:620-657, and whose container cannot tell a packed buffer of exactly BUFSIZE bytes from
+    // a raw one, deculzss.c:94-95): a packed form that is not SMALLER than the buffer is stored raw too
+    const bool ok = (total - M[npk - 1].y) <= (uint32_t)buf_length && total + 2 * npk + 6 < (uint32_t)buf_length;
     if (ok) {
         for (uint32_t i = tid; i < npk; i += 256) {           // packet sizes, big-endian u16 (:626-634)
             const uint32_t sz = M[i].x;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256) void k_lzss_gather(const uint8_t *__restrict__
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_lzss_decode(const uint8_t *__restrict__ packed, size_t pack_stride,
                                                     const int *__restrict__ sizes, int buf_length,
-                                                    uint8_t *__restrict__ out)
+                                                    uint8_t *__restrict__ out, int *__restrict__ d_err)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_in[LZ_STAGE + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_o[LZ_WIN + LZ_PCKT + 256];
@@ -302,8 +305,17 @@ __global__ __launch_bounds__(64) void k_lzss_decode(const uint8_t *__restrict__ 
             reinterpret_cast<uint4 *>(O)[i] = reinterpret_cast<const uint4 *>(P + (size_t)pk * LZ_PCKT)[i];
         return;
     }
+    // a stream that cannot hold its own trailer, or is longer than its slot, is corrupt: the reference
+    // trusts it (gpu_decompress.cu:257-294); here nothing outside the slot is read, the packet decodes to
+    // zeros and the error word is raised
+    if (clen < (int)(2 * npk + 6) || (size_t)clen > pack_stride) {
+        if (d_err && l == 0) atomicOr(d_err, 1);
+        for (uint32_t i = l; i < LZ_PCKT / 16; i += 64) reinterpret_cast<uint4 *>(O)[i] = make_uint4(0, 0, 0, 0);
+        return;
+    }
     // trailer: npk big-endian u16 sizes, u32 length, u16 pad (gpu_decompress.cu:257-294)
-    const uint8_t *tr = P + clen - 6 - 2 * npk;
+    const uint32_t body = (uint32_t)clen - 6 - 2 * npk;
+    const uint8_t *tr = P + body;
     uint32_t start = 0;
     {   // prefix of the packet sizes: all byte loads in flight together
         uint32_t hi[4], lo[4];
@@ -319,6 +331,10 @@ __global__ __launch_bounds__(64) void k_lzss_decode(const uint8_t *__restrict__ 
     start = wave_sum(start);
     uint32_t size = ((uint32_t)tr[2 * pk] << 8) | tr[2 * pk + 1];
     if (size > LZ_STAGE) size = LZ_STAGE;
+    if (start > body || start + size > body) {                 // packet sizes that do not add up: stay inside the body
+        if (d_err && l == 0) atomicOr(d_err, 1);
+        start = min(start, body); size = min(size, body - start);
+    }
     // the packet's bytes: 16-byte loads from the aligned address below `start`, all in flight, then LDS;
     // s_in[sh + i] = stream byte i (a byte-per-trip copy loop costs one memory latency per 64 bytes)
     const uint8_t *src = P + start;
@@ -476,12 +492,12 @@ hipError_t lzss_pack(hipStream_t st, const uint8_t *d_cand, int buf_length, int 
 }
 
 hipError_t lzss_decode(hipStream_t st, const uint8_t *d_packed, const int *d_sizes, int buf_length, int nbuf,
-                       uint8_t *d_out)
+                       uint8_t *d_out, int *d_err)
 {
     if (buf_length <= 0 || buf_length % LZ_PCKT || nbuf <= 0) return hipErrorInvalidValue;
     const uint32_t npk = buf_length / LZ_PCKT;
     hipLaunchKernelGGL(k_lzss_decode, dim3(npk, nbuf), dim3(64), 0, st, d_packed, lzss_pack_stride(buf_length),
-                       d_sizes, buf_length, d_out);
+                       d_sizes, buf_length, d_out, d_err);
     return hipGetLastError();
 }
 

@@ -61,7 +61,8 @@ bool ok(hipError_t e, const char *what)
 void init_locked()
 {
     if (g.inited) return;
-    (void)hipSetDevice(0);                       // gpu_compress.cu:395
+    // the reference pins device 0 (gpu_compress.cu:395); here the streams belong to whatever device is current
+    // in the calling thread, so one process per GPU (rank r on device r) works without HIP_VISIBLE_DEVICES
     for (auto &s : g.slot) {
         (void)hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
         (void)hipEventCreate(&s.e0);
@@ -246,17 +247,21 @@ int decompression_kernel_wrapper(unsigned char *buffer, int buf_length, int *dec
         g.dd_in = g.dd_out = nullptr; g.dd_size = nullptr; g.dd_cap = 0;
         if (!ok(hipMalloc((void **)&g.dd_in, lzss_pack_stride(orig)), "decode in")) return 0;
         if (!ok(hipMalloc((void **)&g.dd_out, (size_t)orig), "decode out")) return 0;
-        if (!ok(hipMalloc((void **)&g.dd_size, sizeof(int)), "decode size")) return 0;
+        if (!ok(hipMalloc((void **)&g.dd_size, 2 * sizeof(int)), "decode size")) return 0;   // {size, error word}
         g.dd_cap = orig;
     }
     if ((size_t)buf_length > lzss_pack_stride(orig)) return 0;
     hipStream_t st = g.slot[NSLOTS].stream;
+    int hdr[2] = {buf_length, 0}, err = 0;
     bool good = ok(hipMemcpyAsync(g.dd_in, buffer, (size_t)buf_length, hipMemcpyHostToDevice, st), "H2D")
-             && ok(hipMemcpyAsync(g.dd_size, &buf_length, sizeof(int), hipMemcpyHostToDevice, st), "H2D size")
-             && ok(hipStreamSynchronize(st), "sync")       // &buf_length is a stack variable
-             && ok(lzss_decode(st, g.dd_in, g.dd_size, orig, 1, g.dd_out), "decode")
-             && ok(hipMemcpyAsync(buffer, g.dd_out, (size_t)(orig - pad), hipMemcpyDeviceToHost, st), "D2H")
+             && ok(hipMemcpyAsync(g.dd_size, hdr, sizeof hdr, hipMemcpyHostToDevice, st), "H2D size")
+             && ok(hipStreamSynchronize(st), "sync")       // hdr is a stack variable
+             && ok(lzss_decode(st, g.dd_in, g.dd_size, orig, 1, g.dd_out, g.dd_size + 1), "decode")
+             && ok(hipMemcpyAsync(&err, g.dd_size + 1, sizeof(int), hipMemcpyDeviceToHost, st), "D2H err")
              && ok(hipStreamSynchronize(st), "sync");
+    if (!good || err) return 0;                             // malformed stream: nothing is written back
+    good = ok(hipMemcpyAsync(buffer, g.dd_out, (size_t)(orig - pad), hipMemcpyDeviceToHost, st), "D2H")
+        && ok(hipStreamSynchronize(st), "sync");
     if (!good) return 0;
     *decomp_length = orig - pad;
     return 1;
@@ -371,7 +376,7 @@ constexpr int GROUP = 16;                       // buffers per in-flight group
 struct Group {
     hipStream_t st = nullptr;
     uint8_t *d_in = nullptr, *d_packed = nullptr, *h_in = nullptr, *h_packed = nullptr;
-    int *d_sizes = nullptr, *h_sizes = nullptr;
+    int *d_sizes = nullptr, *h_sizes = nullptr; // GROUP sizes + one error word
     void *d_work = nullptr;
     uint8_t *d_out = nullptr, *h_out = nullptr;  // decode side
     int nbuf = 0;
@@ -383,9 +388,9 @@ bool group_alloc(Group &g, bool decode)
     const size_t stride = lzss_pack_stride(CBUF);
     if (!ok(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking), "group stream")) return false;
     if (!ok(hipMalloc((void **)&g.d_packed, stride * GROUP), "group packed")) return false;
-    if (!ok(hipMalloc((void **)&g.d_sizes, sizeof(int) * GROUP), "group sizes")) return false;
+    if (!ok(hipMalloc((void **)&g.d_sizes, sizeof(int) * (GROUP + 1)), "group sizes")) return false;
     if (!ok(hipHostMalloc((void **)&g.h_packed, stride * GROUP, hipHostMallocDefault), "group h_packed")) return false;
-    if (!ok(hipHostMalloc((void **)&g.h_sizes, sizeof(int) * GROUP, hipHostMallocDefault), "group h_sizes")) return false;
+    if (!ok(hipHostMalloc((void **)&g.h_sizes, sizeof(int) * (GROUP + 1), hipHostMallocDefault), "group h_sizes")) return false;
     if (!decode) {
         if (!ok(hipMalloc((void **)&g.d_in, (size_t)CBUF * GROUP), "group in")) return false;
         if (!ok(hipHostMalloc((void **)&g.h_in, (size_t)CBUF * GROUP, hipHostMallocDefault), "group h_in")) return false;
@@ -451,8 +456,11 @@ int culzss_container_compress(const unsigned char *in, unsigned long long len, u
     auto collect = [&](Group &G) {
         good = good && ok(hipStreamSynchronize(G.st), "sync");
         for (int i = 0; good && i < G.nbuf; i++) {
-            const int sz = G.h_sizes[i];
+            int sz = G.h_sizes[i];
+            if (sz >= CBUF) sz = 0;                                           // never packed to >= BUFSIZE: a payload of exactly
+                                                                              // BUFSIZE bytes MEANS raw (deculzss.c:94-95)
             const size_t bytes = sz > 0 ? (size_t)sz : (size_t)CBUF;          // 0 => stored raw (culzss.c:241-242)
+            if (wpos + bytes > out_cap || cum + bytes > 0xFFFFFFFFull) { good = false; break; }   // u32 offsets: format limit
             memcpy(out + wpos, sz > 0 ? G.h_packed + (size_t)i * stride : G.h_in + (size_t)i * CBUF, bytes);
             wpos += bytes; cum += bytes;
             const uint32_t c32 = (uint32_t)cum;
@@ -498,17 +506,28 @@ int culzss_container_decompress(const unsigned char *in, unsigned long long len,
         for (int i = 0; good && i < G.nbuf; i++) {
             const size_t a = cumat(first + i), b = cumat(first + i + 1);
             const size_t sz = b - a;
-            if (b < a || sz > stride || payload + b > len) { good = false; break; }
-            memcpy(G.h_packed + (size_t)i * stride, in + payload + a, sz);
+            if (b < a || sz > (size_t)CBUF || payload + b > len) { good = false; break; }
+            const uint8_t *src = in + payload + a;
+            if (sz != (size_t)CBUF) {                                          // packed: must hold its trailer, and the trailer
+                constexpr size_t TR = 2 * (CBUF / GLC_LZSS_PACKET) + 6;        // must describe a 1 MiB buffer without padding
+                if (sz < TR) { good = false; break; }
+                const uint32_t orig = ((uint32_t)src[sz - 6] << 24) | ((uint32_t)src[sz - 5] << 16) |
+                                      ((uint32_t)src[sz - 4] << 8) | (uint32_t)src[sz - 3];
+                if (orig != (uint32_t)CBUF || src[sz - 2] || src[sz - 1]) { good = false; break; }
+            }
+            memcpy(G.h_packed + (size_t)i * stride, src, sz);
             G.h_sizes[i] = (sz == (size_t)CBUF) ? 0 : (int)sz;             // raw buffers: deculzss.c:94-95
         }
+        G.h_sizes[GROUP] = 0;                                              // error word
         good = good && ok(hipMemcpyAsync(G.d_packed, G.h_packed, stride * G.nbuf, hipMemcpyHostToDevice, G.st), "H2D")
-            && ok(hipMemcpyAsync(G.d_sizes, G.h_sizes, sizeof(int) * G.nbuf, hipMemcpyHostToDevice, G.st), "H2D sizes")
-            && ok(lzss_decode(G.st, G.d_packed, G.d_sizes, CBUF, G.nbuf, G.d_out), "decode")
+            && ok(hipMemcpyAsync(G.d_sizes, G.h_sizes, sizeof(int) * (GROUP + 1), hipMemcpyHostToDevice, G.st), "H2D sizes")
+            && ok(lzss_decode(G.st, G.d_packed, G.d_sizes, CBUF, G.nbuf, G.d_out, G.d_sizes + GROUP), "decode")
+            && ok(hipMemcpyAsync(G.h_sizes + GROUP, G.d_sizes + GROUP, sizeof(int), hipMemcpyDeviceToHost, G.st), "D2H err")
             && ok(hipMemcpyAsync(G.h_out, G.d_out, (size_t)G.nbuf * CBUF, hipMemcpyDeviceToHost, G.st), "D2H");
     };
     auto collect = [&](Group &G) {
         good = good && ok(hipStreamSynchronize(G.st), "sync");
+        if (good && G.h_sizes[GROUP]) good = false;                        // a packet table that does not add up
         for (int i = 0; good && i < G.nbuf; i++) {
             const size_t off = (G.first + i) * (size_t)CBUF;
             const size_t take = std::min((size_t)CBUF, (size_t)total - off);  // last buffer loses the padding (deculzss.c:156-159)
@@ -535,9 +554,9 @@ static int slurp(const char *path, unsigned char **data, unsigned long long *len
 {
     FILE *f = fopen(path, "rb");
     if (!f) return 0;
-    fseek(f, 0, SEEK_END);
+    if (fseek(f, 0, SEEK_END) != 0) { fclose(f); return 0; }          // pipes, FIFOs, directories: not seekable
     const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
+    if (sz < 0 || fseek(f, 0, SEEK_SET) != 0) { fclose(f); return 0; }
     unsigned char *p = (unsigned char *)malloc(sz > 0 ? (size_t)sz : 1);
     if (!p) { fclose(f); return 0; }
     const size_t got = fread(p, 1, (size_t)sz, f);

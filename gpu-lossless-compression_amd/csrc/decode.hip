@@ -140,7 +140,8 @@ __global__ __launch_bounds__(DH_WAVES * 64) void k_dec_huff(const uint32_t *__re
                                                             const uint32_t *__restrict__ offsets, size_t offset_stride,
                                                             const uint32_t *__restrict__ lut,
                                                             const uint32_t *__restrict__ nodes, uint32_t n,
-                                                            uint8_t *__restrict__ mtf, size_t mtf_stride)
+                                                            uint8_t *__restrict__ mtf, size_t mtf_stride,
+                                                            uint32_t *__restrict__ d_status)
 {
     __shared__ uint16_t s_lut[1 << DEC_LUT_BITS];
     __shared__ uint32_t s_nodes[HUFF_NODES];
@@ -158,8 +159,15 @@ __global__ __launch_bounds__(DH_WAVES * 64) void k_dec_huff(const uint32_t *__re
     const uint32_t sub = blockIdx.x * DH_WAVES + wv;
     if (sub >= nsub) return;
     const uint32_t lo = sub * HUFF_BLOCK, cnt = min((uint32_t)HUFF_BLOCK, n - lo);
-    const uint32_t *w = comp + (size_t)b * comp_stride + offsets[(size_t)b * offset_stride + sub];
-    const uint32_t nwords = min(w[0], (uint32_t)HUFF_MAX_WORDS);
+    // offsets and lengths come from the stream: stay inside the block's slot whatever they say
+    uint32_t off = offsets[(size_t)b * offset_stride + sub];
+    if ((size_t)off + 1 > comp_stride) { off = 0; if (d_status && l == 0) atomicOr(d_status, ST_CORRUPT); }
+    const uint32_t *w = comp + (size_t)b * comp_stride + off;
+    uint32_t nwords = w[0];
+    if (nwords > HUFF_MAX_WORDS || (size_t)off + 1 + nwords > comp_stride) {
+        nwords = (uint32_t)min((size_t)min(nwords, (uint32_t)HUFF_MAX_WORDS), comp_stride - off - 1);
+        if (d_status && l == 0) atomicOr(d_status, ST_CORRUPT);
+    }
     w++;
     const uint32_t S = max(1u, (nwords + 63) / 64), P = S | 1u;
     uint32_t *sw = s_words[wv];
@@ -376,7 +384,8 @@ __device__ __forceinline__ uint32_t row_symbol(const uint8_t *__restrict__ B, ui
 
 __global__ __launch_bounds__(256) void k_ibwt_hist(const uint8_t *__restrict__ bwt, size_t bwt_stride,
                                                    const int *__restrict__ d_index, uint32_t n,
-                                                   uint32_t *__restrict__ tile_hist, uint32_t max_tiles)
+                                                   uint32_t *__restrict__ tile_hist, uint32_t max_tiles,
+                                                   uint32_t *__restrict__ d_status)
 {
     __shared__ uint32_t s_h[4][512];
     const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
@@ -385,7 +394,8 @@ __global__ __launch_bounds__(256) void k_ibwt_hist(const uint8_t *__restrict__ b
     for (uint32_t i = tid; i < 4 * 512; i += 256) (&s_h[0][0])[i] = 0;
     __syncthreads();
     const uint8_t *B = bwt + (size_t)b * bwt_stride;
-    const uint32_t index = (uint32_t)d_index[b];
+    uint32_t index = (uint32_t)d_index[b];
+    if (index >= n) { index = n - 1; if (d_status && t == 0 && tid == 0) atomicOr(d_status, ST_CORRUPT); }   // row index from the stream
     uint32_t sy[LF_TILE / 256];
 #pragma unroll
     for (int k = 0; k < LF_TILE / 256; k++) {
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(256) void k_ibwt_lf(const uint8_t *__restrict__ bwt
     for (uint32_t i = tid; i < 4 * 512; i += 256) (&s_wc[0][0])[i] = 0;
     __syncthreads();
     const uint8_t *B = bwt + (size_t)b * bwt_stride;
-    const uint32_t index = (uint32_t)d_index[b];
+    const uint32_t index = min((uint32_t)d_index[b], n - 1);
     uint32_t sy[LF_TILE / 256], rk[LF_TILE / 256];
 #pragma unroll
     for (int k = 0; k < LF_TILE / 256; k++) {                 // loads first: the wave barriers below pin them
@@ -655,14 +665,14 @@ void decode_scratch_free(DecodeScratch &s)
 // (glcPlanSetPipelining): A is LDS/VALU work, B is a memory-latency-bound pointer chase.
 hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t *d_offsets, size_t offset_stride,
                           const uint32_t *d_comp, size_t comp_stride_words, uint32_t n, uint32_t nblk, DecodeScratch &s,
-                          uint8_t *bwt)
+                          uint8_t *bwt, uint32_t *d_status)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
     hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes);
     hipLaunchKernelGGL(k_dec_huff, dim3((nsub + DH_WAVES - 1) / DH_WAVES, nblk), dim3(DH_WAVES * 64), 0, st, d_comp, comp_stride_words,
-                       d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax);
+                       d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
     hipLaunchKernelGGL(k_imtf_pos, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
                        s.max_chunks, bwt, (size_t)s.nmax);
     hipLaunchKernelGGL(k_imtf_scan, dim3(nblk), dim3(64), 0, st, s.ilists, n, s.max_chunks);
@@ -672,13 +682,13 @@ hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t
 }
 
 hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t *bwt, uint8_t *d_out, uint32_t n,
-                          uint32_t nblk, DecodeScratch &s)
+                          uint32_t nblk, DecodeScratch &s, uint32_t *d_status)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t rows = n + 1, tiles = (rows + LF_TILE - 1) / LF_TILE, nsplit = (rows + SPLIT - 1) / SPLIT;
     const size_t lf_stride = (size_t)s.nmax + 4;
     hipLaunchKernelGGL(k_ibwt_hist, dim3(tiles, nblk), dim3(256), 0, st, bwt, (size_t)s.nmax, d_bwt_index, n,
-                       s.tile_hist, s.max_tiles);
+                       s.tile_hist, s.max_tiles, d_status);
     GLC_TRY(tile_hist_scan9(st, s.tile_hist, rows, s.digit_base, s.max_tiles, nblk, LF_TILE));
     hipLaunchKernelGGL(k_ibwt_lf, dim3(tiles, nblk), dim3(256), 0, st, bwt, (size_t)s.nmax, d_bwt_index, n,
                        s.tile_hist, s.digit_base, s.max_tiles, s.lf, lf_stride);
@@ -694,10 +704,10 @@ hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t 
 
 hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist, const uint32_t *d_offsets,
                          size_t offset_stride, const uint32_t *d_comp, size_t comp_stride_words, uint8_t *d_out,
-                         uint32_t n, uint32_t nblk, DecodeScratch &s, MtfScratch & /*ms*/, uint32_t * /*d_status*/)
+                         uint32_t n, uint32_t nblk, DecodeScratch &s, MtfScratch & /*ms*/, uint32_t *d_status)
 {
-    GLC_TRY(decode_stage_a(st, d_hist, d_offsets, offset_stride, d_comp, comp_stride_words, n, nblk, s, s.bwt));
-    return decode_stage_b(st, d_bwt_index, s.bwt, d_out, n, nblk, s);
+    GLC_TRY(decode_stage_a(st, d_hist, d_offsets, offset_stride, d_comp, comp_stride_words, n, nblk, s, s.bwt, d_status));
+    return decode_stage_b(st, d_bwt_index, s.bwt, d_out, n, nblk, s, d_status);
 }
 
 } // namespace glc

@@ -21,6 +21,7 @@ constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^2
 // status bits accumulated on the device (PlanBase::d_status)
 constexpr uint32_t ST_BLOCK_OVERFLOW = 1u;       // a 4096-symbol block needs > 1536 words
 constexpr uint32_t ST_CAPACITY       = 2u;       // compressed stream would not fit its stride
+constexpr uint32_t ST_CORRUPT        = 4u;       // decoder: an offset, length or row index of the stream is out of range
 
 // ---------------------------------------------------------------------------
 // suffix array scratch: everything for `rows` blocks of up to nmax elements
@@ -155,9 +156,9 @@ hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows);
 void       decode_scratch_free(DecodeScratch &s);
 hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t *d_offsets, size_t offset_stride,
                           const uint32_t *d_comp, size_t comp_stride_words, uint32_t n, uint32_t nblk, DecodeScratch &s,
-                          uint8_t *bwt);
+                          uint8_t *bwt, uint32_t *d_status);
 hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t *bwt, uint8_t *d_out, uint32_t n,
-                          uint32_t nblk, DecodeScratch &s);
+                          uint32_t nblk, DecodeScratch &s, uint32_t *d_status);
 hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist,
                          const uint32_t *d_offsets, size_t offset_stride, const uint32_t *d_comp,
                          size_t comp_stride_words, uint8_t *d_out, uint32_t n, uint32_t nblk,

@@ -86,7 +86,15 @@ int culzss_decompress(const unsigned char *in, int len, unsigned char *out, int 
  * form of 1 MiB buffer i, or the raw 1 MiB when packing took more (size == 1 MiB,
  * deculzss.c:94-95).  Inputs shorter than 1 MiB are refused like main.c:228-232.
  * The last partial buffer is zero-filled (the reference leaves stale ring-slot
- * bytes there, main.c:122-130).  All return 1 on success, 0 on failure. */
+ * bytes there, main.c:122-130).  All return 1 on success, 0 on failure.
+ * Two more deliberate differences, both format-compatible: (1) a buffer whose packed form incl. trailer
+ * is not SMALLER than 1 MiB is stored raw (aftercomp only checks the bytes flushed before the last token
+ * group, gpu_compress.cu:492-497, so the reference can produce up to 1 MiB + 535 bytes, written past the end
+ * of its slot, and exactly 1 MiB, which deculzss.c:94-95 then reads back as raw); the same rule applies to
+ * culzss_compress / aftercompression_wrapper / glcLzssEncodeDevice (size 0 = store raw).  (2) Offsets are
+ * u32: a container whose payloads exceed 4 GiB - 1 is refused (return 0) instead of written with wrapped
+ * offsets.  The decoder validates what it reads (payload sizes, trailers, packet size tables) and fails
+ * rather than reading outside the stream. */
 unsigned long long culzss_container_bound(unsigned long long len);
 int culzss_container_compress(const unsigned char *in, unsigned long long len, unsigned char *out,
                               unsigned long long out_cap, unsigned long long *out_len);

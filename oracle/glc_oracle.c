@@ -570,7 +570,9 @@ ORC_API int orc_lzss_container_compress(const uint8_t *in, uint64_t len, uint8_t
         memset(buf, 0, LZ_BUF); memcpy(buf, in + off, take);
         orc_lzss_candidates(buf, LZ_BUF, cand);
         int n = 0;
-        if (orc_lzss_pack(cand, LZ_BUF, pk, &n)) { memcpy(out + w, pk, (size_t)n); w += (uint64_t)n; cum += (uint64_t)n; }
+        /* a packed form of >= BUFSIZE bytes is stored raw: the reference would write it past the end of its
+         * 1 MiB slot, and a payload of exactly BUFSIZE bytes is what marks a raw buffer (deculzss.c:94-95) */
+        if (orc_lzss_pack(cand, LZ_BUF, pk, &n) && n < LZ_BUF) { memcpy(out + w, pk, (size_t)n); w += (uint64_t)n; cum += (uint64_t)n; }
         else { memcpy(out + w, buf, LZ_BUF); w += LZ_BUF; cum += LZ_BUF; }
         uint32_t c32 = (uint32_t)cum; memcpy(out + 8 + 4ull * i, &c32, 4);
     }

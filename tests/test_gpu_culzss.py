@@ -58,7 +58,7 @@ def test_device_encode_matches_oracle(glc, cuda, name):
     assert np.array_equal(cand, want_cand), name + " candidates " + _first_diff(cand, want_cand)
     want_packed = O.lzss_pack(want_cand, n)
     size = int(d_size.item())
-    if want_packed is None:
+    if want_packed is None or want_packed.size >= n:               # (>= n: see test_packed_form_not_smaller_than_the_buffer)
         assert size == 0, "oracle says store-raw, gpu packed %d bytes" % size
         assert np.array_equal(d_packed.cpu().numpy()[:n], x)          # slot keeps the input
     else:
@@ -219,6 +219,69 @@ def test_container_many_buffers(glc, cuda):
         want = O.lzss_pack(O.lzss_candidates(blk), MiB)
         got = out[8 + 4 * 41 + cum[i]: 8 + 4 * 41 + cum[i + 1]]
         assert np.array_equal(got, want), "buffer %d" % i
+
+
+@pytest.mark.parametrize("run", [118685, 119175])
+def test_packed_form_not_smaller_than_the_buffer(glc, cuda, run):
+    """aftercomp only gives up when the bytes flushed BEFORE the last group outgrow the buffer
+    (gpu_compress.cu:492-497), so the packed form incl. trailer can reach BUFSIZE + 535 bytes: the reference
+    then writes past its 1 MiB slot, and a payload of exactly BUFSIZE bytes is read back as raw
+    (deculzss.c:94-95).  Both inputs (a run of 'A' followed by random bytes: 1 049 103 and exactly 1 048 576
+    packed bytes by the reference's rules) must be stored raw here and survive the container round trip."""
+    L = glc.lib()
+    x = np.concatenate([np.full(run, 65, dtype=np.uint8),
+                        np.random.default_rng(20260928).integers(0, 256, MiB, dtype=np.uint8)[: MiB - run]])
+    ref_rule = O.lzss_pack(O.lzss_candidates(x), MiB)
+    assert ref_rule is not None and ref_rule.size == {118685: 1049103, 119175: MiB}[run]   # the reference's rule lets it pass
+    out = np.zeros(L.glcLzssPackStride(MiB), dtype=np.uint8)
+    n = C.c_int(0)
+    assert L.culzss_compress(x.ctypes.data, MiB, out.ctypes.data, C.byref(n)) == 2
+    assert n.value == MiB and np.array_equal(out[:MiB], x)
+    y = np.concatenate([datagen.log_bytes(MiB, seed=3), x])
+    cap = L.culzss_container_bound(y.size)
+    cont = np.zeros(cap, dtype=np.uint8)
+    m = C.c_ulonglong(0)
+    assert L.culzss_container_compress(y.ctypes.data, y.size, cont.ctypes.data, cap, C.byref(m)) == 1
+    assert m.value <= cap
+    got = cont[: m.value]
+    assert np.array_equal(got, O.lzss_container_compress(y))
+    back = np.zeros(2 * MiB, dtype=np.uint8)
+    k = C.c_ulonglong(0)
+    assert L.culzss_container_decompress(got.ctypes.data, got.size, back.ctypes.data, back.size, C.byref(k)) == 1
+    assert k.value == y.size and np.array_equal(back, y)
+
+
+def test_malformed_streams_are_rejected(glc, cuda):
+    """the decoder must not trust the stream: a payload too short for its trailer, a trailer that names another
+    buffer length, and packet sizes that run past the body all fail cleanly (no out-of-range device reads)"""
+    L = glc.lib()
+    x = datagen.log_bytes(2 * MiB, seed=41)
+    cap = L.culzss_container_bound(x.size)
+    cont = np.zeros(cap, dtype=np.uint8)
+    m = C.c_ulonglong(0)
+    assert L.culzss_container_compress(x.ctypes.data, x.size, cont.ctypes.data, cap, C.byref(m)) == 1
+    good = cont[: m.value].copy()
+    back = np.zeros(2 * MiB, dtype=np.uint8)
+    k = C.c_ulonglong(0)
+    cum = good[8:16].view(np.uint32).copy()
+    # (a) first payload claims 100 bytes
+    bad = good.copy(); bad[8:12].view(np.uint32)[0] = 100
+    assert L.culzss_container_decompress(bad.ctypes.data, bad.size, back.ctypes.data, back.size, C.byref(k)) == 0
+    # (b) trailer of payload 0 names a 2 MiB buffer
+    bad = good.copy(); bad[16 + cum[0] - 6] = 0; bad[16 + cum[0] - 5] = 0x20
+    assert L.culzss_container_decompress(bad.ctypes.data, bad.size, back.ctypes.data, back.size, C.byref(k)) == 0
+    # (c) packet size table of payload 0 sums to far more than the body
+    bad = good.copy(); tr = 16 + cum[0] - 6 - 512
+    bad[tr:tr + 512] = 0xFF
+    assert L.culzss_container_decompress(bad.ctypes.data, bad.size, back.ctypes.data, back.size, C.byref(k)) == 0
+    # the wrapper ABI on the same corrupted payload
+    buf = np.zeros(L.glcLzssPackStride(MiB), dtype=np.uint8)
+    buf[: cum[0]] = bad[16:16 + cum[0]]
+    dl = C.c_int(0)
+    assert L.decompression_kernel_wrapper(buf.ctypes.data, int(cum[0]), C.byref(dl), 0, 1, 1) == 0
+    # and the intact container still decodes
+    assert L.culzss_container_decompress(good.ctypes.data, good.size, back.ctypes.data, back.size, C.byref(k)) == 1
+    assert np.array_equal(back, x)
 
 
 @pytest.mark.parametrize("shift", [1, 5, 13])

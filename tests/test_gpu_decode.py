@@ -115,3 +115,28 @@ def test_pipelined_decode_calls(glc, cuda):
         back = glc.decompress_batch(plan, comps[2], n, nb)
         plan.synchronize()
         assert np.array_equal(back.cpu().numpy(), batches[2])
+
+
+def test_corrupt_stream_is_reported_not_followed(glc, cuda):
+    """row index, block offsets and block lengths are stream data: out-of-range values must not be
+    dereferenced, and glcPlanSynchronize has to report them"""
+    import torch
+    n = 1 << 16
+    x = datagen.zipf_bytes(n, seed=3)
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=1) as plan:
+        comp = glc.compress_batch(plan, torch.from_numpy(x).cuda(), n, 1)
+        plan.synchronize()
+        for what in ("index", "offset", "length"):
+            bad = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in comp.items()}
+            if what == "index":
+                bad["bwt_index"][0] = n + 12345
+            elif what == "offset":
+                bad["offsets"][3] = 0x7FFFFFF0
+            else:
+                bad["words"][int(comp["offsets"][2].item())] = 0x7FFFFFFF
+            glc.decompress_batch(plan, bad, n, 1)
+            with pytest.raises(glc.CudppError):
+                plan.synchronize()
+        back = glc.decompress_batch(plan, comp, n, 1)           # the plan is still usable
+        plan.synchronize()
+        assert np.array_equal(back.cpu().numpy(), x)
