@@ -299,6 +299,29 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     return hip_result(e);
 }
 
+// the Huffman half of cudppCompress on its own (histogram, tree + codes, bit packer, offsets: rows a5-a8)
+CUDPPResult glcHuffmanEncodeBatch(CUDPPHandle planHandle, const unsigned char *d_symbols, unsigned int *d_hist,
+                                  unsigned int *d_encodeOffset, size_t offsetStride, unsigned int *d_compressedSize,
+                                  unsigned int *d_compressed, size_t compressedStrideWords, size_t numElements,
+                                  size_t numBlocks)
+{
+    CompressPlan *p = plan_from<CompressPlan>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (p->config.algorithm != CUDPP_COMPRESS) return CUDPP_ERROR_INVALID_PLAN;
+    if (numElements == 0 || numElements > p->n || numBlocks == 0 || numBlocks > p->rows)
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    const uint32_t n = (uint32_t)numElements, nb = (uint32_t)numBlocks;
+    if (offsetStride < (n + HUFF_BLOCK - 1) / HUFF_BLOCK) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    p->join_side();
+    hipStream_t st = p->stream;
+    hipError_t e = huff_histogram(st, d_symbols, n, n, nb, p->huff);
+    if (e == hipSuccess) e = huff_build(st, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
+                                        compressedStrideWords, p->d_status);
+    if (e == hipSuccess) e = huff_pack(st, d_symbols, n, n, nb, p->huff, d_encodeOffset, offsetStride, d_compressed,
+                                       compressedStrideWords);
+    return hip_result(e);
+}
+
 CUDPPResult glcPlanSetPipelining(CUDPPHandle planHandle, int on)
 {
     CompressPlan *p = plan_from<CompressPlan>(planHandle);

@@ -118,6 +118,8 @@ struct HuffScratch {
 hipError_t huff_scratch_alloc(HuffScratch &s, uint32_t nmax, uint32_t rows);
 void       huff_scratch_free(HuffScratch &s);
 
+// sub-block histograms of caller-supplied symbols (stand-alone Huffman entry point)
+hipError_t huff_histogram(hipStream_t st, const uint8_t *sym, size_t stride, uint32_t n, uint32_t nblk, HuffScratch &s);
 // tree + codes + offsets (writes d_hist[b][256], d_offsets[b*offset_stride..], d_size[b])
 hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
                       uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size,

@@ -249,6 +249,35 @@ void huff_scratch_free(HuffScratch &s)
     s = HuffScratch();
 }
 
+// histograms of the 4096-symbol sub-blocks of caller-supplied symbols (the compress pipeline gets them from the
+// MTF kernel; this is for the stand-alone Huffman entry point): one wave per sub-block, 4 copies against
+// same-symbol serialisation of the LDS atomics
+__global__ __launch_bounds__(256) void k_sub_hist(const uint8_t *__restrict__ sym, size_t stride, uint32_t n,
+                                                  uint32_t max_sub, uint32_t *__restrict__ sub_hist)
+{
+    __shared__ uint32_t s_h[4][4 * 257];
+    const uint32_t b = blockIdx.y, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK, sub = blockIdx.x * 4 + w;
+    for (uint32_t i = l; i < 4 * 257; i += 64) s_h[w][i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (sub >= nsub) return;
+    const uint32_t lo = sub * HUFF_BLOCK, hi = min(n, lo + HUFF_BLOCK);
+    const uint8_t *S = sym + (size_t)b * stride;
+    uint32_t *H = s_h[w] + (l & 3) * 257;
+    for (uint32_t i = lo + l; i < hi; i += 64) atomicAdd(&H[S[i]], 1u);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *O = sub_hist + ((size_t)b * max_sub + sub) * 256;
+    for (uint32_t i = l; i < 256; i += 64) O[i] = s_h[w][i] + s_h[w][257 + i] + s_h[w][514 + i] + s_h[w][771 + i];
+}
+
+hipError_t huff_histogram(hipStream_t st, const uint8_t *sym, size_t stride, uint32_t n, uint32_t nblk, HuffScratch &s)
+{
+    if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
+    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    hipLaunchKernelGGL(k_sub_hist, dim3((nsub + 3) / 4, nblk), dim3(256), 0, st, sym, stride, n, s.max_sub, s.sub_hist);
+    return hipGetLastError();
+}
+
 hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
                       uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size, size_t capacity_words,
                       uint32_t *d_status)

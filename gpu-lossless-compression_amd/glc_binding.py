@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcHuffmanEncodeBatch",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
@@ -93,6 +93,7 @@ def lib():
     L.glcPlanSetStream.argtypes = [sz, vp]
     L.glcPlanSynchronize.argtypes = [sz]
     L.glcPlanSetPipelining.argtypes = [sz, C.c_int]
+    L.glcHuffmanEncodeBatch.argtypes = [sz, vp, vp, vp, sz, vp, vp, sz, sz, sz]
     L.glcPlanSetSorter.argtypes = [sz, C.c_int]
     L.glcPlanLastSortStats.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
@@ -279,6 +280,22 @@ def compress_batch(plan, d_in, n, nblk):
                                 out["hist"].data_ptr(), out["offsets"].data_ptr(), nsub,
                                 out["size"].data_ptr(), out["words"].data_ptr(), stride, n, nblk)
     _chk("glcCompressBatch", rc)
+    return out
+
+
+def huffman_encode_batch(plan, d_sym, n, nblk):
+    """stand-alone Huffman stage on symbols (uint8 cuda tensor of nblk*n bytes); same outputs as compress_batch"""
+    import torch
+    dev = d_sym.device
+    nsub = (n + HUFF_BLOCK - 1) // HUFF_BLOCK
+    stride = compressed_stride_words(n)
+    out = dict(hist=torch.empty(nblk * 256, dtype=torch.int32, device=dev),
+               offsets=torch.empty(nblk * nsub, dtype=torch.int32, device=dev),
+               size=torch.empty(nblk, dtype=torch.int32, device=dev),
+               words=torch.empty(nblk * stride, dtype=torch.int32, device=dev), stride=stride, nsub=nsub)
+    rc = lib().glcHuffmanEncodeBatch(plan.handle, d_sym.data_ptr(), out["hist"].data_ptr(), out["offsets"].data_ptr(),
+                                     nsub, out["size"].data_ptr(), out["words"].data_ptr(), stride, n, nblk)
+    _chk("glcHuffmanEncodeBatch", rc)
     return out
 
 

@@ -206,6 +206,15 @@ CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4);
  * suffix)}; reading resets the accumulators. */
 CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3);
 
+/* The Huffman half of cudppCompress on caller-supplied symbols (what the pipeline feeds with the MTF output):
+ * histogram, tree + codes, bit packer and offsets -- huffman_build_histogram_kernel / huffman_build_tree_kernel /
+ * huffman_kernel_en / huffman_datapack_kernel, compress_kernel.cuh:2037-2750.  Plan: CUDPP_COMPRESS.  Outputs as
+ * glcCompressBatch.  Lets tests pin the tree's tie-break rule on chosen histograms. */
+CUDPPResult glcHuffmanEncodeBatch(CUDPPHandle planHandle, const unsigned char *d_symbols, unsigned int *d_hist,
+                                  unsigned int *d_encodeOffset, size_t offsetStride, unsigned int *d_compressedSize,
+                                  unsigned int *d_compressed, size_t compressedStrideWords, size_t numElements,
+                                  size_t numBlocks);
+
 /* Suffix sorter selection (plans of CUDPP_COMPRESS / CUDPP_BWT / CUDPP_SA).  0 (default): the bucket sorter
  * (one bucketing pass + in-LDS sort), with the general sorter for the blocks it flags as too repetitive;
  * 1: general sorter only; 2: general sorter, prefix doubling from the first refinement round.  All three

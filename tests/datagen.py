@@ -76,3 +76,26 @@ def log_bytes(n, seed=0x5eed0003):
             1 + (t // 86400000) % 28, h, mi, s, ms, r[1] % 16, svcs[r[2] % 6], r[3] % 32768,
             levels[r[4] % 4], msgs[r[5] % 8], r[6] % 1000, r[7] % 100000)
     return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+
+
+def symbols_from_hist(hist, a=0x9E3779B1, c=12345):
+    """n = sum(hist) symbols (n must be a power of two) with exactly the given counts, spread by the affine
+    permutation i -> (a * i + c) mod n (a odd): version-independent, so a committed histogram names its bytes."""
+    hist = np.asarray(hist, dtype=np.int64)
+    n = int(hist.sum())
+    assert n & (n - 1) == 0 and a & 1
+    ordered = np.repeat(np.arange(hist.size, dtype=np.uint8), hist)
+    idx = (np.arange(n, dtype=np.uint64) * np.uint64(a) + np.uint64(c)) & np.uint64(n - 1)
+    out = np.empty(n, dtype=np.uint8)
+    out[idx.astype(np.int64)] = ordered
+    return out
+
+
+def glibc_rand_bytes(n, mod, seed=95835):
+    """the reference's test inputs: srand(95835); (rand() % mod) + 1  (test_compress.cpp:439-441,552-556,687-692;
+    test_sa.cpp:124-126) -- glibc's rand(), which is what the reference's testrig links."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(seed)
+    rand = libc.rand
+    return np.fromiter(((rand() % mod) + 1 for _ in range(n)), dtype=np.uint8, count=n)

@@ -279,6 +279,84 @@ def ref_sa_gold(data):
     return ref[: a.size]
 
 
+COMPRESSGOLD_SO = os.path.join(os.path.dirname(SAGOLD_SO), "libcompressgold.so")
+_cgold = None
+
+
+def have_ref_compress_gold():
+    return os.path.exists(COMPRESSGOLD_SO)
+
+
+def _cg():
+    """oracle/_ref/libcompressgold.so: the CPU gold of test_compress.cpp (FindMinimumCountTest, huffman_build_tree_cpu,
+    computeMtfGold, computeBwtGold, Huffman + inverse-MTF half of computeCompressGold), built by
+    oracle/mk_ref_compress_gold.sh from the reference's own lines."""
+    global _cgold
+    if _cgold is None:
+        L = C.CDLL(COMPRESSGOLD_SO)
+        ip = C.POINTER(C.c_int)
+        L.ref_huffman_tree.argtypes = [_u32p, ip, _u32p, ip, ip, ip, ip, _u32p]
+        L.ref_huffman_tree.restype = C.c_int
+        L.ref_compress_gold_decode.argtypes = [_u32p, _u32p, _u32p, C.c_size_t, _u8p, _u8p]
+        L.ref_compress_gold_decode.restype = C.c_int
+        L.ref_mtf_gold.argtypes = [_u8p, _u8p, C.c_uint]
+        L.ref_bwt_gold.argtypes = [_u8p, _u8p, C.c_uint]
+        L.ref_bwt_gold.restype = C.c_int
+        _cgold = L
+    return _cgold
+
+
+def ref_huffman_tree(hist256):
+    """huffman_build_tree_cpu on hist (+EOF count 1).  Returns dict(head, nnodes, value, count, level, left, right)."""
+    h = np.zeros(257, dtype=np.uint32)
+    h[:256] = np.asarray(hist256, dtype=np.uint32)
+    arr = {k: np.zeros(513, dtype=np.int32) for k in ("value", "level", "left", "right", "parent")}
+    cnt = np.zeros(513, dtype=np.uint32)
+    nn = C.c_uint32(0)
+    ip = C.POINTER(C.c_int)
+    head = _cg().ref_huffman_tree(_p32(h), arr["value"].ctypes.data_as(ip), _p32(cnt), arr["level"].ctypes.data_as(ip),
+                                  arr["left"].ctypes.data_as(ip), arr["right"].ctypes.data_as(ip),
+                                  arr["parent"].ctypes.data_as(ip), C.byref(nn))
+    return dict(head=head, nnodes=nn.value, count=cnt, **arr)
+
+
+def ref_codes_from_tree(tree):
+    """root-to-leaf paths of the reference's tree, left = 0 / right = 1 (the walk of the reference's own decoder,
+    test_compress.cpp:258-266).  Returns (codes as python ints [257], lens [257])."""
+    codes, lens = [0] * 257, np.zeros(257, dtype=np.uint16)
+    stack = [(tree["head"], 0, 0)]
+    while stack:
+        node, code, ln = stack.pop()
+        if tree["value"][node] != -1:                      # COMPOSITE_NODE
+            codes[int(tree["value"][node])] = code; lens[int(tree["value"][node])] = ln
+            continue
+        stack.append((int(tree["left"][node]), code << 1, ln + 1))
+        stack.append((int(tree["right"][node]), (code << 1) | 1, ln + 1))
+    return codes, lens
+
+
+def ref_compress_gold_decode(hist256, offsets256, words, n):
+    """Huffman decode + inverse MTF of a 1 MiB stream by computeCompressGold's own lines.  Returns (symbols, bytes)."""
+    h = np.zeros(257, dtype=np.uint32); h[:256] = np.asarray(hist256, dtype=np.uint32)
+    off = np.ascontiguousarray(offsets256, dtype=np.uint32)
+    w = np.zeros(len(words) + 4, dtype=np.uint32); w[: len(words)] = words     # the gold reads one word ahead
+    sym = np.zeros(n, dtype=np.uint8); out = np.zeros(n, dtype=np.uint8)
+    _cg().ref_compress_gold_decode(_p32(h), _p32(off), _p32(w), n, _p8(sym), _p8(out))
+    return sym, out
+
+
+def ref_mtf_gold(data):
+    a = _as_u8(data).copy(); out = np.zeros(a.size, dtype=np.uint8)
+    _cg().ref_mtf_gold(_p8(out), _p8(a), a.size)
+    return out
+
+
+def ref_bwt_gold(data):
+    a = _as_u8(data).copy(); out = np.zeros(a.size, dtype=np.uint8)
+    idx = _cg().ref_bwt_gold(_p8(a), _p8(out), a.size)
+    return out, idx
+
+
 # --------------------------------------------------------------------------
 # the reference test-input generators (glibc rand, srand(95835))
 # test_compress.cpp:439-441,552-556,687-692 ; test_sa.cpp:124-126

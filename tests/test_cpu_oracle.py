@@ -238,3 +238,60 @@ def test_product_does_not_reference_the_oracle():
                 if "oracle_lib" in t or "glc_oracle" in t or "libglc_oracle" in t or "/root/reference" in t:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+# --------------------------------------------------------------------------
+# Huffman half pinned to the reference (tests/golden/ref_huff_gold.npz, made by make_huff_gold.py from the
+# reference's own huffman_build_tree_cpu / FindMinimumCountTest / computeCompressGold lines)
+# --------------------------------------------------------------------------
+HUFF = np.load(os.path.join(GOLD, "ref_huff_gold.npz"))
+
+
+@pytest.mark.parametrize("name", [str(s) for s in HUFF["hist_cases"]])
+def test_oracle_huffman_vs_reference_tree(name):
+    hist = HUFF["h_%s_hist" % name]
+    sym = datagen.symbols_from_hist(hist)
+    _, lens, _ = O.huff_codes(hist)
+    assert np.array_equal(lens, HUFF["h_%s_lens" % name]), "code lengths differ from huffman_build_tree_cpu"
+    r = O.huff_encode(sym)
+    assert r["size"] == int(HUFF["h_%s_size" % name][0])
+    assert O.crc32(r["words"].view(np.uint8)) == int(HUFF["h_%s_crc_words" % name][0])
+    assert O.crc32(r["offsets"].view(np.uint8)) == int(HUFF["h_%s_crc_offsets" % name][0])
+    assert O.crc32(O.imtf(sym)) == int(HUFF["h_%s_crc_imtf" % name][0])        # inverse MTF of computeCompressGold
+
+
+@pytest.mark.parametrize("name", [str(s) for s in HUFF["e2e_cases"]])
+def test_oracle_compress_vs_reference_gold_chain(name):
+    n = 1 << 20
+    if name == "ref_compressTest":
+        x = datagen.glibc_rand_bytes(n, 255); x[-1] = 0
+    else:
+        x = {"zipf": datagen.zipf_bytes, "float": datagen.float_bytes, "text": datagen.text_bytes}[name](n)
+    assert O.crc32(x) == int(HUFF["e_%s_crc_in" % name][0])
+    r = O.compress(x)
+    assert r["bwt_index"] == int(HUFF["e_%s_bwt_index" % name][0])
+    assert r["size"] == int(HUFF["e_%s_size" % name][0])
+    assert O.crc32(r["words"].view(np.uint8)) == int(HUFF["e_%s_crc_words" % name][0])
+    assert O.crc32(r["offsets"].view(np.uint8)) == int(HUFF["e_%s_crc_offsets" % name][0])
+    assert np.array_equal(r["hist"], HUFF["e_%s_hist" % name])
+
+
+@pytest.mark.skipif(not O.have_ref_compress_gold(), reason="oracle/_ref/libcompressgold.so not built (no /root/reference)")
+def test_reference_gold_live_against_oracle():
+    """where the reference's lines are compiled: trees, MTF, BWT and the gold decoder against the oracle, live"""
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        k = int(rng.integers(1, 257))
+        hist = np.zeros(256, dtype=np.uint32)
+        hist[rng.choice(256, k, replace=False)] = rng.integers(1, 50, k) if rng.random() < 0.5 else rng.integers(1, 100000, k)
+        _, lens = O.ref_codes_from_tree(O.ref_huffman_tree(hist))
+        assert np.array_equal(lens.astype(np.uint8), O.huff_codes(hist)[1])
+    x = datagen.text_bytes(20000, seed=8)
+    b, idx = O.ref_bwt_gold(x)
+    ob, oidx = O.bwt(x)
+    assert idx == oidx and np.array_equal(b, ob)
+    assert np.array_equal(O.ref_mtf_gold(b), O.mtf(b))
+    y = datagen.zipf_bytes(1 << 20, seed=77)
+    r = O.compress(y)
+    sym, byt = O.ref_compress_gold_decode(r["hist"], r["offsets"], r["words"], y.size)
+    assert np.array_equal(byt, O.bwt(y)[0])                  # gold Huffman decode + inverse MTF reads the oracle's stream
