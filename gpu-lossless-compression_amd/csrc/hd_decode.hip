@@ -351,6 +351,28 @@ size_t glcHdEncodeHost(const unsigned char *in, size_t nsym, const unsigned char
 
 size_t glcHdWorkBytes(size_t nunits) { return hd_layout(nunits ? nunits : 1).total; }
 
+static int hd_decode_lut(const unsigned int *d_units, size_t nunits, const uint16_t *lut, unsigned char *d_out,
+                         size_t nsym, void *d_work, void *stream)
+{
+    const HdLayout L = hd_layout(nunits);
+    if (L.nchunks > HD_CHUNK) return 0;
+    uint8_t *W = (uint8_t *)d_work;
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t *d_lut = (uint16_t *)(W + L.o_lut);
+    if (hipMemcpyAsync(d_lut, lut, 2048 * sizeof(uint16_t), hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+    if (hipStreamSynchronize(st) != hipSuccess) return 0;     // lut is a stack array of the caller
+    uint32_t *pexcl = (uint32_t *)(W + L.o_pexcl), *fwg = (uint32_t *)(W + L.o_fwg), *G = (uint32_t *)(W + L.o_g);
+    uint32_t *coff = (uint32_t *)(W + L.o_coff), *soff = (uint32_t *)(W + L.o_soff);
+    unsigned long long *cbase = (unsigned long long *)(W + L.o_cbase), *sbase = (unsigned long long *)(W + L.o_sbase);
+    hipLaunchKernelGGL(k_hd_span_functions, dim3((unsigned)L.nwg), dim3(HD_LANES), 0, st, d_units, nunits, d_lut, pexcl, fwg);
+    hipLaunchKernelGGL(k_hd_walk, dim3((unsigned)L.nchunks), dim3(64), 0, st, 0, fwg, L.nwg, G, coff, cbase, soff, sbase);
+    hipLaunchKernelGGL(k_hd_walk, dim3(1), dim3(64), 0, st, 1, fwg, L.nchunks, G, coff, cbase, soff, sbase);
+    hipLaunchKernelGGL(k_hd_walk, dim3((unsigned)L.nchunks), dim3(64), 0, st, 2, fwg, L.nwg, G, coff, cbase, soff, sbase);
+    hipLaunchKernelGGL(k_hd_emit, dim3((unsigned)L.nwg), dim3(HD_LANES), 0, st, d_units, nunits, d_lut, pexcl, soff, sbase,
+                       d_out, nsym);
+    return hipGetLastError() == hipSuccess ? 1 : 0;
+}
+
 int glcHdDecodeDevice(const unsigned int *d_units, size_t nunits, const unsigned char lens[256],
                       const unsigned short codes[256], unsigned char *d_out, size_t nsym, void *d_work, void *stream)
 {
@@ -367,23 +389,22 @@ int glcHdDecodeDevice(const unsigned int *d_units, size_t nunits, const unsigned
         if (lo + span > 2048) return 0;
         for (int i = 0; i < span; i++) lut[lo + i] = (uint16_t)((l << 8) | s);
     }
-    const HdLayout L = hd_layout(nunits);
-    if (L.nchunks > HD_CHUNK) return 0;
-    uint8_t *W = (uint8_t *)d_work;
-    hipStream_t st = (hipStream_t)stream;
-    uint16_t *d_lut = (uint16_t *)(W + L.o_lut);
-    if (hipMemcpyAsync(d_lut, lut, sizeof lut, hipMemcpyHostToDevice, st) != hipSuccess) return 0;
-    if (hipStreamSynchronize(st) != hipSuccess) return 0;     // lut is a stack array
-    uint32_t *pexcl = (uint32_t *)(W + L.o_pexcl), *fwg = (uint32_t *)(W + L.o_fwg), *G = (uint32_t *)(W + L.o_g);
-    uint32_t *coff = (uint32_t *)(W + L.o_coff), *soff = (uint32_t *)(W + L.o_soff);
-    unsigned long long *cbase = (unsigned long long *)(W + L.o_cbase), *sbase = (unsigned long long *)(W + L.o_sbase);
-    hipLaunchKernelGGL(k_hd_span_functions, dim3((unsigned)L.nwg), dim3(HD_LANES), 0, st, d_units, nunits, d_lut, pexcl, fwg);
-    hipLaunchKernelGGL(k_hd_walk, dim3((unsigned)L.nchunks), dim3(64), 0, st, 0, fwg, L.nwg, G, coff, cbase, soff, sbase);
-    hipLaunchKernelGGL(k_hd_walk, dim3(1), dim3(64), 0, st, 1, fwg, L.nchunks, G, coff, cbase, soff, sbase);
-    hipLaunchKernelGGL(k_hd_walk, dim3((unsigned)L.nchunks), dim3(64), 0, st, 2, fwg, L.nwg, G, coff, cbase, soff, sbase);
-    hipLaunchKernelGGL(k_hd_emit, dim3((unsigned)L.nwg), dim3(HD_LANES), 0, st, d_units, nunits, d_lut, pexcl, soff, sbase,
-                       d_out, nsym);
-    return hipGetLastError() == hipSuccess ? 1 : 0;
+    return hd_decode_lut(d_units, nunits, lut, d_out, nsym, d_work, stream);
+}
+
+// the table exactly as the reference holds it: cuhd::CUHDCodetableItemSingle[2048] = {num_bits, symbol} byte
+// pairs indexed by the next 11 bits of the stream (cuhd_codetable.h:20-23, llhuffman_encoder.cc:240-262)
+int glcHdDecodeDeviceTable(const unsigned int *d_units, size_t nunits, const unsigned char *table2048,
+                           unsigned char *d_out, size_t nsym, void *d_work, void *stream)
+{
+    if (!d_units || !table2048 || !d_out || !d_work || nunits == 0 || nunits > (1ull << 31)) return 0;
+    uint16_t lut[2048];
+    for (int i = 0; i < 2048; i++) {
+        const unsigned bits = table2048[2 * i], sym = table2048[2 * i + 1];
+        if (bits > GLC_HD_MAX_LEN) return 0;
+        lut[i] = (uint16_t)(((bits ? bits : 1u) << 8) | sym);   // prefixes no codeword reaches: never met in a valid stream
+    }
+    return hd_decode_lut(d_units, nunits, lut, d_out, nsym, d_work, stream);
 }
 
 } // extern "C"

@@ -49,7 +49,7 @@ CULZSS_SYMBOLS = [
     "glcLzssWorkBytes", "culzss_container_bound", "culzss_container_compress", "culzss_container_decompress",
     "culzss_compress_file", "culzss_decompress_file",
 ]
-HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice"]
+HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice", "glcHdDecodeDeviceTable"]
 
 
 class CUDPPConfiguration(C.Structure):
@@ -157,6 +157,8 @@ def lib():
         L.glcHdWorkBytes.restype = sz
         L.glcHdDecodeDevice.argtypes = [vp, sz, vp, vp, vp, sz, vp, vp]
         L.glcHdDecodeDevice.restype = C.c_int
+        L.glcHdDecodeDeviceTable.argtypes = [vp, sz, vp, vp, sz, vp, vp]
+        L.glcHdDecodeDeviceTable.restype = C.c_int
     _lib = L
     return L
 

@@ -50,6 +50,13 @@ int glcHdDecodeDevice(const unsigned int *d_units, size_t nunits, const unsigned
                       const unsigned short codes[256], unsigned char *d_out, size_t nsym,
                       void *d_work, void *stream);
 
+/* Same, with the decoder table exactly as the reference holds it: cuhd::CUHDCodetableItemSingle[2048], i.e.
+ * {num_bits, symbol} byte pairs indexed by the next 11 stream bits (cuhd_codetable.h:20-23, built by
+ * LLHuffmanEncoder::get_decoder_table, llhuffman_encoder.cc:240-262).  This is the call
+ * cuhd::CUHDGPUDecoder::decode (cuhd_gpu_decoder.cu:422-431) maps to: units, table, output. */
+int glcHdDecodeDeviceTable(const unsigned int *d_units, size_t nunits, const unsigned char *table2048,
+                           unsigned char *d_out, size_t nsym, void *d_work, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,3 +104,58 @@ def test_device_decoder_large_multi_chunk(glc, cuda):
     out = glc.hd_decode_device(d_units, lens, codes, data.size)
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), torch.from_numpy(data))
+
+
+# --------------------------------------------------------------------------
+# streams written by the REFERENCE's encoder (tests/golden/ref_cuhd_gold.npz, made by make_cuhd_gold.py from
+# cuhd-icpp/encoder/src/llhuffman_encoder.cc + src/cuhd_codetable.cc compiled unmodified)
+# --------------------------------------------------------------------------
+import os  # noqa: E402
+
+import datagen  # noqa: E402
+
+REF = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_cuhd_gold.npz"))
+REF_CASES = [str(s) for s in REF["cases"]]
+
+
+def _ref_symbols(name):
+    if name + "_symbols" in REF.files:
+        return REF[name + "_symbols"]
+    return datagen.symbols_from_hist(REF[name + "_hist"])
+
+
+@pytest.mark.parametrize("name", REF_CASES)
+def test_reference_encoded_stream_through_oracle_decoder(name):
+    """CPU: the reference's units + its dictionary decode (bit-serially) to the symbols -- pins the stream shape
+    this repo assumes (MSB-first 32-bit units, pad unit) and the oracle's decoder to the reference's encoder"""
+    sym = _ref_symbols(name)
+    got = O.hd_decode(REF[name + "_units"], REF[name + "_lens"], REF[name + "_codes"].astype(np.uint16), sym.size)
+    assert np.array_equal(got, sym)
+    # the reference's decoder table says the same as its dictionary
+    t = REF[name + "_table"].reshape(2048, 2)
+    for s in np.nonzero(REF[name + "_lens"])[0]:
+        ln, code = int(REF[name + "_lens"][s]), int(REF[name + "_codes"][s])
+        lo = code << (11 - ln)
+        assert (t[lo:lo + (1 << (11 - ln)), 0] == ln).all() and (t[lo:lo + (1 << (11 - ln)), 1] == s).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REF_CASES)
+def test_device_decodes_reference_encoded_stream(glc, cuda, name):
+    """config 5 driven by the reference's own encoder: glcHdDecodeDeviceTable(reference units, reference table)
+    == original (the reference's pass criterion, demo.cc:176-178), and the dictionary form agrees"""
+    import torch
+    L = glc.lib()
+    sym = _ref_symbols(name)
+    units = REF[name + "_units"]
+    d_units = torch.from_numpy(units.view(np.int32).copy()).cuda()
+    work = torch.empty(L.glcHdWorkBytes(units.size), dtype=torch.uint8, device=cuda)
+    out = torch.zeros(sym.size, dtype=torch.uint8, device=cuda)
+    table = np.ascontiguousarray(REF[name + "_table"])
+    assert L.glcHdDecodeDeviceTable(d_units.data_ptr(), units.size, table.ctypes.data, out.data_ptr(), sym.size,
+                                    work.data_ptr(), None) == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), sym)
+    back = glc.hd_decode_device(d_units, REF[name + "_lens"], REF[name + "_codes"].astype(np.uint16), sym.size)
+    torch.cuda.synchronize()
+    assert np.array_equal(back.cpu().numpy(), sym)
