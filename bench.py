@@ -3,28 +3,33 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): synthetic Zipf(1.0)-distributed bytes in
-independent 1 MiB blocks, cudppCompress (BWT -> MTF -> Huffman) encode, inputs
-resident in HBM before the timed region.  A "step" is one pass of the hot path
-over the whole per-GPU input (--gib, default 4 GiB) in plan-sized batches.
-For N > 1 the blocks are dealt round-robin (global block g -> rank g % N), each
-rank encodes its own blocks with no data-path collective (weak scaling: the
-per-GPU input is fixed).  The one exchange step of SURVEY.md 8(e) -- gathering the
-compacted bitstreams on rank 0 over RCCL -- runs once after the timed region and is
-reported as `gather_to_rank0` (--with-gather moves it into every timed step).
+`value` (BASELINE.json configs[1] at N = 1): synthetic Zipf(1.0)-distributed bytes in independent 1 MiB blocks,
+cudppCompress (BWT -> MTF -> Huffman) encode, inputs resident in HBM before the timed region.  A "step" is one pass
+of the hot path over the whole per-GPU input (--gib, default 4 GiB) in plan-sized batches.
 
-The timed encode leg uses one plan with its stages back to back, so that the launch time of the
-dominant kernel reported under `roofline` is the kernel's own (--enc-pipeline and --enc-threads 2
---rows 128 overlap stages / plans for +5-10 % throughput).  The decode leg, reported beside it, uses
---plans host threads with stage pipelining.
+N > 1 (configs[3]): random-float32-as-bytes, global block g on rank g % N, every rank encodes its own blocks with no
+data-path collective (weak scaling: per-GPU input fixed).  The one exchange step of SURVEY.md 8(e) -- records +
+exact-length streams gathered on rank 0 over RCCL -- runs after the timed region (--with-gather moves it inside);
+rank 0 then checks that what it gathered equals what a single process produces for sampled blocks of every rank and
+DECODES gathered blocks of every rank back to their input.
 
-Prints ONE JSON line on rank 0; `value` = whole-job input GB/s of the encode.
+The same JSON line carries, measured in the same run on rank 0 at N = 1:
+    single_call                  what a drop-in caller of the reference API gets: cudppCompress, one 1 MiB block
+    culzss                       configs[2]: 4 GiB log-style ASCII through the CULZSS path, device resident
+    hd_decode                    configs[4] (one GPU's share): CUHD-shaped Huffman-only decode
+    stream_read_ceiling_GBps     a trivial 16-byte-per-lane read kernel over the input, this box, this run
+    cpu_baseline                 oracle port (1 core / all effective cores), libbz2 -9 encode + decode (1 / all),
+                                 the reference's serial LZSS (oracle/_ref/lzss_serial) for config 3
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib.util
 import json
 import os
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +38,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MiB = 1 << 20
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic HBM bytes per input byte of the profiled kernels
+ALG_BYTES = {"k_fs_part": 9.0, "k_fs_sort": 9.0, "k_fs_hist": 1.0, "k_mtf_encode": 2.0,
+             "k_mtf_chunk_lists+k_mtf_scan_lists": 1.0, "k_huff_pack": None, "k_huff_build": 1.0 / 16,
+             "k_rs_onesweep<8,false>": 16.0}
 
 
 def _load(name, path):
@@ -44,8 +53,8 @@ def _load(name, path):
 
 
 def zipf_blocks_on_device(torch, dev, nblocks, first_global_block, stride_blocks, seed=0x5EED0002):
-    """Zipf(1.0) bytes over 256 symbols, identity symbol permutation.  Block g of the
-    global stream is generated from seed+g so any rank / any N produces the same bytes."""
+    """Zipf(1.0) bytes over 256 symbols, identity symbol permutation.  Block g of the global stream is generated
+    from seed+g so any rank / any N produces the same bytes."""
     out = torch.empty(nblocks * MiB, dtype=torch.uint8, device=dev)
     p = 1.0 / torch.arange(1, 257, dtype=torch.float64)
     cdf = torch.cumsum(p / p.sum(), 0).to(torch.float32).to(dev)
@@ -58,60 +67,263 @@ def zipf_blocks_on_device(torch, dev, nblocks, first_global_block, stride_blocks
     return out
 
 
-def cpu_baseline(sample_blocks):
-    """The oracle (a port of the reference algorithm, same bitstream) timed on the
-    host cores of this box over a bounded sample of the same workload."""
+def float_blocks_on_device(torch, dev, nblocks, first_global_block, stride_blocks, seed=0x5EED0004):
+    """configs[3]: float32 ~ N(0,1) as little-endian bytes (cuSZ quant-code surrogate); block g from seed+g."""
+    out = torch.empty(nblocks * MiB, dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    for i in range(nblocks):
+        g = first_global_block + i * stride_blocks
+        gen.manual_seed(seed + g)
+        out[i * MiB:(i + 1) * MiB] = torch.randn(MiB // 4, generator=gen, device=dev, dtype=torch.float32).view(torch.uint8)
+    return out
+
+
+def effective_cores():
+    """cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(sample_blocks, log_sample):
+    """Reported baselines (not targets), bounded to ~20-30 s: the oracle port of cudppCompress and libbz2 -9 on the
+    same Zipf blocks, single core and on all effective cores; the reference's serial LZSS on log-style ASCII."""
     import bz2
     from concurrent.futures import ThreadPoolExecutor
 
+    import numpy as np
     import oracle_lib as O
     O.lib()
+    cores = effective_cores()
     t0 = time.perf_counter()
-    for blk in sample_blocks[:8]:
+    for blk in sample_blocks[:6]:
         O.compress(blk)
-    t1 = time.perf_counter()
-    single = 8 * MiB / (t1 - t0) / 1e9
-    ncores = os.cpu_count() or 1
+    single = 6 * MiB / (time.perf_counter() - t0) / 1e9
+    nall = min(len(sample_blocks), max(cores, 8))
+    flat = np.concatenate(sample_blocks[:nall])
+    t0 = time.perf_counter()
+    O.compress_many(flat, MiB, cores)                       # pthreads inside the oracle, one block per thread
+    allcore = nall * MiB / (time.perf_counter() - t0) / 1e9
+    raw = [b.tobytes() for b in sample_blocks[:nall]]
+    t0 = time.perf_counter()
+    comp = [bz2.compress(r, 9) for r in raw[:4]]
+    bz_enc1 = 4 * MiB / (time.perf_counter() - t0) / 1e9
+    t0 = time.perf_counter()
+    for c in comp:
+        bz2.decompress(c)
+    bz_dec1 = 4 * MiB / (time.perf_counter() - t0) / 1e9
+    with ThreadPoolExecutor(max_workers=cores) as ex:       # libbz2 releases the GIL
+        t0 = time.perf_counter()
+        comp = list(ex.map(lambda r: bz2.compress(r, 9), raw))
+        bz_enc = nall * MiB / (time.perf_counter() - t0) / 1e9
+        t0 = time.perf_counter()
+        list(ex.map(bz2.decompress, comp))
+        bz_dec = nall * MiB / (time.perf_counter() - t0) / 1e9
+    res = {"value": round(single, 5), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": "6 x 1 MiB Zipf blocks of this workload through oracle/glc_oracle.c orc_compress (same bitstream), one thread",
+           "all_cores": {"cores": cores, "cpu_count": os.cpu_count(), "blocks": nall,
+                         "oracle_port_encode_GBps": round(allcore, 5),
+                         "libbz2_9_encode_GBps": round(bz_enc, 5), "libbz2_9_decode_GBps": round(bz_dec, 5)},
+           "libbz2_9_single_core": {"encode_GBps": round(bz_enc1, 5), "decode_GBps": round(bz_dec1, 5)}}
+    exe = os.path.join(ROOT, "oracle", "_ref", "lzss_serial")
+    if log_sample is not None and os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as d:
+            fi, fo, fb = os.path.join(d, "in"), os.path.join(d, "out"), os.path.join(d, "back")
+            open(fi, "wb").write(log_sample.tobytes())
+            t0 = time.perf_counter()
+            subprocess.run([exe, "-c", "-i", fi, "-o", fo], check=True, stdout=subprocess.DEVNULL)
+            te = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            subprocess.run([exe, "-d", "-i", fo, "-o", fb], check=True, stdout=subprocess.DEVNULL)
+            td = time.perf_counter() - t0
+            res["serial_lzss_config3"] = {
+                "kind": "reference", "cores": 1, "encode_GBps": round(log_sample.size / te / 1e9, 5),
+                "decode_GBps": round(log_sample.size / td / 1e9, 5), "ratio": round(log_sample.size / os.path.getsize(fo), 4),
+                "sample": "%d MiB of the config-3 log data through oracle/_ref/lzss_serial (the reference's "
+                          "cuda-lzss-unknown/lzss-0.6.2, brute-force matcher, compiled unmodified; 4 KiB window format)"
+                          % (log_sample.size >> 20)}
+    return res
+
+
+def leg_single_call(torch, glc, dev, d_block, iters=20):
+    """the reference API as its own test drives it: cudppCompress on one 1 MiB block with a rows=1 plan, outputs read
+    back afterwards (test_compress.cpp:744-779) -- here the wait is glcPlanSynchronize"""
+    L = glc.lib()
+    n = MiB
+    nsub, stride = n // 4096, glc.compressed_stride_words(n)
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=1) as plan:
+        o = dict(idx=torch.empty(1, dtype=torch.int32, device=dev), hist=torch.empty(256, dtype=torch.int32, device=dev),
+                 off=torch.empty(nsub, dtype=torch.int32, device=dev), size=torch.empty(1, dtype=torch.int32, device=dev),
+                 words=torch.empty(stride, dtype=torch.int32, device=dev))
+
+        def call():
+            rc = L.cudppCompress(plan.handle, d_block.data_ptr(), o["idx"].data_ptr(), None, o["hist"].data_ptr(),
+                                 o["off"].data_ptr(), o["size"].data_ptr(), o["words"].data_ptr(), n)
+            assert rc == 0
+            plan.synchronize()
+        for _ in range(3):
+            call()
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            call()
+            ts.append(time.perf_counter() - t0)
+        # how long the host is held inside the call itself (enqueue + the sort's one readback)
+        t0 = time.perf_counter()
+        rc = L.cudppCompress(plan.handle, d_block.data_ptr(), o["idx"].data_ptr(), None, o["hist"].data_ptr(),
+                             o["off"].data_ptr(), o["size"].data_ptr(), o["words"].data_ptr(), n)
+        t_call = time.perf_counter() - t0
+        plan.synchronize()
+        assert rc == 0
+    med = statistics.median(ts)
+    return {"api": "cudppCompress (reference entry point), plan rows=1, one 1 MiB Zipf block, glcPlanSynchronize after each call",
+            "ms_per_call_median": round(med * 1e3, 4), "GBps": round(n / med / 1e9, 4),
+            "ms_host_in_call": round(t_call * 1e3, 4), "calls": iters,
+            "host_syncs_per_call": "1 inside (flagged-block count of the bucket sorter) + the caller's wait"}
+
+
+def leg_culzss(torch, glc, dev, gib, iters=3):
+    """configs[2]: CULZSS on log-style ASCII, 1 MiB buffers of 4096-byte packets, 128-byte window, device resident"""
     import numpy as np
-    flat = np.concatenate(sample_blocks)
+    import datagen
+    import oracle_lib as O
+    L = glc.lib()
+    nbuf = max(1, int(gib * 1024))
+    uniq = min(64, nbuf)
+    host = np.concatenate([datagen.log_bytes(MiB, seed=0x5EED0003 + i) for i in range(uniq)])
+    d_u = torch.from_numpy(host).to(dev)
+    d_in = d_u.repeat((nbuf + uniq - 1) // uniq)[: nbuf * MiB].contiguous()
+    del d_u
+    stride = L.glcLzssPackStride(MiB)
+    d_packed = torch.empty(nbuf * stride, dtype=torch.uint8, device=dev)
+    d_sizes = torch.empty(nbuf, dtype=torch.int32, device=dev)
+    d_work = torch.empty(L.glcLzssWorkBytes(MiB, nbuf), dtype=torch.uint8, device=dev)
+    d_out = torch.empty(nbuf * MiB, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+    sp = st.cuda_stream
+
+    def enc():
+        assert L.glcLzssEncodeDevice(d_in.data_ptr(), MiB, nbuf, None, d_packed.data_ptr(), d_sizes.data_ptr(),
+                                     d_work.data_ptr(), sp) == 1
+
+    def dec():
+        assert L.glcLzssDecodeDevice(d_packed.data_ptr(), d_sizes.data_ptr(), MiB, nbuf, d_out.data_ptr(), sp) == 1
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        ms = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st); fn(); e1.record(st); torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        return statistics.median(ms)
+
+    ms_enc, ms_dec = timed(enc), timed(dec)
+    if not torch.equal(d_out, d_in):
+        raise RuntimeError("CULZSS round trip failed")
+    sizes = d_sizes.cpu().numpy().astype(np.int64)
+    raw = int((sizes == 0).sum())
+    comp_bytes = int(sizes.sum()) + raw * MiB
+    ok, pick = 0, [0, uniq // 2, uniq - 1]
     t0 = time.perf_counter()
-    O.compress_many(flat, MiB, ncores)                      # pthreads inside the oracle, one block per thread
-    t1 = time.perf_counter()
-    allcore = len(sample_blocks) * MiB / (t1 - t0) / 1e9
+    for b in pick:
+        blk = host[b * MiB:(b + 1) * MiB]
+        want = O.lzss_pack(O.lzss_candidates(blk), MiB)
+        ok += int(want is not None and np.array_equal(d_packed[b * stride: b * stride + int(sizes[b])].cpu().numpy(), want))
+    cpu_s = (time.perf_counter() - t0) / len(pick)
+    if ok != len(pick):
+        raise RuntimeError("CULZSS parity failure in bench sample")
+    total = nbuf * MiB
+    rho = comp_bytes / total
+    return {"workload": "configs[2]: %g GiB log-style ASCII (%d MiB unique, tiled), 1 MiB buffers, 4096-B packets, 128-B window, "
+                        "device resident (glcLzssEncodeDevice / glcLzssDecodeDevice)" % (gib, uniq),
+            "encode_GBps": round(total / ms_enc / 1e6, 3), "decode_GBps": round(total / ms_dec / 1e6, 3),
+            "encode_ms": round(ms_enc, 3), "decode_ms": round(ms_dec, 3), "timing": "median of %d, hipEvents on the launch stream" % iters,
+            "compression_ratio": round(1.0 / rho, 4), "raw_stored_buffers": raw,
+            "hbm_frac": {"encode": round((1 + rho) * total / ms_enc / 1e6 / HBM_PEAK_GBPS, 5),
+                         "decode": round((1 + rho) * total / ms_dec / 1e6 / HBM_PEAK_GBPS, 5),
+                         "algorithmic_bytes": "1 R + rho W (encode), rho R + 1 W (decode) per input byte",
+                         "bound": "VALU: k_lzss_match does 127 window compares per input byte (6 VALU each); see DESIGN.md"},
+            "roundtrip": "decode(encode(x)) == x on all %d buffers" % nbuf,
+            "parity": "%d/%d sampled buffers byte-exact vs oracle" % (ok, len(pick)),
+            "cpu_port": {"value": round(MiB / cpu_s / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": "3 x 1 MiB buffers through the oracle's lock-step EncodeKernel emulation + aftercomp"}}, host[:8 * MiB]
+
+
+def leg_hd(torch, glc, dev, mib, iters=5):
+    """configs[4], one GPU's share: CUHD-shaped Huffman-only stream, symbols ~ Binomial(255, 0.5) (demo.cc.ori:54-62)"""
+    import numpy as np
+    import oracle_lib as O
+    L = glc.lib()
+    n = mib << 20
+    data = np.random.default_rng(5).binomial(255, 0.5, size=n).astype(np.uint8)
+    lens, codes = glc.hd_build_table(np.bincount(data, minlength=256).astype(np.uint64))
+    units = glc.hd_encode_host(data, lens, codes)
+    d_units = torch.from_numpy(units.view(np.int32)).to(dev)
+    work = torch.empty(L.glcHdWorkBytes(units.size), dtype=torch.uint8, device=dev)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev)
+
+    def dec():
+        assert L.glcHdDecodeDevice(d_units.data_ptr(), units.size, lens.ctypes.data, codes.ctypes.data, out.data_ptr(), n,
+                                   work.data_ptr(), st.cuda_stream)
+    dec(); torch.cuda.synchronize()
+    if not torch.equal(out.cpu(), torch.from_numpy(data)):
+        raise RuntimeError("CUHD-shaped decode: decoded != original")
+    ms = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st); dec(); e1.record(st); torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    m = statistics.median(ms)
+    ns = min(n, 16 << 20)
+    su = glc.hd_encode_host(data[:ns], lens, codes)
     t0 = time.perf_counter()
-    for blk in sample_blocks[:4]:
-        bz2.compress(blk.tobytes(), 9)
-    t1 = time.perf_counter()
-    bz = 4 * MiB / (t1 - t0) / 1e9
-    return {"value": round(single, 5), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "8 x 1 MiB Zipf blocks of this workload through oracle/glc_oracle.c orc_compress (single thread)",
-            "all_cores_value": round(allcore, 5), "all_cores": ncores,
-            "all_cores_sample": "%d blocks, one block per thread" % len(sample_blocks),
-            "libbz2_9_single_core_GBps": round(bz, 5)}
+    O.hd_decode(su, lens, codes, ns)
+    t_cpu = time.perf_counter() - t0
+    comp = units.size * 4.0
+    return {"workload": "configs[4] (one GPU's share): %d MiB of Binomial(255, 0.5) symbols, <= 11-bit length-limited codes, "
+                        "32-bit units, glcHdDecodeDevice" % mib,
+            "decode_GBps": round(n / m / 1e6, 3), "ms": round(m, 3), "units": int(units.size), "ratio": round(n / comp, 4),
+            "hbm_frac": round((comp + n) / m / 1e6 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": "rho R + 1 W per decoded byte",
+            "decoded_equals_original": True, "timing": "median of %d, hipEvents" % iters,
+            "cpu_port": {"value": round(ns / t_cpu / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
+                         "sample": "%d MiB bit-serial oracle decode" % (ns >> 20)}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gib", type=float, default=4.0, help="input per GPU (GiB)")
     ap.add_argument("--rows", type=int, default=256, help="blocks per batched call (plan rows)")
     ap.add_argument("--plans", type=int, default=3, help="plans (each with its own stream) per GPU")
-    ap.add_argument("--enc-threads", type=int, default=1,
-                    help="host threads (= plans) used by the timed encode leg; 2 x 128-block plans give +7-10 %% "
-                         "throughput, but kernels of concurrent sorts share the machine, so the per-launch duration "
-                         "that `roofline` reports no longer describes the kernel")
+    ap.add_argument("--enc-threads", type=int, default=1, help="host threads (= plans) used by the timed encode leg")
     ap.add_argument("--dec-threads", type=int, default=3, help="host threads (= plans) used by the decode leg")
+    ap.add_argument("--data", choices=["auto", "zipf", "float"], default="auto",
+                    help="auto: configs[1] Zipf bytes at N = 1, configs[3] float32-as-bytes at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--enc-pipeline", action="store_true",
-                    help="stage pipelining in the timed encode leg too (+4-8 %% throughput; MTF + Huffman of batch i then "
-                         "share the machine with the sort of batch i+1, so the per-launch time of the roofline kernel is "
-                         "no longer its own)")
+    ap.add_argument("--main-only", action="store_true", help="skip the single_call / culzss / hd_decode / ceiling legs")
+    ap.add_argument("--culzss-gib", type=float, default=4.0)
+    ap.add_argument("--hd-mib", type=int, default=1024)
+    ap.add_argument("--enc-pipeline", action="store_true", help="stage pipelining in the timed encode leg too")
     ap.add_argument("--no-dec-pipeline", action="store_true", help="decode leg: no stage pipelining")
     ap.add_argument("--with-gather", action="store_true",
-                    help="N>1: include the RCCL gather of the bitstreams to rank 0 in the timed region")
+                    help="N>1: include the RCCL gather of records + streams to rank 0 in the timed region")
+    ap.add_argument("--sorter", type=int, default=0, help="0 bucket sorter (default), 1 general sorter only (A/B)")
     args = ap.parse_args()
 
     import numpy as np
@@ -121,11 +333,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
-    # GLC_BENCH_ONE_DEVICE=1: dry run of the N > 1 code path on a one-GPU box (all ranks share device 0 and
-    # talk over gloo; RCCL refuses two ranks on one device).  Not a measurement.
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`" % (args.gpus, args.gpus))
+    # GLC_BENCH_ONE_DEVICE=1: dry run of the N > 1 code path on a one-GPU box (all ranks share device 0 and talk over
+    # gloo; RCCL refuses two ranks on one device).  Not a measurement.
     one_device = os.environ.get("GLC_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local = 0
@@ -139,13 +350,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     glc = _load("glc_binding", os.path.join(PKG, "glc_binding.py"))
-    glc.lib()                                             # fails loudly if the HIP library is missing
-    gather_mod = _load("glc_dist", os.path.join(PKG, "dist_gather.py"))
+    L = glc.lib()                                         # fails loudly if the HIP library is missing
+    ex = _load("glc_dist", os.path.join(PKG, "dist_gather.py"))
 
+    kind = args.data if args.data != "auto" else ("zipf" if world == 1 else "float")
+    gen_blocks = zipf_blocks_on_device if kind == "zipf" else float_blocks_on_device
     nblocks = max(1, int(args.gib * 1024))
     rows = min(args.rows, nblocks)
     n = MiB
-    d_in = zipf_blocks_on_device(torch, dev, nblocks, rank, world)
+    d_in = gen_blocks(torch, dev, nblocks, rank, world)
     nsub = n // 4096
     stride = glc.compressed_stride_words(n)
     out = dict(bwt_index=torch.empty(nblocks, dtype=torch.int32, device=dev),
@@ -155,14 +368,7 @@ def main():
                words=torch.empty(nblocks * stride, dtype=torch.int32, device=dev))
     compact = torch.empty(nblocks * stride, dtype=torch.int32, device=dev)
     compact_off = torch.empty(nblocks + 1, dtype=torch.int64, device=dev)
-    L = glc.lib()
     ctx = glc.Cudpp()
-    # CUDPP's convention is one plan per host thread.  Several plans driven by their own host threads and
-    # streams keep more of the machine busy than one (the sort of a batch is a chain of latency-bound
-    # kernels with one host round trip per round): measured on MI355X, 4 GiB: 1 plan x 256 blocks 21.2 GB/s
-    # encode / 27.2 decode, 2 x 128 23.6 / 27.8, 3 x 128 22.3 / 31.1, 3 x 256 23.0 / 30.4.  The timed encode
-    # leg defaults to ONE plan so that the dominant kernel's launch time (roofline) is its own; the decode
-    # leg uses all of them.
     nplans = max(1, args.plans)
     plans, streams = [], []
     for _ in range(nplans):
@@ -170,12 +376,14 @@ def main():
         st_ = torch.cuda.current_stream(dev) if nplans == 1 else torch.cuda.Stream(dev)
         pl.set_stream(st_.cuda_stream)
         pl.set_pipelining(bool(args.enc_pipeline))
+        pl.set_sorter(args.sorter)
         plans.append(pl)
         streams.append(st_)
     plan = plans[0]
     batches = list(range(0, nblocks, rows))
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=nplans)
+    flagged = [0]
 
     def run_threads(fn, nthreads):
         nthreads = max(1, min(nthreads, nplans))
@@ -195,6 +403,7 @@ def main():
                                     out["size"].data_ptr() + 4 * b0, out["words"].data_ptr() + 4 * stride * b0, stride, n, nb)
             if rc != 0:
                 raise RuntimeError("glcCompressBatch -> %d" % rc)
+            flagged[0] += pl.last_flagged_blocks()
         pl.synchronize()
 
     def encode_all():
@@ -205,12 +414,14 @@ def main():
             raise RuntimeError("glcCompactStreams -> %d" % rc)
         plan.synchronize()                                    # the compacted streams are complete for any stream
 
+    def exchange():
+        return ex.gather_blocks(dist, torch, compact, compact_off, ex.pack_records(torch, out, nblocks, nsub), dst=0)
+
     def step():
         # the hot path: every rank encodes its own blocks; nothing crosses GPUs.
-        # --with-gather puts the result collection on rank 0 inside the timed region as well.
         encode_all()
         if world > 1 and args.with_gather:
-            return gather_mod.gather_streams(dist, torch, compact, compact_off, dst=0)
+            return exchange()
         return None
 
     def barrier():
@@ -223,34 +434,76 @@ def main():
     for pl in plans:
         pl.synchronize()
         pl.enable_timing(3)
+    flagged[0] = 0
     barrier()
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         gathered = step()
+        step_s.append(time.perf_counter() - ts)
     barrier()
     t1 = time.perf_counter()
-    kp = {"ms": 0.0, "launches": 0, "bytes": 0.0}
+    kernels = {}
     for pl in plans:
         pl.synchronize()
-        k1 = pl.kernel_profile()
-        for key in kp:
-            kp[key] += k1[key]
+        for name, k in pl.kernel_profiles().items():
+            a = kernels.setdefault(name, dict(ms=0.0, launches=0, units=0.0))
+            for key in a:
+                a[key] += k[key]
     stage_ms = plan.last_timing()
     for pl in plans:
         pl.enable_timing(0)
 
-    # result collection (the one exchange step of the multi-GPU path), timed on its own
-    gather_ms = None
+    # result collection (the one exchange step of the multi-GPU path), timed on its own, then checked on rank 0
+    gather_info = None
     if world > 1:
         barrier()
         tg0 = time.perf_counter()
-        gathered = gather_mod.gather_streams(dist, torch, compact, compact_off, dst=0)
+        gathered = exchange()
         barrier()
         gather_ms = (time.perf_counter() - tg0) * 1e3
+        gather_info = {"ms": round(gather_ms, 2),
+                       "what": "all_gather of {blocks, words}, gather of per-block records {size, bwtIndex, hist[256], "
+                               "encodeOffset[256]}, exact-length gather-v of the streams (grouped RCCL send/recv), outside "
+                               "the timed region"}
+        if rank == 0 and not args.no_verify:
+            # (a) gathered == what ONE process produces: rank 0 regenerates sampled blocks of every rank and encodes them
+            # (b) rank 0 DECODES gathered blocks of every rank back to the regenerated input
+            per = min(8, nblocks)
+            idx = sorted(set(int(x) for x in np.linspace(0, nblocks - 1, per).astype(int)))
+            okc = okd = tot = 0
+            with glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=len(idx)) as vp:
+                for r in range(world):
+                    xin = torch.cat([gen_blocks(torch, dev, 1, r + i * world, 1) for i in idx])
+                    ref = glc.compress_batch(vp, xin, n, len(idx))
+                    vp.synchronize()
+                    rs = ref["size"].cpu().numpy()
+                    recs = torch.stack([gathered["records"][r][i] for i in idx])
+                    words = [ex.block_of(gathered, r + i * world)[0] for i in idx]
+                    for k in range(len(idx)):
+                        tot += 1
+                        okc += int(int(recs[k][0].item()) == int(rs[k]) and
+                                   torch.equal(words[k], ref["words"][k * stride: k * stride + int(rs[k])]))
+                    f = ex.unpack_records(torch, recs, nsub)
+                    goff = torch.zeros(len(idx) + 1, dtype=torch.int64, device=dev)
+                    goff[1:] = torch.cumsum(f["size"].to(torch.int64), 0)
+                    strided = torch.zeros(len(idx) * stride, dtype=torch.int32, device=dev)
+                    assert L.glcExpandStreams(vp.handle, torch.cat(words).data_ptr(), goff.data_ptr(), len(idx),
+                                              strided.data_ptr(), stride, None) == 0
+                    back = glc.decompress_batch(vp, dict(bwt_index=f["bwt_index"], hist=f["hist"], offsets=f["offsets"],
+                                                         words=strided, nsub=nsub, stride=stride), n, len(idx))
+                    vp.synchronize()
+                    okd += int(torch.equal(back, xin)) * len(idx)
+            gather_info["gathered_equals_single_process_streams"] = "%d/%d sampled blocks over all %d ranks" % (okc, tot, world)
+            gather_info["root_decodes_gathered_blocks"] = "%d/%d" % (okd, tot)
+            gather_info["gathered_words"] = int(sum(gathered["words"]))
+            if okc != tot or okd != tot:
+                raise RuntimeError("multi-GPU result check failed: %s" % gather_info)
         del gathered
 
-    # decode leg (not part of `value`): every block back through the HIP
-    # decoder, then the full-size property check decode(encode(x)) == x on all bytes
+    # decode leg (not part of `value`): every block back through the HIP decoder, then the
+    # full-size property check decode(encode(x)) == x on all bytes
     d_back = torch.empty_like(d_in)
 
     def dec_worker(t, nt):
@@ -270,17 +523,30 @@ def main():
 
     for pl in plans:                                          # second half of a call overlaps the first half of the next
         pl.set_pipelining(not args.no_dec_pipeline)
-
     decode_all()
     barrier()
     td0 = time.perf_counter()
     decode_all()
     barrier()
     td1 = time.perf_counter()
-    roundtrip_ok = bool(torch.equal(d_back, d_in))
-    if not roundtrip_ok:
+    if not bool(torch.equal(d_back, d_in)):
         raise RuntimeError("round trip failed: decode(encode(x)) != x")
     del d_back
+    # one plan, stages back to back: the decoder as a single caller sees it
+    for pl in plans:
+        pl.set_pipelining(False)
+    d_back1 = torch.empty(rows * n, dtype=torch.uint8, device=dev)
+    plan.synchronize()
+    t0d = time.perf_counter()
+    nrep = min(4, len(batches))
+    for b0 in batches[:nrep]:
+        nb = min(rows, nblocks - b0)
+        L.glcDecompressBatch(plan.handle, out["bwt_index"].data_ptr() + 4 * b0, out["hist"].data_ptr() + 1024 * b0,
+                             out["offsets"].data_ptr() + 4 * nsub * b0, nsub, out["words"].data_ptr() + 4 * stride * b0, stride,
+                             d_back1.data_ptr(), n, nb)
+    plan.synchronize()
+    dec1 = sum(min(rows, nblocks - b0) for b0 in batches[:nrep]) * n / (time.perf_counter() - t0d) / 1e9
+    del d_back1
     dec_elapsed = torch.tensor([td1 - td0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(dec_elapsed, op=dist.ReduceOp.MAX)
@@ -293,70 +559,120 @@ def main():
     total_bytes = float(nblocks) * n * world * args.steps
     value = total_bytes / elapsed / 1e9
 
-    # compression ratio + parity of a sample against the oracle (after the timed region)
+    # compression ratio + parity of 64 sampled blocks against the oracle (after the timed region)
     sizes = out["size"].cpu().numpy().astype(np.int64)
     ratio = float(nblocks * n) / float(sizes.sum() * 4)
-    verify = None
-    sample_host = []
+    verify, sample_host = None, []
     if rank == 0:
-        pick = sorted(set(int(x) for x in np.linspace(0, nblocks - 1, min(nblocks, max(16, os.cpu_count() or 16))).astype(int)))
+        nver = min(nblocks, 64)
+        pick = sorted(set(int(x) for x in np.linspace(0, nblocks - 1, nver).astype(int)))
         sample_host = [d_in[b * n:(b + 1) * n].cpu().numpy() for b in pick]
         if not args.no_verify:
             import oracle_lib as O
+            cores = effective_cores()
+            with ThreadPoolExecutor(max_workers=cores) as tp:           # the oracle is C behind ctypes: the GIL is released
+                wants = list(tp.map(O.compress, sample_host))
             okc = 0
-            for b, blk in zip(pick[:4], sample_host[:4]):
-                want = O.compress(blk)
+            for b, want in zip(pick, wants):
                 got = out["words"][b * stride: b * stride + int(sizes[b])].cpu().numpy().view(np.uint32)
                 okc += int(int(out["bwt_index"][b].item()) == want["bwt_index"] and int(sizes[b]) == want["size"]
-                           and np.array_equal(got, want["words"]))
-            verify = "%d/4 sampled blocks bit-exact vs oracle" % okc
-            if okc != 4:
+                           and np.array_equal(got, want["words"])
+                           and np.array_equal(out["hist"][b * 256:(b + 1) * 256].cpu().numpy().view(np.uint32), want["hist"]))
+            verify = "%d/%d sampled blocks bit-exact vs oracle" % (okc, len(pick))
+            if okc != len(pick):
                 raise RuntimeError("parity failure in bench sample: " + verify)
 
+    res = None
     if rank == 0:
-        avg_ms = kp["ms"] / max(1, kp["launches"])
-        per_launch_bytes = kp["bytes"] / max(1, kp["launches"])
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        rho = 1.0 / ratio
+        ktab = {}
+        for name, k in kernels.items():
+            avg = k["ms"] / max(1, k["launches"])
+            per_launch_units = k["units"] / max(1, k["launches"])
+            ab = ALG_BYTES.get(name)
+            if name == "k_huff_pack":
+                ab = 1.0 + rho
+            ach = per_launch_units * ab / (avg * 1e-3) / 1e9 if (ab and avg > 0) else None
+            ktab[name] = {"avg_launch_ms": round(avg, 4), "launches": k["launches"], "alg_bytes_per_input_byte": ab,
+                          "achieved_GBps": round(ach, 1) if ach else None,
+                          "hbm_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
+        dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
+        d = ktab.get(dom, {})
+        traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and dom:
             try:
-                traffic = json.load(open(tpath)).get("k_rs_onesweep8_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
+                tsrc = "profiles/pmc_traffic.json (offline rocprofv3 --pmc passes, %s)" % tj.get("collected", "see file")
             except Exception:
                 traffic = None
         res = {
             "metric": "encode+decode GB/s (input bytes) per GPU and whole-node; compression ratio parity",
             "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_median_rank0": round(statistics.median(step_s) * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]: %g GiB/GPU Zipf(1.0) bytes, 1 MiB blocks, cudppCompress BWT+MTF+Huffman encode"
-                                   % args.gib,
+            "config": {"workload": ("configs[1]: %g GiB/GPU Zipf(1.0) bytes" if kind == "zipf" else
+                                    "configs[3]: %g GiB/GPU random-float32-as-bytes, blocks round-robin over the GPUs") % args.gib
+                                   + ", 1 MiB blocks, cudppCompress BWT+MTF+Huffman encode",
                        "value_is": "encode input bytes of all ranks / wall time (inputs resident in HBM; no data-path collective"
-                                   + ("; RCCL gather of the bitstreams to rank 0 included)" if args.with_gather else ")"),
+                                   + ("; RCCL gather of records + streams to rank 0 included)" if args.with_gather else ")"),
                        "block_bytes": n, "blocks_per_gpu": nblocks, "batch_rows": rows,
                        "plans_per_gpu": nplans, "encode_host_threads": min(args.enc_threads, nplans),
                        "decode_host_threads": min(args.dec_threads, nplans),
+                       "suffix_sorter": {0: "bucket sorter (general sorter for flagged blocks)", 1: "general sorter only",
+                                         2: "general sorter, prefix doubling only"}[args.sorter],
+                       "blocks_sent_to_general_sorter": flagged[0],
                        "stage_pipelining": {"encode": bool(args.enc_pipeline), "decode": not args.no_dec_pipeline},
                        "parallelism": "blocks round-robin over %d GPU(s), no data-path collective" % world},
             "compression_ratio": round(ratio, 4),
             "decode_GBps": round(decode_gbps, 4),
+            "decode_one_plan_GBps": round(dec1, 4),
             "roundtrip": "decode(encode(x)) == x on all %d blocks per GPU" % nblocks,
             "frac_of_hbm_read_roofline": round(value / world / HBM_PEAK_GBPS, 6),
+            "frac_of_hbm_roofline_algorithmic_1_plus_rho": round((1 + rho) * value / world / HBM_PEAK_GBPS, 6),
             "stage_ms_last_batch": {"bwt": round(stage_ms[0], 3), "mtf": round(stage_ms[1], 3),
                                     "huffman": round(stage_ms[2], 3), "total": round(stage_ms[3], 3)},
-            "roofline": {"kernel": "glc::k_rs_onesweep<8, false> (stable LSD radix scatter with decoupled look-back, suffix sorter)",
-                         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "avg_launch_ms": round(avg_ms, 4), "launches": kp["launches"],
-                         "algorithmic_bytes_per_launch": round(per_launch_bytes, 1),
-                         "timing": "hipEvent pairs on the launch stream around every launch inside the timed region"},
+            "roofline": {"kernel": "glc::" + dom if dom else None, "bound": "hbm", "achieved": d.get("achieved_GBps"),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d.get("hbm_frac"), "traffic": traffic,
+                         "traffic_source": tsrc, "avg_launch_ms": d.get("avg_launch_ms"), "launches": d.get("launches"),
+                         "algorithmic_bytes_per_launch": (round(kernels[dom]["units"] / max(1, kernels[dom]["launches"])
+                                                                * d["alg_bytes_per_input_byte"], 1)
+                                                          if dom and d.get("alg_bytes_per_input_byte") else None),
+                         "timing": "hipEvent pairs on the launch stream around every launch inside the timed region",
+                         "note": "dominant = largest summed launch time of the encode pipeline; the per-kernel table is under `kernels`"},
+            "kernels": ktab,
             "parity": verify,
         }
-        if gather_ms is not None:
-            res["gather_to_rank0"] = {"ms": round(gather_ms, 2),
-                                      "what": "all_gather of totals + padded gather of the compacted streams (RCCL), outside the timed region"}
-        if not args.no_cpu_baseline and world == 1:          # host-side baseline: rank 0 at N=1 only
-            res["cpu_baseline"] = cpu_baseline(sample_host)
+        if gather_info is not None:
+            res["gather_to_rank0"] = gather_info
+
+    # the other configs' single-GPU figures, same run (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.main_only:
+        for pl in plans[1:]:
+            pl.close()
+        plans = plans[:1]
+        res["single_call"] = leg_single_call(torch, glc, dev, d_in[:n])
+        import ctypes
+        ms = ctypes.c_float(0)
+        if L.glcProbeStreamRead(d_in.data_ptr(), d_in.numel(), 5, ctypes.byref(ms), None) == 1:
+            res["stream_read_ceiling_GBps"] = round(d_in.numel() / (ms.value * 1e-3) / 1e9, 1)
+            res["stream_read_ceiling_note"] = "trivial uint4-per-lane read of the %g GiB input, 5 launches, hipEvents" % args.gib
+        del out, compact
+        torch.cuda.empty_cache()
+        log_sample = None
+        if args.culzss_gib > 0:
+            res["culzss"], log_sample = leg_culzss(torch, glc, dev, args.culzss_gib)
+            torch.cuda.empty_cache()
+        if args.hd_mib > 0:
+            res["hd_decode"] = leg_hd(torch, glc, dev, args.hd_mib)
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sample_host, log_sample)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(sample_host, None)
+    if rank == 0:
         print(json.dumps(res))
     pool.shutdown()
     for pl in plans:

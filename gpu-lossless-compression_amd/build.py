@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libglc_amd.so")
 SOURCES = ["cudpp_api.cpp", "bwt_sa.hip", "bwt_bucket.hip", "mtf.hip", "huffman.hip", "decode.hip", "culzss.hip",
-           "culzss_api.cpp", "hd_decode.hip"]
+           "culzss_api.cpp", "hd_decode.hip", "probe.hip"]
 
 
 def _newest_source_mtime():

@@ -463,14 +463,21 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     GLC_TRY(hipMemsetAsync(s.fs_flag, 0, (size_t)nblk * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_nflag, 0, 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_wlcnt, 0, (size_t)nblk * 4, st));
+    const double units = (double)n * nblk;
+    int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
                        s.fs_hist);
+    if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab);
+    pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
     hipLaunchKernelGGL(k_fs_part, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
                        nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag);
+    if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag);
+    pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
     hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, n, nbl, s.keyA, s.fs_kstride, s.fs_fill, s.fs_base,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt, fs_stop);
+    if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_ties, dim3(8, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag);

@@ -857,20 +857,7 @@ void sa_scratch_free(SaScratch &s)
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
-    for (auto &e : s.prof_ev) if (e) (void)hipEventDestroy(e);
     s = SaScratch();
-}
-
-// fold the finished event pairs into the running profile (stream must be idle)
-static void prof_collect(SaScratch &s)
-{
-    for (int i = 0; i < s.prof_used; i++) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.prof_ev[2 * i], s.prof_ev[2 * i + 1]) == hipSuccess) {
-            s.prof_ms += ms; s.prof_launches++; s.prof_bytes += 16.0 * s.prof_live[i];
-        }
-    }
-    s.prof_used = 0;
 }
 
 // one LSD sort = prehist + digitbase + npass onesweep launches; result ends in `*cur`
@@ -896,12 +883,7 @@ static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, con
         GLC_TRY(hipMemsetAsync(s.ticket, 0, (size_t)nblk * 4, st));
         // profiled kernel = k_rs_onesweep<8,false> (16 algorithmic bytes per live suffix); the text-sourced
         // first pass of round 0 is a different kernel (1 R + 8 W) and is left out
-        const bool prof = profile && s.prof && pp.bits[p] == 8 && !(p == 0 && src) && s.prof_used < 64;
-        if (prof) {
-            for (int k = 0; k < 2; k++)
-                if (!s.prof_ev[2 * s.prof_used + k]) GLC_TRY(hipEventCreate(&s.prof_ev[2 * s.prof_used + k]));
-            (void)hipEventRecord(s.prof_ev[2 * s.prof_used], st);
-        }
+        const int pi = (profile && s.prof && pp.bits[p] == 8 && !(p == 0 && src)) ? s.prof->begin(PROF_RS_ONESWEEP8, st) : -1;
         dim3 g(nblk, rs_tiles);
         if (pp.bits[p] == 8 && p == 0 && src)
             hipLaunchKernelGGL((k_rs_onesweep<8, true>), g, dim3(RS_NT), 0, st, cur, alt, cnt, nfixed, pp.shift[p],
@@ -915,10 +897,7 @@ static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, con
             hipLaunchKernelGGL(k_rs_onesweep<9>, g, dim3(RS_NT), 0, st, cur, alt, cnt, nfixed, pp.shift[p], s.tile_hist,
                                s.ticket, s.epoch, s.digit_base + p * SA_MAXRADIX, (uint32_t)(RS_MAXPASS * SA_MAXRADIX),
                                s.nmax, s.rs_tiles, s.d_max_cnt + 2);
-        if (prof) {
-            (void)hipEventRecord(s.prof_ev[2 * s.prof_used + 1], st);
-            s.prof_live[s.prof_used++] = live_total;
-        }
+        if (pi >= 0) s.prof->end(pi, live_total, st);
         uint64_t *x = cur; cur = alt; alt = x;
     }
     return hipGetLastError();
@@ -993,7 +972,6 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
         GLC_TRY(hipGetLastError());
         GLC_TRY(hipMemcpyAsync(s.h_max_cnt, s.d_max_cnt, 16, hipMemcpyDeviceToHost, st));
         GLC_TRY(hipStreamSynchronize(st));
-        if (s.prof) prof_collect(s);
         rounds++;
         const uint32_t maxc = s.h_max_cnt[0];
         live_total = (double)s.h_max_cnt[1];

@@ -14,6 +14,7 @@
 
 #include <new>
 #include <stdlib.h>
+#include <string.h>
 
 using namespace glc;
 
@@ -30,6 +31,7 @@ struct PlanBase {
     uint32_t *d_status = nullptr;
     uint32_t *h_status = nullptr;
     bool timing = false;
+    KernelProf prof;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     float last_ms[4] = {0, 0, 0, 0};
@@ -496,10 +498,13 @@ CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable)
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     p->timing = enable != 0;
     p->ev_valid = false;
-    if (SaScratch *s = sa_of(p)) {
-        s->prof = (enable & 2) != 0;
-        s->prof_ms = 0; s->prof_bytes = 0; s->prof_launches = 0; s->prof_used = 0;
-    }
+    p->prof.on = (enable & 2) != 0;
+    p->prof.reset();
+    if (SaScratch *s = sa_of(p)) s->prof = &p->prof;
+    if (p->config.algorithm == CUDPP_COMPRESS) {
+        CompressPlan *cp = static_cast<CompressPlan *>(p);
+        cp->mtf.prof = &p->prof; cp->huff.prof = &p->prof;
+    } else if (p->config.algorithm == CUDPP_MTF) static_cast<MtfPlan *>(p)->mtf.prof = &p->prof;
     return CUDPP_SUCCESS;
 }
 
@@ -524,14 +529,28 @@ CUDPPResult glcPlanLastSortStats(CUDPPHandle planHandle, unsigned int *flaggedBl
     return CUDPP_SUCCESS;
 }
 
+// call after glcPlanSynchronize (the event pairs are read when the plan's streams are idle)
+CUDPPResult glcPlanKernelProfileEx(CUDPPHandle planHandle, int index, char *name, size_t nameCap, double *out3)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out3) return CUDPP_ERROR_INVALID_HANDLE;
+    if (index < 0 || index >= PROF_NSLOT) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    p->prof.collect();
+    out3[0] = p->prof.ms[index]; out3[1] = (double)p->prof.launches[index]; out3[2] = p->prof.units[index];
+    if (name && nameCap) { strncpy(name, p->prof.name[index], nameCap - 1); name[nameCap - 1] = 0; }
+    return CUDPP_SUCCESS;
+}
+
+// the kernel with the largest accumulated launch time: {ms, launches, input bytes processed}; resets the profile
 CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE || !out3) return CUDPP_ERROR_INVALID_HANDLE;
-    SaScratch *s = sa_of(p);
-    if (!s) return CUDPP_ERROR_INVALID_PLAN;
-    out3[0] = s->prof_ms; out3[1] = (double)s->prof_launches; out3[2] = s->prof_bytes;
-    s->prof_ms = 0; s->prof_bytes = 0; s->prof_launches = 0;
+    p->prof.collect();
+    int best = 0;
+    for (int k = 1; k < PROF_NSLOT; k++) if (p->prof.ms[k] > p->prof.ms[best]) best = k;
+    out3[0] = p->prof.ms[best]; out3[1] = (double)p->prof.launches[best]; out3[2] = p->prof.units[best];
+    p->prof.reset();
     return CUDPP_SUCCESS;
 }
 
@@ -546,6 +565,19 @@ CUDPPResult glcCompactStreams(CUDPPHandle planHandle, const unsigned int *d_comp
     if (p->config.algorithm == CUDPP_COMPRESS) static_cast<CompressPlan *>(p)->join_side();
     return hip_result(compact_streams(p->stream, d_compressed, compressedStrideWords, d_compressedSize,
                                       (uint32_t)numBlocks, d_out, d_outOffsets));
+}
+
+CUDPPResult glcExpandStreams(CUDPPHandle planHandle, const unsigned int *d_in, const unsigned long long *d_inOffsets,
+                             size_t numBlocks, unsigned int *d_compressed, size_t compressedStrideWords,
+                             unsigned int *d_compressedSize)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    if (!d_in || !d_inOffsets || !d_compressed || numBlocks == 0 || compressedStrideWords == 0)
+        return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (p->config.algorithm == CUDPP_COMPRESS) static_cast<CompressPlan *>(p)->join_side();
+    return hip_result(expand_streams(p->stream, d_in, d_inOffsets, (uint32_t)numBlocks, d_compressed,
+                                     compressedStrideWords, d_compressedSize, p->d_status));
 }
 
 CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4)

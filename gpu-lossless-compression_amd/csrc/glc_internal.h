@@ -24,6 +24,56 @@ constexpr uint32_t ST_CAPACITY       = 2u;       // compressed stream would not 
 constexpr uint32_t ST_CORRUPT        = 4u;       // decoder: an offset, length or row index of the stream is out of range
 
 // ---------------------------------------------------------------------------
+// live per-kernel profile (glcPlanEnableTiming(plan, 3)): hipEvent pairs recorded on the launch stream around
+// the launches of the named kernels; durations are folded in when the plan's streams are idle
+// ---------------------------------------------------------------------------
+enum ProfSlot { PROF_FS_PART = 0, PROF_FS_SORT, PROF_MTF_ENCODE, PROF_HUFF_PACK, PROF_RS_ONESWEEP8, PROF_FS_HIST,
+                PROF_MTF_LISTS, PROF_HUFF_BUILD, PROF_NSLOT };
+struct KernelProf {
+    static constexpr int NPAIR = 4096;
+    bool       on = false;
+    const char *name[PROF_NSLOT] = {"k_fs_part", "k_fs_sort", "k_mtf_encode", "k_huff_pack", "k_rs_onesweep<8,false>",
+                                    "k_fs_hist", "k_mtf_chunk_lists+k_mtf_scan_lists", "k_huff_build"};
+    double     ms[PROF_NSLOT] = {}, units[PROF_NSLOT] = {};
+    long       launches[PROF_NSLOT] = {};
+    hipEvent_t ev[2 * NPAIR] = {};
+    int        pend_slot[NPAIR] = {};
+    double     pend_units[NPAIR] = {};
+    int        npend = 0;
+    long       dropped = 0;
+    int begin(int slot, hipStream_t st)
+    {
+        if (!on) return -1;
+        if (npend >= NPAIR) { dropped++; return -1; }
+        const int i = npend;
+        for (int k = 0; k < 2; k++)
+            if (!ev[2 * i + k] && hipEventCreate(&ev[2 * i + k]) != hipSuccess) return -1;
+        pend_slot[i] = slot;
+        (void)hipEventRecord(ev[2 * i], st);
+        return i;
+    }
+    void end(int i, double nunits, hipStream_t st)
+    {
+        if (i < 0) return;
+        (void)hipEventRecord(ev[2 * i + 1], st);
+        pend_units[i] = nunits;
+        npend = i + 1;
+    }
+    void collect()                               // every stream the events were recorded on must be idle
+    {
+        for (int i = 0; i < npend; i++) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) {
+                ms[pend_slot[i]] += t; units[pend_slot[i]] += pend_units[i]; launches[pend_slot[i]]++;
+            }
+        }
+        npend = 0;
+    }
+    void reset() { for (int k = 0; k < PROF_NSLOT; k++) { ms[k] = 0; units[k] = 0; launches[k] = 0; } npend = 0; dropped = 0; }
+    ~KernelProf() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+};
+
+// ---------------------------------------------------------------------------
 // suffix array scratch: everything for `rows` blocks of up to nmax elements
 // ---------------------------------------------------------------------------
 struct SaScratch {
@@ -59,14 +109,7 @@ struct SaScratch {
     uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
     uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build that took the general sorter
-    // optional live profile of the dominant kernel (k_rs_scatter<8>): HIP events on
-    // the launch stream around every launch, accumulated across sa_build calls
-    bool       prof = false;
-    hipEvent_t prof_ev[128] = {};
-    int        prof_used = 0;
-    double     prof_live[64] = {};               // live suffixes of the launch bracketed by event pair i
-    double     prof_ms = 0, prof_bytes = 0;
-    long       prof_launches = 0;
+    KernelProf *prof = nullptr;                  // owned by the plan
 };
 
 hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows);
@@ -92,6 +135,7 @@ hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *o
 // MTF
 // ---------------------------------------------------------------------------
 struct MtfScratch {
+    KernelProf *prof = nullptr;
     uint32_t nmax = 0, rows = 0, max_chunks = 0;
     uint8_t  *lists = nullptr;       // [rows][max_chunks][256] chunk-local recency lists, then start lists
     uint16_t *lens = nullptr;        // [rows][max_chunks]
@@ -109,6 +153,7 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
 // Huffman
 // ---------------------------------------------------------------------------
 struct HuffScratch {
+    KernelProf *prof = nullptr;
     uint32_t nmax = 0, rows = 0, max_sub = 0;
     uint32_t *sub_hist = nullptr;    // [rows][max_sub][256]
     uint32_t *codes = nullptr;       // [rows][257]
@@ -131,6 +176,9 @@ hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint
 
 hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride, const uint32_t *d_sizes,
                            uint32_t nblk, uint32_t *d_out, unsigned long long *d_off);
+
+hipError_t expand_streams(hipStream_t st, const uint32_t *d_in, const unsigned long long *d_off, uint32_t nblk,
+                          uint32_t *d_comp, size_t stride, uint32_t *d_sizes, uint32_t *d_status);
 
 // ---------------------------------------------------------------------------
 // decoder (round-trip parity only; the reference has no GPU decoder)

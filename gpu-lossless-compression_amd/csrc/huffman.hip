@@ -227,6 +227,29 @@ hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride
     return hipGetLastError();
 }
 
+// the mirror (decode side of the exchange): block b's words move from in[off[b] .. off[b+1]) back to the strided
+// layout the decoder reads; a block longer than its stride is cut and reported
+__global__ __launch_bounds__(256) void k_expand_copy(const uint32_t *__restrict__ in,
+                                                     const unsigned long long *__restrict__ off, size_t stride,
+                                                     uint32_t *__restrict__ comp, uint32_t *__restrict__ sizes,
+                                                     uint32_t *__restrict__ d_status)
+{
+    const uint32_t b = blockIdx.y;
+    unsigned long long sz = off[b + 1] - off[b];
+    if (sz > stride) { sz = stride; if (d_status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(d_status, ST_CAPACITY); }
+    const uint32_t *src = in + off[b];
+    uint32_t *dst = comp + (size_t)b * stride;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (uint32_t)sz; i += gridDim.x * 256) dst[i] = src[i];
+    if (sizes && blockIdx.x == 0 && threadIdx.x == 0) sizes[b] = (uint32_t)sz;
+}
+
+hipError_t expand_streams(hipStream_t st, const uint32_t *d_in, const unsigned long long *d_off, uint32_t nblk,
+                          uint32_t *d_comp, size_t stride, uint32_t *d_sizes, uint32_t *d_status)
+{
+    hipLaunchKernelGGL(k_expand_copy, dim3(32, nblk), dim3(256), 0, st, d_in, d_off, stride, d_comp, d_sizes, d_status);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 #define GLC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -283,8 +306,10 @@ hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s,
                       uint32_t *d_status)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
+    const int pi = s.prof ? s.prof->begin(PROF_HUFF_BUILD, st) : -1;
     hipLaunchKernelGGL(k_huff_build, dim3(nblk), dim3(256), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
                        s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status);
+    if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
 }
 
@@ -293,8 +318,10 @@ hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint
                      size_t comp_stride_words)
 {
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    const int pi = s.prof ? s.prof->begin(PROF_HUFF_PACK, st) : -1;
     hipLaunchKernelGGL(k_huff_pack, dim3(nsub, nblk), dim3(256), 0, st, mtf, mtf_stride, n, s.codes, s.lens,
                        d_offsets, offset_stride, d_compressed, comp_stride_words, (uint64_t)comp_stride_words);
+    if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
 }
 

@@ -249,14 +249,19 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
     dim3 g((nchunks + MTF_WAVES - 1) / MTF_WAVES, nblk), t(MTF_WAVES * 64);
+    const double units = (double)n * nblk;
+    int pi = s.prof ? s.prof->begin(PROF_MTF_LISTS, st) : -1;
     hipLaunchKernelGGL(k_mtf_chunk_lists, g, t, 0, st, in, in_stride, n, s.lists, s.lens, s.max_chunks);
     hipLaunchKernelGGL(k_mtf_scan_lists, dim3(nblk), dim3(64), 0, st, s.lists, s.lens, n, s.max_chunks);
+    if (pi >= 0) s.prof->end(pi, units, st);
+    pi = s.prof ? s.prof->begin(PROF_MTF_ENCODE, st) : -1;
     if (sub_hist)
         hipLaunchKernelGGL(k_mtf_encode<true>, g, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
                            out_stride, sub_hist);
     else
         hipLaunchKernelGGL(k_mtf_encode<false>, g, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
                            out_stride, sub_hist);
+    if (pi >= 0) s.prof->end(pi, units, st);
     return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcHuffmanEncodeBatch",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
@@ -99,9 +99,13 @@ def lib():
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
     L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
     L.glcPlanKernelProfile.argtypes = [sz, C.POINTER(C.c_double)]
+    L.glcPlanKernelProfileEx.argtypes = [sz, C.c_int, C.c_char_p, sz, C.POINTER(C.c_double)]
     L.glcCompactStreams.argtypes = [sz, vp, sz, vp, sz, vp, vp]
+    L.glcExpandStreams.argtypes = [sz, vp, vp, sz, vp, sz, vp]
     for name in CUDPP_SYMBOLS:
         getattr(L, name).restype = C.c_int
+    L.glcProbeStreamRead.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_float), vp]
+    L.glcProbeStreamRead.restype = C.c_int
     # CULZSS
     if hasattr(L, "compression_kernel_wrapper"):
         L.compression_kernel_wrapper.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -241,9 +245,21 @@ class Plan:
         _chk("glcPlanEnableTiming", lib().glcPlanEnableTiming(self.handle, int(mode)))
 
     def kernel_profile(self):
+        """dominant kernel {ms, launches, units}; resets the accumulators"""
         a = (C.c_double * 3)()
         _chk("glcPlanKernelProfile", lib().glcPlanKernelProfile(self.handle, a))
-        return dict(ms=a[0], launches=int(a[1]), bytes=a[2])
+        return dict(ms=a[0], launches=int(a[1]), units=a[2])
+
+    def kernel_profiles(self):
+        """{kernel name: dict(ms, launches, units)} of every profiled kernel (call after synchronize())"""
+        out, i = {}, 0
+        name = C.create_string_buffer(96)
+        a = (C.c_double * 3)()
+        while lib().glcPlanKernelProfileEx(self.handle, i, name, 96, a) == CUDPP_SUCCESS:
+            if a[1] > 0:
+                out[name.value.decode()] = dict(ms=a[0], launches=int(a[1]), units=a[2])
+            i += 1
+        return out
 
     def last_timing(self):
         a = (C.c_float * 4)()

@@ -199,11 +199,12 @@ CUDPPResult glcPlanSetPipelining(CUDPPHandle planHandle, int on);
 CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable);
 CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4);
 
-/* With glcPlanEnableTiming(plan, 3) the suffix sorter also brackets every launch
- * of its dominant kernel (the 8-bit stable radix scatter) with hipEvents on the
- * plan's stream.  out3 = {sum of launch durations in ms, number of launches,
- * algorithmic bytes moved by those launches (8 B read + 8 B written per live
- * suffix)}; reading resets the accumulators. */
+/* With glcPlanEnableTiming(plan, 3) the library also brackets every launch of its main kernels with hipEvents
+ * on the stream they are launched on.  After glcPlanSynchronize, glcPlanKernelProfileEx(plan, i, name, cap, out3)
+ * returns for slot i = 0, 1, ... (CUDPP_ERROR_ILLEGAL_CONFIGURATION past the last) the kernel's name and
+ * out3 = {sum of launch durations in ms, number of launches, input bytes those launches processed};
+ * glcPlanKernelProfile returns the slot with the largest total and resets the accumulators. */
+CUDPPResult glcPlanKernelProfileEx(CUDPPHandle planHandle, int index, char *name, size_t nameCap, double *out3);
 CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3);
 
 /* The Huffman half of cudppCompress on caller-supplied symbols (what the pipeline feeds with the MTF output):
@@ -229,6 +230,18 @@ CUDPPResult glcPlanLastSortStats(CUDPPHandle planHandle, unsigned int *flaggedBl
 CUDPPResult glcCompactStreams(CUDPPHandle planHandle, const unsigned int *d_compressed,
                               size_t compressedStrideWords, const unsigned int *d_compressedSize,
                               size_t numBlocks, unsigned int *d_out, unsigned long long *d_outOffsets);
+
+/* The mirror of glcCompactStreams (decode side of the multi-GPU exchange): block b's words move from
+ * d_in[d_inOffsets[b] .. d_inOffsets[b+1]) back to the strided layout glcDecompressBatch reads;
+ * d_compressedSize (optional) receives the word counts. */
+CUDPPResult glcExpandStreams(CUDPPHandle planHandle, const unsigned int *d_in, const unsigned long long *d_inOffsets,
+                             size_t numBlocks, unsigned int *d_compressed, size_t compressedStrideWords,
+                             unsigned int *d_compressedSize);
+
+/* Measurement aid (not part of the reference): launches a trivial 16-byte-per-lane streaming-read kernel over
+ * d_buf `iters` times on `stream` and returns the average launch duration in *ms -- the read ceiling of this
+ * box, measured in the same run as the numbers it is quoted beside.  Returns 1 on success. */
+int glcProbeStreamRead(const void *d_buf, size_t bytes, int iters, float *ms, void *stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ def main():
     if prof:
         md = os.path.join(HERE, tag + "_kernel_stats.md")
         open(md, "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --gib 4 --steps 1 --warmup 1 "
-                            "--no-cpu-baseline  (MI355X, %s)\n\n" % tag)
+                            "--no-cpu-baseline --main-only  (MI355X, %s)\n\n" % tag)
         subprocess.run([sys.executable, os.path.join(HERE, "summarize_rocpd.py"), prof, md], check=True,
                        capture_output=True)
     bj = os.path.join(out, tag + "_bench.json")
@@ -56,9 +56,23 @@ def main():
                 return v
         return None
     o8 = find("k_rs_onesweep<8, false") or find("k_rs_onesweep<8")
+    # per-launch HBM bytes of the kernels bench.py profiles live (its `roofline.traffic` reads this table), and the
+    # whole encode's HBM bytes per input byte (every glc:: kernel of one 256-block batch / 256 MiB)
+    short = {"k_fs_part": "k_fs_part(", "k_fs_sort": "k_fs_sort(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
+             "k_mtf_encode": "k_mtf_encode<", "k_huff_pack": "k_huff_pack(", "k_huff_build": "k_huff_build(",
+             "k_mtf_chunk_lists": "k_mtf_chunk_lists(", "k_mtf_scan_lists": "k_mtf_scan_lists(",
+             "k_rs_onesweep<8,false>": "k_rs_onesweep<8, false"}
+    per_launch = {}
+    for nm, sub in short.items():
+        v = find(sub)
+        if v:
+            per_launch[nm] = v["avg_hbm_bytes_per_launch"]
+    enc = ["k_fs_hist", "k_fs_part", "k_fs_sort", "k_fs_ties", "k_mtf_chunk_lists", "k_mtf_scan_lists", "k_mtf_encode",
+           "k_huff_build", "k_huff_pack"]
+    enc_bytes = sum(per_launch.get(k, 0) for k in enc)
     res = {
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --gib 0.25 --steps 1 "
-                   "--warmup 0 --no-cpu-baseline --no-verify (one pass per counter; MI355X; tag %s)" % tag,
+                   "--warmup 0 --no-cpu-baseline --no-verify --main-only (one pass per counter; MI355X; tag %s)" % tag,
         "units": "rocprofv3 reports KB; bytes = KB*1024 * correction",
         "calibration": {
             "fetch": "a kernel that streams exactly 8 B x 2^28 suffix words (2097152 KB) reported FETCH_SIZE "
@@ -66,6 +80,11 @@ def main():
             "write": "k_sa_init_keys writes exactly 2097152 KB; WRITE_SIZE reported 2097152.0 KB -> correction x1.0000",
         },
         "fetch_correction": FETCH_CORR, "write_correction": WRITE_CORR,
+        "collected": tag,
+        "hbm_bytes_per_launch": per_launch,
+        "encode_hbm_bytes_per_input_byte": round(enc_bytes / float(256 << 20), 2) if enc_bytes else None,
+        "encode_hbm_bytes_note": "sum over the encode kernels of one 256-block launch each / 256 MiB "
+                                 "(BWT: k_fs_hist, k_fs_part, k_fs_sort, k_fs_ties; MTF; Huffman)",
         "k_rs_onesweep8_hbm_bytes_per_launch": o8["avg_hbm_bytes_per_launch"] if o8 else None,
         "kernels": kernels,
     }
