@@ -14,9 +14,9 @@
 //   2. k_mtf_scan_lists   one wave per block folds the chunk lists left to
 //      right with the associative operator  S' = P ++ (S \ P)  to get the MTF
 //      list at the start of every chunk (wave-wide filter: 4 ballots / fold).
-//   3. k_mtf_encode       one wave per chunk keeps the 256-entry list in 64
-//      VGPR lanes x 4 packed bytes; per input byte: SWAR zero-byte test +
-//      ballot finds the position, one cross-lane shift rotates the prefix.
+//   3. k_mtf_encode       MTF as dominance counting over previous-occurrence
+//      timestamps (see the kernel): four chunks per wave, one per 16-lane DPP row;
+//      no serial list, no per-byte dependency chain.
 #include "glc_device.h"
 #include "glc_internal.h"
 
@@ -25,6 +25,13 @@ namespace glc {
 constexpr int MTF_WAVES = 4;                       // waves per workgroup
 
 // --- 1. chunk-local recency lists ------------------------------------------
+// list = distinct symbols of the chunk, most recent first = the symbols sorted by the ORDER INDEX o (0 = last byte
+// of the chunk) of their most recent occurrence.  That minimum does not depend on the order the bytes are looked at,
+// so the wave does not walk the chunk batch by batch behind one 64-byte load at a time (a memory latency per half
+// cache line: 0.30 ms per 256 MiB, 0.9 TB/s): every lane loads its 4 x 16 bytes up front and lowers
+// first[sym] with an LDS atomicMin only when a plain read says it would (most recent bytes first, so after the
+// first few dozen bytes almost nothing passes the test); the symbols are then ranked by first[] through a 4096-bit
+// occupancy bitmap + prefix popcounts.
 __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_chunk_lists(const uint8_t *__restrict__ in,
                                                                    size_t in_stride, uint32_t n,
                                                                    uint8_t *__restrict__ lists,
@@ -32,34 +39,61 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_chunk_lists(const uint8_
                                                                    uint32_t max_chunks)
 {
     __shared__ uint32_t s_first[MTF_WAVES][256];
+    __shared__ unsigned long long s_bm[MTF_WAVES][64];
+    __shared__ uint32_t s_cum[MTF_WAVES][64];
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const uint32_t chunk = blockIdx.x * MTF_WAVES + w;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
     if (chunk >= nchunks) return;                           // whole wave exits together
-    const uint32_t lo = chunk * MTF_CHUNK, hi = min(n, lo + MTF_CHUNK);
+    const uint32_t lo = chunk * MTF_CHUNK, hi = min(n, lo + MTF_CHUNK), C = hi - lo;
     const uint8_t *src = in + (size_t)b * in_stride;
     uint8_t *L = lists + ((size_t)b * max_chunks + chunk) * 256;
     uint32_t *first = s_first[w];
     for (int i = l; i < 256; i += 64) first[i] = 0xFFFFFFFFu;
+    s_bm[w][l] = 0;
     __builtin_amdgcn_wave_barrier();
-    uint32_t len = 0;
-    // order index o = hi-1-p : 0 is the most recent byte of the chunk
-    uint32_t sym_next = src[hi - 1 - (l < hi - lo ? l : 0u)];
-    for (uint32_t o0 = 0; o0 < hi - lo && len < 256; o0 += 64) {
-        const uint32_t o = o0 + l;
-        const bool valid = o < hi - lo;
-        const uint32_t sym = valid ? sym_next : 0u;
-        sym_next = src[hi - 1 - (o + 64 < hi - lo ? o + 64 : 0u)];               // in flight during this batch
-        if (valid) atomicMin(&first[sym], o);
-        __builtin_amdgcn_wave_barrier();
-        const bool isnew = valid && first[sym] == o;        // most recent occurrence of sym in the chunk
-        const uint64_t bal = __ballot(isnew);
-        if (isnew) L[len + mbcnt(bal)] = (uint8_t)sym;
-        len += (uint32_t)__popcll(bal);
-        __builtin_amdgcn_wave_barrier();
+    if (C == MTF_CHUNK && (reinterpret_cast<uintptr_t>(src + lo) & 15) == 0) {
+        // lane l of segment g holds order indices [1024 g + 16 l, +16): the 16 bytes at lo + 4096 - 1024 g - 16 (l + 1)
+        uint4 q[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            q[g] = *reinterpret_cast<const uint4 *>(src + lo + MTF_CHUNK - 1024 * g - 16 * (l + 1));
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t d[4] = {q[g].x, q[g].y, q[g].z, q[g].w};
+#pragma unroll
+            for (int k = 15; k >= 0; k--) {                   // byte k sits at order index 1024 g + 16 l + 15 - k
+                const uint32_t sym = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu, o = 1024u * g + 16u * l + 15u - k;
+                if (o < first[sym]) atomicMin(&first[sym], o);
+            }
+        }
+    } else {
+        for (uint32_t o = l; o < C; o += 64) {
+            const uint32_t sym = src[hi - 1 - o];
+            if (o < first[sym]) atomicMin(&first[sym], o);
+        }
     }
-    if (l == 0) lens[(size_t)b * max_chunks + chunk] = (uint16_t)len;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t f[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f[j] = first[4 * l + j];
+        if (f[j] != 0xFFFFFFFFu) atomicOr(&s_bm[w][f[j] >> 6], 1ull << (f[j] & 63));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t c = (uint32_t)__popcll(s_bm[w][l]);
+    const uint32_t inc = wave_incl_add(c);
+    s_cum[w][l] = inc - c;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (f[j] != 0xFFFFFFFFu) {
+            const uint32_t wd = f[j] >> 6, r = f[j] & 63;
+            L[s_cum[w][wd] + (uint32_t)__popcll(s_bm[w][wd] & ((1ull << r) - 1ull))] = (uint8_t)(4 * l + j);
+        }
+    }
+    if (l == 0) lens[(size_t)b * max_chunks + chunk] = (uint16_t)__builtin_amdgcn_readlane((int)inc, 63);
 }
 
 // --- 2. exclusive scan of the lists (in place: lists[c] becomes the MTF list
@@ -118,16 +152,22 @@ __global__ __launch_bounds__(64) void k_mtf_scan_lists(uint8_t *__restrict__ lis
 // symbols of the start list: the symbol at list position q "occurred" at -1-q).
 // The P values are distinct, and
 //     mtf[i] = #{ j in (P[i], i) : P[j] < P[i] }
-// (the symbols whose first occurrence after P[i] lies before i).  A wave evaluates
-// 64 positions at once:
+// (the symbols whose first occurrence after P[i] lies before i).  Positions are
+// evaluated a batch at a time:
 //   * j in earlier batches:  P[j] marks a "killed" timestamp; a 4352-bit bitmap of
 //     killed timestamps + per-word prefix counts in LDS answers
 //     #{j < base : P[j] < P[i]} with two LDS reads and a popcount; the j <= P[i]
 //     part of it is exactly P[i]+1.
-//   * j in the same batch:   T = #{k < lane : P[k] < P[lane]} by a 64-step
-//     readlane / compare / add-with-carry loop (3 VALU per step for 64 outputs).
-// No per-byte serial dependency chain and almost no scalar-unit work: the previous
-// kernel (one list rotation per input byte) was bound by instruction issue.
+//   * j in the same batch:   T = #{k < lane : P[k] < P[lane]} by sliding the P values
+//     up one lane per step (DPP) and counting -- the cost that sets the batch size:
+//     a 64-lane batch needs 63 steps (126 VALU for 64 symbols, half of the kernel,
+//     which is VALU-bound).  A batch is therefore a ROW of 16 lanes: every wave works
+//     on FOUR chunks at once, one per DPP row, so the slide is 15 steps of row_shr:1
+//     (which never crosses a row) for the same 64 symbols, and each row keeps its own
+//     last-occurrence table, bitmap and prefix counts.  1.76 -> ~1.1 ms per 256 MiB.
+constexpr int MTF_ROWS = 4;                                 // chunks per wave (one per 16-lane DPP row)
+constexpr int MTF_NWORDS = 80;                              // bitmap words per chunk: 68 used, 5 per lane of the row
+
 template <bool WITH_HIST>
 __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__restrict__ in,
                                                               size_t in_stride, uint32_t n,
@@ -136,57 +176,60 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
                                                               uint8_t *__restrict__ out, size_t out_stride,
                                                               uint32_t *__restrict__ sub_hist)
 {
-    constexpr int NW = (MTF_CHUNK + 256) / 64;                 // 68 bitmap words
-    __shared__ uint32_t s_hist[WITH_HIST ? MTF_WAVES : 1][256];
-    __shared__ int s_last[MTF_WAVES][256];
-    __shared__ unsigned long long s_bm[MTF_WAVES][NW + 4];
-    __shared__ uint32_t s_cum[MTF_WAVES][NW + 4];
-    const uint32_t b = blockIdx.y, l = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-    const uint32_t chunk = blockIdx.x * MTF_WAVES + w;
+    __shared__ uint32_t s_hist[WITH_HIST ? MTF_WAVES * MTF_ROWS : 1][128];   // two 16-bit counters per word (a chunk has <= 4096 symbols)
+    __shared__ int16_t s_last[MTF_WAVES * MTF_ROWS][256];
+    __shared__ unsigned long long s_bm[MTF_WAVES * MTF_ROWS][MTF_NWORDS];
+    __shared__ uint16_t s_cum[MTF_WAVES * MTF_ROWS][MTF_NWORDS];
+    const uint32_t b = blockIdx.y, l = threadIdx.x & 63, lr = l & 15, row = l >> 4;
+    const uint32_t w = threadIdx.x >> 6, slot = w * MTF_ROWS + row;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
-    if (chunk >= nchunks) return;
-    const uint32_t lo = chunk * MTF_CHUNK, C = min(n, lo + MTF_CHUNK) - lo;
+    const uint32_t chunk0 = (blockIdx.x * MTF_WAVES + w) * MTF_ROWS;       // first chunk of this wave
+    if (chunk0 >= nchunks) return;                                           // whole wave exits together
+    const uint32_t chunk = chunk0 + row;
+    const bool live = chunk < nchunks;
+    const uint32_t lo = (live ? chunk : chunk0) * MTF_CHUNK, C = live ? min(n, lo + MTF_CHUNK) - lo : 0u;
+    const uint32_t Cmax = min(n, chunk0 * MTF_CHUNK + MTF_CHUNK) - chunk0 * MTF_CHUNK;   // the wave's first chunk is its longest
     const uint8_t *src = in + (size_t)b * in_stride + lo;
     uint8_t *dst = out + (size_t)b * out_stride + lo;
-    int *last = s_last[w];
-    unsigned long long *bm = s_bm[w];
-    uint32_t *cum = s_cum[w];
+    int16_t *last = s_last[slot];
+    unsigned long long *bm = s_bm[slot];
+    uint16_t *cum = s_cum[slot];
     {
-        const uint32_t lw = reinterpret_cast<const uint32_t *>(lists + ((size_t)b * max_chunks + chunk) * 256)[l];
+        const uint4 lw = reinterpret_cast<const uint4 *>(lists + ((size_t)b * max_chunks + (live ? chunk : chunk0)) * 256)[lr];
+        const uint32_t q[4] = {lw.x, lw.y, lw.z, lw.w};
 #pragma unroll
-        for (int j = 0; j < 4; j++) last[(lw >> (8 * j)) & 0xFF] = -1 - (int)(4 * l + j);
-        bm[l] = 0; cum[l] = 0;
-        if (l < NW + 4 - 64) { bm[64 + l] = 0; cum[64 + l] = 0; }
-        if (WITH_HIST) for (int i = l; i < 256; i += 64) s_hist[w][i] = 0;
+        for (int j = 0; j < 16; j++) last[(q[j >> 2] >> (8 * (j & 3))) & 0xFF] = (int16_t)(-1 - (int)(16 * lr + j));
+#pragma unroll
+        for (int k = 0; k < 5; k++) { bm[5 * lr + k] = 0; cum[5 * lr + k] = 0; }
+        if (WITH_HIST) for (int i = lr; i < 128; i += 16) s_hist[slot][i] = 0;
         __builtin_amdgcn_wave_barrier();
     }
+    const uint64_t rowmask = 0xFFFFull << (16 * row);
     const uint64_t lt_mask = (1ull << l) - 1ull;
-    uint32_t sym_next = src[l < C ? l : 0u];
-    for (uint32_t base = 0; base < C; base += 64) {
-        const uint32_t i = base + l;
+    uint32_t sym_next = src[lr < C ? lr : 0u];
+    for (uint32_t base = 0; base < Cmax; base += 16) {
+        const uint32_t i = base + lr;
         const bool valid = i < C;
         const uint32_t sym = valid ? sym_next : 0u;
-        sym_next = src[i + 64 < C ? i + 64 : 0u];                                // in flight during this batch
-        // lanes of this batch holding the same symbol
-        const uint64_t peers = wave_match<8>(sym, __ballot(valid));
+        sym_next = src[i + 16 < C ? i + 16 : 0u];                                // in flight during this batch
+        // lanes of this row holding the same symbol
+        const uint64_t peers = wave_match<8>(sym, __ballot(valid)) & rowmask;
         const uint64_t before = peers & lt_mask;
         const bool hasprev = before != 0;
-        const int p = 63 - __builtin_clzll(before | 1ull);                       // previous lane with my symbol
+        const int p = (63 - __builtin_clzll(before | 1ull)) & 15;                // previous lane of the row with my symbol
         const bool last_in_batch = (peers >> l) == 1ull;
-        const int P = hasprev ? (int)base + p : last[sym];
-        // T = #{k < l : P[k] < P[l]}
-        // the (biased, strictly positive) P values slide up one lane per step (DPP wave_shr:1,
-        // lanes with no source read 0), so lane l meets P[l-1], P[l-2], ... P[0]; counting the
-        // LARGER ones lets the zero fill drop out: T = #{k < l : P[k] < P[l]} = l - G
+        const int P = hasprev ? (int)base + p : (int)last[sym];
+        // T = #{k < lr : P[k] < P[lr]}: the (biased, strictly positive) P values slide up one lane per step
+        // (DPP row_shr:1, lanes with no source read 0), so lane lr meets P[lr-1], ... P[0]; counting the
+        // LARGER ones lets the zero fill drop out: T = lr - G
         const uint32_t Pb = (uint32_t)(P + 257);
         uint32_t G = 0, slide = Pb;
 #pragma unroll
-        for (int k = 0; k < 63; k++) {
-            slide = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)slide, 0x138, 0xf, 0xf, true);
+        for (int k = 0; k < 15; k++) {
+            slide = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)slide, 0x111, 0xf, 0xf, true);
             G += (slide > Pb) ? 1u : 0u;
         }
-        const uint32_t T = l - G;
+        const uint32_t T = lr - G;
         uint32_t o;
         if (hasprev) o = T - (uint32_t)(p + 1);
         else {
@@ -197,29 +240,32 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             dst[i] = (uint8_t)o;
-            if (WITH_HIST) atomicAdd(&s_hist[w][o], 1u);
+            if (WITH_HIST) atomicAdd(&s_hist[slot][(o & 0xFF) >> 1], 1u << (16 * (o & 1)));
             const uint32_t bitx = (uint32_t)(P + 256);
             atomicOr(&bm[bitx >> 6], 1ull << (bitx & 63));                       // timestamp P is killed by i
-            if (last_in_batch) last[sym] = (int)i;
+            if (last_in_batch) last[sym] = (int16_t)i;
         }
         __builtin_amdgcn_wave_barrier();
-        // prefix counts of the killed-timestamp bitmap
+        // prefix counts of the killed-timestamp bitmap: 5 words per lane, scan across the row
         {
-            const uint32_t c = (uint32_t)__popcll(bm[l]);
-            const uint32_t inc = wave_incl_add(c);
-            cum[l] = inc - c;
-            const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
-            if (l == 0) {
-                uint32_t run = tot;
-                for (int q = 64; q < NW; q++) { cum[q] = run; run += (uint32_t)__popcll(bm[q]); }
-            }
+            uint32_t c[5], s = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) { c[k] = (uint32_t)__popcll(bm[5 * lr + k]); s += c[k]; }
+            uint32_t inc = s;
+            inc += GLC_DPP(inc, 0x111, 0xf);
+            inc += GLC_DPP(inc, 0x112, 0xf);
+            inc += GLC_DPP(inc, 0x114, 0xf);
+            inc += GLC_DPP(inc, 0x118, 0xf);
+            uint32_t run = inc - s;
+#pragma unroll
+            for (int k = 0; k < 5; k++) { cum[5 * lr + k] = (uint16_t)run; run += c[k]; }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (WITH_HIST) {
+    if (WITH_HIST && live) {
         __builtin_amdgcn_wave_barrier();
         uint32_t *H = sub_hist + ((size_t)b * max_chunks + chunk) * 256;
-        for (int i = l; i < 256; i += 64) H[i] = s_hist[w][i];
+        for (int i = lr; i < 256; i += 16) H[i] = (s_hist[slot][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
     }
 }
 
@@ -249,6 +295,7 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
     dim3 g((nchunks + MTF_WAVES - 1) / MTF_WAVES, nblk), t(MTF_WAVES * 64);
+    dim3 ge((nchunks + MTF_WAVES * MTF_ROWS - 1) / (MTF_WAVES * MTF_ROWS), nblk);      // encode: 4 chunks per wave
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_MTF_LISTS, st) : -1;
     hipLaunchKernelGGL(k_mtf_chunk_lists, g, t, 0, st, in, in_stride, n, s.lists, s.lens, s.max_chunks);
@@ -256,10 +303,10 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_MTF_ENCODE, st) : -1;
     if (sub_hist)
-        hipLaunchKernelGGL(k_mtf_encode<true>, g, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
+        hipLaunchKernelGGL(k_mtf_encode<true>, ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
                            out_stride, sub_hist);
     else
-        hipLaunchKernelGGL(k_mtf_encode<false>, g, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
+        hipLaunchKernelGGL(k_mtf_encode<false>, ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
                            out_stride, sub_hist);
     if (pi >= 0) s.prof->end(pi, units, st);
     return hipGetLastError();
