@@ -98,51 +98,106 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_chunk_lists(const uint8_
 
 // --- 2. exclusive scan of the lists (in place: lists[c] becomes the MTF list
 //        in force at the start of chunk c) -----------------------------------
-__global__ __launch_bounds__(64) void k_mtf_scan_lists(uint8_t *__restrict__ lists,
-                                                       const uint16_t *__restrict__ lens, uint32_t n,
-                                                       uint32_t max_chunks)
+// The operator  S' = P ++ (S \ P)  is associative, so the 256 folds of a 1 MiB block need not be one chain
+// (one wave per block, 0.15 ms with the rest of the machine idle): 16 waves per block
+//   A  each wave folds the lists of its 16 chunks into the group's combined list,
+//   B  wave 0 folds the 16 combined lists into the state at the start of every group,
+//   C  each wave walks its 16 chunks again from that state, publishing the start list of every chunk.
+constexpr int MSC_WAVES = 16, MSC_GROUP = 16;
+
+// next[0 .. m) = P (entries 4l .. 4l+3 in p4), then the entries of cur[0 .. ls) not in P, in order.  Returns the new length.
+__device__ __forceinline__ uint32_t mtf_fold(const uint8_t *cur, uint8_t *next, uint8_t *inp, uint32_t p4, uint32_t m,
+                                             uint32_t ls, uint32_t l)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_state[2][256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_inp[256];
-    const uint32_t b = blockIdx.x, l = threadIdx.x;
-    const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
-    int cur = 0;
-    for (int i = l; i < 256; i += 64) s_state[0][i] = (uint8_t)i;
+    reinterpret_cast<uint32_t *>(inp)[l] = 0;
     __builtin_amdgcn_wave_barrier();
-    uint32_t p4n = reinterpret_cast<const uint32_t *>(lists + (size_t)b * max_chunks * 256)[l];
-    uint32_t mn = lens[(size_t)b * max_chunks];
-    for (uint32_t c = 0; c < nchunks; c++) {
-        uint8_t *L = lists + ((size_t)b * max_chunks + c) * 256;
-        const uint32_t m = mn;
-        // P = chunk-local list (registers), then publish the current state as the start list
-        const uint32_t p4 = p4n;                                       // entries 4l..4l+3 of P
-        if (c + 1 < nchunks) {                                         // next chunk's list: in flight during this fold
-            p4n = reinterpret_cast<const uint32_t *>(L + 256)[l];
-            mn = lens[(size_t)b * max_chunks + c + 1];
-        }
-        reinterpret_cast<uint32_t *>(L)[l] = reinterpret_cast<const uint32_t *>(s_state[cur])[l];
-        if (c + 1 == nchunks) break;
-        // membership table of P
-        reinterpret_cast<uint32_t *>(s_inp)[l] = 0;
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t e = 4 * l + j;
-            if (e < m) { const uint8_t sy = (uint8_t)(p4 >> (8 * j)); s_inp[sy] = 1; s_state[cur ^ 1][e] = sy; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // append the survivors of the old state in order
-        uint32_t base = m;
+    for (int j = 0; j < 4; j++) {
+        const uint32_t e = 4 * l + j;
+        if (e < m) { const uint8_t sy = (uint8_t)(p4 >> (8 * j)); inp[sy] = 1; next[e] = sy; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t base = m;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const uint8_t sy = s_state[cur][r * 64 + l];
-            const bool keep = !s_inp[sy];
-            const uint64_t bal = __ballot(keep);
-            if (keep) s_state[cur ^ 1][base + mbcnt(bal)] = sy;
-            base += (uint32_t)__popcll(bal);
+    for (int r = 0; r < 4; r++) {
+        const uint32_t idx = r * 64 + l;
+        const uint8_t sy = cur[idx];
+        const bool keep = idx < ls && !inp[sy];
+        const uint64_t bal = __ballot(keep);
+        if (keep) next[base + mbcnt(bal)] = sy;
+        base += (uint32_t)__popcll(bal);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return base;
+}
+
+__global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__restrict__ lists,
+                                                                  const uint16_t *__restrict__ lens, uint32_t n,
+                                                                  uint32_t max_chunks)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_state[MSC_WAVES][2][256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_inp[MSC_WAVES][256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_comb[MSC_WAVES][256];      // combined list of every group
+    __shared__ uint32_t s_clen[MSC_WAVES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_start[MSC_WAVES][256];     // state at the start of every group
+    __shared__ __attribute__((aligned(16))) uint8_t s_carry[256];                // state at the start of the round
+    const uint32_t b = blockIdx.x, l = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
+    uint8_t *LB = lists + (size_t)b * max_chunks * 256;
+    const uint16_t *NB = lens + (size_t)b * max_chunks;
+    if (w == 0) for (int i = l; i < 256; i += 64) s_carry[i] = (uint8_t)i;      // identity list before the first chunk
+    // 256 chunks (16 groups of 16) per round; cudppCompress blocks (n <= 2^20) need one round, MTF plans may be longer
+    for (uint32_t r0 = 0; r0 < nchunks; r0 += MSC_WAVES * MSC_GROUP) {
+        const uint32_t nch = min(nchunks - r0, (uint32_t)(MSC_WAVES * MSC_GROUP));
+        const uint32_t ngroups = (nch + MSC_GROUP - 1) / MSC_GROUP;
+        const uint32_t c0 = r0 + w * MSC_GROUP, c1 = min(r0 + nch, c0 + MSC_GROUP);
+        // A: combined list of the group (most recent first), built from an empty state
+        uint32_t p4[MSC_GROUP], mm[MSC_GROUP];
+#pragma unroll
+        for (int k = 0; k < MSC_GROUP; k++) {                  // all loads of the group in flight
+            const bool in = c0 + k < c1;
+            p4[k] = in ? reinterpret_cast<const uint32_t *>(LB + (size_t)(c0 + k) * 256)[l] : 0u;
+            mm[k] = in ? NB[c0 + k] : 0u;
         }
-        __builtin_amdgcn_wave_barrier();
-        cur ^= 1;
+        if (w < ngroups) {
+            int cur = 0;
+            uint32_t ls = 0;
+#pragma unroll
+            for (int k = 0; k < MSC_GROUP; k++)
+                if (c0 + k < c1) { ls = mtf_fold(s_state[w][cur], s_state[w][cur ^ 1], s_inp[w], p4[k], mm[k], ls, l); cur ^= 1; }
+            reinterpret_cast<uint32_t *>(s_comb[w])[l] = reinterpret_cast<const uint32_t *>(s_state[w][cur])[l];
+            if (l == 0) s_clen[w] = ls;
+        }
+        __syncthreads();
+        // B: state at the start of every group, and the state the next round starts from
+        if (w == 0) {
+            int cur = 0;
+            reinterpret_cast<uint32_t *>(s_state[0][0])[l] = reinterpret_cast<const uint32_t *>(s_carry)[l];
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t g = 0; g < ngroups; g++) {
+                reinterpret_cast<uint32_t *>(s_start[g])[l] = reinterpret_cast<const uint32_t *>(s_state[0][cur])[l];
+                (void)mtf_fold(s_state[0][cur], s_state[0][cur ^ 1], s_inp[0], reinterpret_cast<const uint32_t *>(s_comb[g])[l],
+                               s_clen[g], 256, l);
+                cur ^= 1;
+            }
+            reinterpret_cast<uint32_t *>(s_carry)[l] = reinterpret_cast<const uint32_t *>(s_state[0][cur])[l];
+        }
+        __syncthreads();
+        // C: start list of every chunk of the group
+        if (w < ngroups) {
+            int cur = 0;
+            reinterpret_cast<uint32_t *>(s_state[w][0])[l] = reinterpret_cast<const uint32_t *>(s_start[w])[l];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < MSC_GROUP; k++) {
+                if (c0 + k < c1) {
+                    reinterpret_cast<uint32_t *>(LB + (size_t)(c0 + k) * 256)[l] = reinterpret_cast<const uint32_t *>(s_state[w][cur])[l];
+                    if (c0 + k + 1 < c1) { (void)mtf_fold(s_state[w][cur], s_state[w][cur ^ 1], s_inp[w], p4[k], mm[k], 256, l); cur ^= 1; }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -299,7 +354,7 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_MTF_LISTS, st) : -1;
     hipLaunchKernelGGL(k_mtf_chunk_lists, g, t, 0, st, in, in_stride, n, s.lists, s.lens, s.max_chunks);
-    hipLaunchKernelGGL(k_mtf_scan_lists, dim3(nblk), dim3(64), 0, st, s.lists, s.lens, n, s.max_chunks);
+    hipLaunchKernelGGL(k_mtf_scan_lists, dim3(nblk), dim3(MSC_WAVES * 64), 0, st, s.lists, s.lens, n, s.max_chunks);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_MTF_ENCODE, st) : -1;
     if (sub_hist)
