@@ -319,12 +319,16 @@ def main():
     ap.add_argument("--main-only", action="store_true", help="skip the single_call / culzss / hd_decode / ceiling legs")
     ap.add_argument("--culzss-gib", type=float, default=4.0)
     ap.add_argument("--hd-mib", type=int, default=1024)
-    ap.add_argument("--enc-pipeline", action="store_true", help="stage pipelining in the timed encode leg too")
+    ap.add_argument("--no-enc-pipeline", action="store_true",
+                    help="timed encode leg: stages of a batch back to back on one stream (default: glcPlanSetPipelining -- the "
+                         "VALU-bound MTF + Huffman stages of batch i overlap the HBM/latency-bound suffix sort of batch i+1; "
+                         "+6-8 %% throughput, per-kernel launch times then include that sharing)")
     ap.add_argument("--no-dec-pipeline", action="store_true", help="decode leg: no stage pipelining")
     ap.add_argument("--with-gather", action="store_true",
                     help="N>1: include the RCCL gather of records + streams to rank 0 in the timed region")
     ap.add_argument("--sorter", type=int, default=0, help="0 bucket sorter (default), 1 general sorter only (A/B)")
     args = ap.parse_args()
+    args.enc_pipeline = not args.no_enc_pipeline
 
     import numpy as np
     import torch

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
         uint32_t g = 0;
         if (c) {
             g = atomicAdd(&fill[(size_t)b * FS_MAXNB + tid], c);
-            if (g + c > FS_CAP) atomicOr(&flag[b], 1u);
+            if (g + c > FS_FILLMAX) atomicOr(&flag[b], 1u);
         }
         s_start[tid] = start; s_gbase[tid] = g;
     }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict
     __shared__ uint32_t s_tmp[FS_MAXNB / 64 + 1];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t f = fill[(size_t)b * FS_MAXNB + tid];
-    if (f > FS_CAP) atomicOr(&flag[b], 1u);
+    if (f > FS_FILLMAX) atomicOr(&flag[b], 1u);
     fbase[(size_t)b * FS_MAXNB + tid] = block_excl_add<FS_MAXNB>(f, s_tmp);
 }
 
@@ -235,22 +235,28 @@ __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict
 // the critical path of every workgroup cost more than the whole sort -- but appended to a work list that
 // k_fs_ties resolves with one thread per member afterwards.
 // ---------------------------------------------------------------------------
+// LDS diet (40.7 KB: FOUR workgroups per CU, 8 waves per SIMD, where 52 KB allowed three): the bin counters are
+// 16-bit pairs (a bucket holds < 4096 words), the sorted words are capped at FS_FILLMAX (a fuller bucket flags its
+// block), and the BWT byte of an element is written over byte 0 of the word at its final position instead of into
+// a staging array -- every thread has its own words in registers by then, and the codes other threads still
+// compare live in bits 28..63.
 __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, const uint64_t *__restrict__ keys,
                                                     size_t kstride, const uint32_t *__restrict__ fill,
                                                     const uint32_t *__restrict__ fbase, uint32_t *__restrict__ flag,
                                                     uint8_t *__restrict__ bwt_out, size_t bwt_stride,
                                                     int *__restrict__ d_index, uint32_t *__restrict__ sa_out,
                                                     size_t sa_stride, uint4 *__restrict__ wl, uint32_t wl_cap,
-                                                    uint32_t *__restrict__ wl_count, int stop)
+                                                    uint32_t *__restrict__ wl_count)
 {
-    __shared__ uint64_t s_w[FS_CAP];
-    __shared__ uint32_t s_cnt[FS_BINS + 1];
-    __shared__ __attribute__((aligned(16))) uint8_t s_bwt[FS_CAP];
+    __shared__ uint64_t s_w[FS_FILLMAX];
+    __shared__ uint32_t s_cp[FS_BINS / 2];                     // bin counters, then bin starts: two 16-bit values per word
     __shared__ uint32_t s_tmp[FSS_NT / 64 + 1];
     __shared__ uint32_t s_deep, s_wl;
+    uint16_t *s16 = reinterpret_cast<uint16_t *>(s_cp);
+    uint8_t *s_b = reinterpret_cast<uint8_t *>(s_w);
     const uint32_t b = blockIdx.y, bk = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) { s_deep = flag[b]; s_wl = 0; }              // (one read: another bucket may flag the block meanwhile)
-    for (uint32_t i = tid; i < FS_BINS + 1; i += FSS_NT) s_cnt[i] = 0;
+    for (uint32_t i = tid; i < FS_BINS / 2; i += FSS_NT) s_cp[i] = 0;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
     const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
     const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
@@ -258,40 +264,51 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
         const uint32_t i = r * FSS_NT + tid;
-        w[r] = (i < c && c <= FS_CAP) ? K[i] : ~0ull;
+        w[r] = ~0ull;
+        if (r * FSS_NT < c && c <= FS_FILLMAX && i < c) w[r] = K[i];
     }
     __syncthreads();
     if (s_deep || c == 0) return;                              // flagged: the block goes through the general sorter
-    if (stop == 0) return;
     // 1. counting sort on the 12 bits below the bucket number (arrival order inside a bin: any order will do)
     const uint32_t bshift = 64 - nbl - FS_BIN_BITS;
     uint32_t rk[FSS_ITEMS];
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
+        rk[r] = 0;
+        if (r * FSS_NT >= c) continue;                         // (uniform: a bucket fills half of the slots on average)
         const uint32_t i = r * FSS_NT + tid;
-        rk[r] = i < c ? atomicAdd(&s_cnt[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)], 1u) : 0u;
+        const uint32_t bin = (uint32_t)(w[r] >> bshift) & (FS_BINS - 1), sh = 16 * (bin & 1);
+        if (i < c) rk[r] = (atomicAdd(&s_cp[bin >> 1], 1u << sh) >> sh) & 0xFFFFu;
     }
     __syncthreads();
-    if (stop == 1) { if (rk[0] == 77777) flag[b] = 1; return; }
     {
-        constexpr int PER = FS_BINS / FSS_NT;
-        uint32_t v[PER], sum = 0;
+        constexpr int PW = FS_BINS / 2 / FSS_NT;               // packed words per thread
+        uint32_t v[PW], sum = 0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { v[k] = s_cnt[tid * PER + k]; sum += v[k]; }
+        for (int k = 0; k < PW; k++) { v[k] = s_cp[tid * PW + k]; sum += (v[k] & 0xFFFFu) + (v[k] >> 16); }
         uint32_t run = block_excl_add<FSS_NT>(sum, s_tmp);
 #pragma unroll
-        for (int k = 0; k < PER; k++) { s_cnt[tid * PER + k] = run; run += v[k]; }
-        if (tid == FSS_NT - 1) s_cnt[FS_BINS] = run;
+        for (int k = 0; k < PW; k++) {
+            const uint32_t lo = run, hi = run + (v[k] & 0xFFFFu);
+            s_cp[tid * PW + k] = lo | (hi << 16);
+            run = hi + (v[k] >> 16);
+        }
     }
     __syncthreads();
-    if (stop == 2) { if (s_cnt[tid] == 77777) flag[b] = 1; return; }
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
+        if (r * FSS_NT >= c) continue;
         const uint32_t i = r * FSS_NT + tid;
-        if (i < c) s_w[s_cnt[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] = w[r];
+        if (i < c) s_w[s16[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] = w[r];
     }
     __syncthreads();
-    if (stop == 3) { if (s_w[tid] == 77777) flag[b] = 1; return; }
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) {                      // own words (byte 0 of a slot is overwritten below)
+        if (r * FSS_NT >= c) continue;
+        const uint32_t p = r * FSS_NT + tid;
+        w[r] = p < c ? s_w[p] : ~0ull;
+    }
+    __syncthreads();
     // 2. final position = bin start + number of smaller codes in the bin.  Elements with equal codes form a
     //    group [gp, gp + gs) whose internal order is not known yet.
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
@@ -301,11 +318,12 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
     for (int r = 0; r < FSS_ITEMS; r++) {
         const uint32_t p = r * FSS_NT + tid;
         pos[r] = 0; grp[r] = 0;
+        if (r * FSS_NT >= c) continue;
         if (p < c) {
-            const uint64_t wv = s_w[p];
+            const uint64_t wv = w[r];
             const uint32_t key = (uint32_t)(wv >> 28);         // inside a bin only the low 32 bits of the code can differ
             const uint32_t bin = (uint32_t)(wv >> bshift) & (FS_BINS - 1);
-            const uint32_t gs = s_cnt[bin], ge = s_cnt[bin + 1];
+            const uint32_t gs = s16[bin], ge = bin + 1 < FS_BINS ? (uint32_t)s16[bin + 1] : c;
             if (ge - gs > FS_MAX_GROUP) { s_deep = 1; }
             else {
                 uint32_t less = 0, eqb = 0, eqt = 0;
@@ -318,17 +336,15 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
                 const uint32_t idx = (uint32_t)(wv >> 8) & 0xFFFFFu;
                 if (eqt > 1) grp[r] = ((gs + less) << 16) | eqt;
                 else {
-                    s_bwt[pos[r]] = (uint8_t)wv;
+                    s_b[8 * pos[r]] = (uint8_t)wv;
                     if (SAo) SAo[pos[r]] = idx;
                     if (idx == 0 && d_index) d_index[b] = (int)(R0 + pos[r]);
                 }
             }
-            w[r] = wv;
         }
     }
-    __syncthreads();                                           // s_cnt (bin starts) is dead from here
+    __syncthreads();                                           // s_cp (bin starts) is dead from here
     if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-    if (stop == 4) { if (pos[0] == 77777) flag[b] = 1; return; }
     // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup
     //    (an atomic per group on a shared counter serialised the whole kernel: +2.4 ms per 256 blocks).
     bool any = false;
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
         if (grp[r]) {
             any = true;
             const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu;
-            if (pos[r] == gp) s_cnt[gp] = atomicAdd(&s_wl, gs);
+            if (pos[r] == gp) s16[gp] = (uint16_t)atomicAdd(&s_wl, gs);
         }
     }
     if (__syncthreads_or((int)any)) {
@@ -354,23 +370,22 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
 #pragma unroll
             for (int r = 0; r < FSS_ITEMS; r++) {
                 if (grp[r]) {
-                    const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, slot0 = base + s_cnt[gp];
+                    const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, slot0 = base + s16[gp];
                     WL[slot0 + (pos[r] - gp)] = make_uint4((uint32_t)(w[r] & FS_LOW_MASK), R0 + gp, slot0, gs);
                 }
             }
         }
     }
-    if (stop == 5) return;
     // 4. rows R0 .. R0 + c of the block's BWT (rows of tied groups are rewritten by k_fs_ties)
     if (O) {
         const uint32_t head = min(c, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u)) & 3u));
         const uint32_t nq = (c - head) / 4;
-        if (tid < head) O[tid] = s_bwt[tid];
-        for (uint32_t p = head + 4 * nq + tid; p < c; p += FSS_NT) O[p] = s_bwt[p];
+        if (tid < head) O[tid] = s_b[8 * tid];
+        for (uint32_t p = head + 4 * nq + tid; p < c; p += FSS_NT) O[p] = s_b[8 * p];
         for (uint32_t q = tid; q < nq; q += FSS_NT) {
             const uint32_t p = head + 4 * q;
-            const uint32_t v = (uint32_t)s_bwt[p] | ((uint32_t)s_bwt[p + 1] << 8) | ((uint32_t)s_bwt[p + 2] << 16) |
-                               ((uint32_t)s_bwt[p + 3] << 24);
+            const uint32_t v = (uint32_t)s_b[8 * p] | ((uint32_t)s_b[8 * p + 8] << 8) | ((uint32_t)s_b[8 * p + 16] << 16) |
+                               ((uint32_t)s_b[8 * p + 24] << 24);
             *reinterpret_cast<uint32_t *>(O + p) = v;
         }
     }
@@ -461,7 +476,6 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out)
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
-    static const int fs_stop = getenv("GLC_FS_STOP") ? atoi(getenv("GLC_FS_STOP")) : 99;
     GLC_TRY(hipMemsetAsync(s.fs_hist, 0, (size_t)nblk * 256 * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)nblk * FS_MAXNB * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_flag, 0, (size_t)nblk * 4, st));
@@ -480,7 +494,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag);
     pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
     hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, n, nbl, s.keyA, s.fs_kstride, s.fs_fill, s.fs_base,
-                       s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt, fs_stop);
+                       s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt);
     if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_ties, dim3(8, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);

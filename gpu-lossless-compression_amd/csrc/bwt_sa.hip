@@ -1,5 +1,7 @@
-// bwt_sa.hip -- suffix array + BWT for blocks of <= 2^20 bytes, many blocks per
-// launch (blockIdx.y = block).  gfx950 / wave64.
+// bwt_sa.hip -- the GENERAL suffix sorter (any data, any LCP depth): suffix array + BWT for blocks of
+// <= 2^20 bytes, many blocks per launch (blockIdx.y = block).  gfx950 / wave64.  sa_build() at the end of this
+// file runs the bucket sorter of bwt_bucket.hip first and sends only the blocks that one flags (deep common
+// prefixes: text, logs, long repeats) through the kernels below.
 //
 // Replaces, result-for-result, the reference's
 //   cudppSuffixArrayDispatch / ComputeSA     (cudpp-inpar/src/cudpp/app/sa_app.cu:125-298,365-391)
@@ -374,13 +376,10 @@ constexpr int MODE_ISA = 0, MODE_TEXT = 1;
 constexpr uint32_t TXT_GRP_SHIFT = 45, TXT_CODE_SHIFT = 20;
 
 // ---------------------------------------------------------------------------
-// One kernel per round.  Tiles of a block take tickets in arrival order and chain
-// their (last head, #unresolved, #unresolved groups) prefix through 8-byte
-// {flag, value} granules with a wave-parallel decoupled look-back (agent-scope
-// relaxed atomics: the granule IS the flag, so no fence is needed).  The sorted
-// words are staged through LDS once; the BWT byte T[SA-1] is gathered here, so
-// there is no separate gather kernel and (unless the caller wants it) no second
-// pass over the suffix array.
+// One kernel per round.  The sorted words are staged through LDS once; every tile gets its exclusive prefix
+// (last head, #unresolved, #unresolved groups) from k_rank_pre + k_rank_scan below, so tiles are static: no
+// tickets, no look-back, no spinning.  The BWT byte T[SA-1] is gathered here, so there is no separate gather
+// kernel and (unless the caller wants it) no second pass over the suffix array.
 // ---------------------------------------------------------------------------
 constexpr uint64_t LB_AGG = 1ull << 62, LB_PFX = 2ull << 62, LB_FLAGS = 3ull << 62;
 
@@ -495,7 +494,6 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
                                                          const uint32_t *__restrict__ pos,
                                                          const uint32_t *__restrict__ cnt, uint32_t nfixed,
                                                          unsigned long long *__restrict__ tile_state,
-                                                         uint32_t *__restrict__ ticket,
                                                          uint32_t *__restrict__ isa, uint32_t *__restrict__ sa,
                                                          uint64_t *__restrict__ key_next,
                                                          uint32_t *__restrict__ pos_next,
@@ -961,12 +959,12 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
                            s.max_tiles, cnt_next, s.d_max_cnt);
         if (!pos_cur)
             hipLaunchKernelGGL(k_sa_rank1<true>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
-                               (unsigned long long *)s.tile_state, s.ticket, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
+                               (unsigned long long *)s.tile_state, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
                                s.d_max_cnt, s.nmax, s.max_tiles, mode, text, text_stride, n, depth, bwt_out, bwt_stride,
                                d_index, s.d_max_cnt + 2);
         else
             hipLaunchKernelGGL(k_sa_rank1<false>, g, dim3(SA_THREADS), 0, st, cur, pos_cur, cnt_cur, live,
-                               (unsigned long long *)s.tile_state, s.ticket, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
+                               (unsigned long long *)s.tile_state, s.isa, s.sa, alt, pos_next, hd_next, cnt_next,
                                s.d_max_cnt, s.nmax, s.max_tiles, mode, text, text_stride, n, depth, bwt_out, bwt_stride,
                                d_index, s.d_max_cnt + 2);
         GLC_TRY(hipGetLastError());

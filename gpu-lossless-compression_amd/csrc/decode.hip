@@ -28,7 +28,7 @@
 #include <stdlib.h>
 #include "glc_device.h"
 #include "glc_internal.h"
-#include "huff_tree.cuh"
+#include "huff_tree.h"
 
 namespace glc {
 

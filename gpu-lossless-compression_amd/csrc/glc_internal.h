@@ -15,7 +15,8 @@ constexpr uint32_t MTF_CHUNK       = 4096;       // bytes of BWT output per wave
 
 // fast suffix sorter (bwt_bucket.hip): buckets of FS_AVG suffixes on average, FS_CAP words of slot each
 constexpr uint32_t FS_AVG   = 2048;
-constexpr uint32_t FS_CAP   = 4096;
+constexpr uint32_t FS_CAP   = 4096;             // slot size in the word array
+constexpr uint32_t FS_FILLMAX = 4032;            // fullest bucket the in-LDS sort takes (a fuller one flags its block)
 constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20
 
 // status bits accumulated on the device (PlanBase::d_status)

@@ -1,4 +1,4 @@
-// huff_tree.cuh -- the reference's Huffman tree shape, built by one wave64.
+// huff_tree.h -- the reference's Huffman tree shape, built by one wave64.
 // Shared by the encoder (huffman.hip) and the decoder (decode.hip): both must
 // derive the identical tree from the 256-bin histogram (+EOF with count 1).
 //

@@ -26,7 +26,7 @@
 // (compress_app.cu:106).
 #include "glc_device.h"
 #include "glc_internal.h"
-#include "huff_tree.cuh"
+#include "huff_tree.h"
 
 namespace glc {
 
