@@ -319,16 +319,19 @@ def main():
     ap.add_argument("--main-only", action="store_true", help="skip the single_call / culzss / hd_decode / ceiling legs")
     ap.add_argument("--culzss-gib", type=float, default=4.0)
     ap.add_argument("--hd-mib", type=int, default=1024)
-    ap.add_argument("--no-enc-pipeline", action="store_true",
-                    help="timed encode leg: stages of a batch back to back on one stream (default: glcPlanSetPipelining -- the "
-                         "VALU-bound MTF + Huffman stages of batch i overlap the HBM/latency-bound suffix sort of batch i+1; "
-                         "+6-8 %% throughput, per-kernel launch times then include that sharing)")
+    ap.add_argument("--enc-pipeline", action="store_true",
+                    help="stage pipelining in the timed encode leg (glcPlanSetPipelining: the VALU-bound MTF + Huffman stages of "
+                         "batch i overlap the suffix sort of batch i+1: +6-8 %% throughput).  Off by default so that the "
+                         "launch times under `roofline` / `kernels` are each kernel's own; the overlapped figure is measured "
+                         "in an extra pass and reported as `value_stage_overlap_GBps`")
     ap.add_argument("--no-dec-pipeline", action="store_true", help="decode leg: no stage pipelining")
+    ap.add_argument("--no-overlap-pass", action="store_true",
+                    help="skip the extra stage-overlap pass (profiles/collect.sh: keeps rocprofv3's per-kernel averages equal to "
+                         "the timed region's)")
     ap.add_argument("--with-gather", action="store_true",
                     help="N>1: include the RCCL gather of records + streams to rank 0 in the timed region")
     ap.add_argument("--sorter", type=int, default=0, help="0 bucket sorter (default), 1 general sorter only (A/B)")
     args = ap.parse_args()
-    args.enc_pipeline = not args.no_enc_pipeline
 
     import numpy as np
     import torch
@@ -458,6 +461,26 @@ def main():
     stage_ms = plan.last_timing()
     for pl in plans:
         pl.enable_timing(0)
+    # the same encode with stage overlap across batches (a library feature; not `value`): 2 passes, best of them
+    overlap_gbps = None
+    if not args.enc_pipeline and not args.no_overlap_pass:
+        for pl in plans:
+            pl.set_pipelining(True)
+        encode_all()
+        best = None
+        for _ in range(2):
+            barrier()
+            ts = time.perf_counter()
+            encode_all()
+            barrier()
+            dt = time.perf_counter() - ts
+            best = dt if best is None or dt < best else best
+        tov = torch.tensor([best], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tov, op=dist.ReduceOp.MAX)
+        overlap_gbps = float(nblocks) * n * world / float(tov.item()) / 1e9
+        for pl in plans:
+            pl.set_pipelining(False)
 
     # result collection (the one exchange step of the multi-GPU path), timed on its own, then checked on rank 0
     gather_info = None
@@ -600,6 +623,12 @@ def main():
             ktab[name] = {"avg_launch_ms": round(avg, 4), "launches": k["launches"], "alg_bytes_per_input_byte": ab,
                           "achieved_GBps": round(ach, 1) if ach else None,
                           "hbm_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
+            if name == "k_mtf_encode" and avg > 0:
+                # this kernel is bound by VALU issue, not by HBM: its loop body is 162 VALU instructions per 64 symbols
+                # (ISA of k_mtf_encode<true>); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 op
+                issued = per_launch_units / 64.0 * 162.0 / (avg * 1e-3)
+                ktab[name]["valu_issue_frac"] = round(issued / (1024 * 2.4e9 / 4), 3)
+                ktab[name]["bound"] = "VALU issue (162 wave64 VALU instructions per 64 symbols)"
         dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
         d = ktab.get(dom, {})
         traffic, tsrc = None, None
@@ -632,6 +661,7 @@ def main():
                        "stage_pipelining": {"encode": bool(args.enc_pipeline), "decode": not args.no_dec_pipeline},
                        "parallelism": "blocks round-robin over %d GPU(s), no data-path collective" % world},
             "compression_ratio": round(ratio, 4),
+            "value_stage_overlap_GBps": round(overlap_gbps, 4) if overlap_gbps else None,
             "decode_GBps": round(decode_gbps, 4),
             "decode_one_plan_GBps": round(dec1, 4),
             "roundtrip": "decode(encode(x)) == x on all %d blocks per GPU" % nblocks,

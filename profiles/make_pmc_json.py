@@ -29,7 +29,7 @@ def main():
     if prof:
         md = os.path.join(HERE, tag + "_kernel_stats.md")
         open(md, "w").write("# rocprofv3 --kernel-trace --stats -- python bench.py --gib 4 --steps 1 --warmup 1 "
-                            "--no-cpu-baseline --main-only  (MI355X, %s)\n\n" % tag)
+                            "--no-cpu-baseline --main-only --no-overlap-pass  (MI355X, %s)\n\n" % tag)
         subprocess.run([sys.executable, os.path.join(HERE, "summarize_rocpd.py"), prof, md], check=True,
                        capture_output=True)
     bj = os.path.join(out, tag + "_bench.json")
@@ -72,7 +72,7 @@ def main():
     enc_bytes = sum(per_launch.get(k, 0) for k in enc)
     res = {
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --gib 0.25 --steps 1 "
-                   "--warmup 0 --no-cpu-baseline --no-verify --main-only (one pass per counter; MI355X; tag %s)" % tag,
+                   "--warmup 0 --no-cpu-baseline --no-verify --main-only --no-overlap-pass (one pass per counter; MI355X; tag %s)" % tag,
         "units": "rocprofv3 reports KB; bytes = KB*1024 * correction",
         "calibration": {
             "fetch": "a kernel that streams exactly 8 B x 2^28 suffix words (2097152 KB) reported FETCH_SIZE "
