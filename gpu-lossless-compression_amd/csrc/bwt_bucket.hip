@@ -138,7 +138,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     if (base >= n) return;
     const uint8_t *T = text + (size_t)b * stride;
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
-    s_cnt[tid] = 0;
+    if (tid < FS_MAXNB) s_cnt[tid] = 0;
     const bool edge = base + FSP_TILE + 16 > n;
     if (base > 0 && !edge && (reinterpret_cast<uintptr_t>(T) & 3) == 0) {
         // aligned dwords of T[base - 4 ...], shifted by 3 bytes on the way into LDS
@@ -190,14 +190,14 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
 #undef FS_BYTE
     __syncthreads();
     {
-        const uint32_t c = s_cnt[tid];
+        const uint32_t c = tid < FS_MAXNB ? s_cnt[tid] : 0u;
         const uint32_t start = block_excl_add<FSP_NT>(c, s_tmp);
         uint32_t g = 0;
         if (c) {
             g = atomicAdd(&fill[(size_t)b * FS_MAXNB + tid], c);
             if (g + c > FS_FILLMAX) atomicOr(&flag[b], 1u);
         }
-        s_start[tid] = start; s_gbase[tid] = g;
+        if (tid < FS_MAXNB) { s_start[tid] = start; s_gbase[tid] = g; }
     }
     __syncthreads();
 #pragma unroll
