@@ -363,10 +363,12 @@ float glcLzssLastKernelMs(void)
 // (main.c:122-130), so its bytes are run-dependent; here the tail is zero-filled.
 //
 // The reference overlaps file I/O, PCIe and the GPU with four pthreads and a
-// 4-slot ledger.  Here the same overlap comes from two HIP streams working on
+// 4-slot ledger.  Here PCIe and the GPU overlap through two HIP streams working on
 // alternating groups of buffers (copy-in / kernels / copy-out of group g+1 run
 // while the host assembles group g) -- no thread ring, no busy-wait on
-// cudaStreamQuery (gpu_compress.cu:415-424).
+// cudaStreamQuery (gpu_compress.cu:415-424).  File I/O is NOT overlapped: the
+// *_file functions read the whole input and hold the whole output in memory
+// (inputs are bounded by the 4 GiB - 1 payload limit of the u32 offsets anyway).
 // ==========================================================================
 namespace {
 
