@@ -50,7 +50,7 @@ constexpr uint64_t FS_LOW_MASK = (1ull << 28) - 1;  // [index : 20 | bwt : 8]
 uint32_t fs_bucket_log2(uint32_t n)
 {
     uint32_t l = 0;
-    while (((uint64_t)FS_AVG << l) < n && l < 9) l++;
+    while (((uint64_t)FS_AVG << l) < n && l < FS_MAXNB_LOG2) l++;
     return l;
 }
 
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
         if (grp[r]) {
             any = true;
             const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu;
-            if (pos[r] == gp) s16[gp] = (uint16_t)atomicAdd(&s_wl, gs);
+            if (pos[r] == gp) reinterpret_cast<uint32_t *>(s_w)[2 * gp + 1] = atomicAdd(&s_wl, gs);   // (the codes are dead)
         }
     }
     if (__syncthreads_or((int)any)) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
 #pragma unroll
             for (int r = 0; r < FSS_ITEMS; r++) {
                 if (grp[r]) {
-                    const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, slot0 = base + s16[gp];
+                    const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, slot0 = base + reinterpret_cast<const uint32_t *>(s_w)[2 * gp + 1];
                     WL[slot0 + (pos[r] - gp)] = make_uint4((uint32_t)(w[r] & FS_LOW_MASK), R0 + gp, slot0, gs);
                 }
             }

@@ -17,7 +17,8 @@ constexpr uint32_t MTF_CHUNK       = 4096;       // bytes of BWT output per wave
 constexpr uint32_t FS_AVG   = 2048;
 constexpr uint32_t FS_CAP   = 4096;             // slot size in the word array
 constexpr uint32_t FS_FILLMAX = 4032;            // fullest bucket the in-LDS sort takes (a fuller one flags its block)
-constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20
+constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20 (256 buckets of 4096 words: k_fs_sort 1.62 vs 1.3 ms)
+constexpr uint32_t FS_MAXNB_LOG2 = 9;
 
 // status bits accumulated on the device (PlanBase::d_status)
 constexpr uint32_t ST_BLOCK_OVERFLOW = 1u;       // a 4096-symbol block needs > 1536 words
