@@ -326,11 +326,27 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
             const uint32_t gs = s16[bin], ge = bin + 1 < FS_BINS ? (uint32_t)s16[bin + 1] : c;
             if (ge - gs > FS_MAX_GROUP) { s_deep = 1; }
             else {
+                // a bin holds ~1.5 words seen from one of them: the first four are compared in straight-line code
+                // (four LDS reads in flight, no loop set-up, no exec juggling -- the compiler's 4x-unrolled loop with
+                // its remainder code cost ~100 VALU + 60 SALU per 64 elements), the rare rest in a plain loop
                 uint32_t less = 0, eqb = 0, eqt = 0;
-                for (uint32_t q = gs; q < ge; q++) {
-                    const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[q];
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) {
+                    const uint32_t q = gs + t;
+                    const bool in = q < ge;
+                    const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[in ? q : gs];
                     const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
-                    less += kq < key; eqt += kq == key; eqb += (kq == key) & (q < p);
+                    less += (in && kq < key) ? 1u : 0u;
+                    eqt += (in && kq == key) ? 1u : 0u;
+                    eqb += (in && kq == key && q < p) ? 1u : 0u;
+                }
+                if (ge - gs > 4) {
+#pragma clang loop unroll(disable)
+                    for (uint32_t q = gs + 4; q < ge; q++) {
+                        const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[q];
+                        const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
+                        less += kq < key; eqt += kq == key; eqb += (kq == key) & (q < p);
+                    }
                 }
                 pos[r] = gs + less + eqb;
                 const uint32_t idx = (uint32_t)(wv >> 8) & 0xFFFFFu;
