@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libglc_amd.so")
+LIB_PATH = os.environ.get("GLC_LIB") or os.path.join(HERE, "libglc_amd.so")    # GLC_LIB: A/B builds of the same library
 
 # enum values of include/cudpp.h (identical to the reference header)
 CUDPP_SUCCESS = 0
