@@ -855,6 +855,7 @@ void sa_scratch_free(SaScratch &s)
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
+    if (s.ev_flag) (void)hipEventDestroy(s.ev_flag);
     s = SaScratch();
 }
 
@@ -1015,16 +1016,23 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
     return hipSuccess;
 }
 
-hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
-                    SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out)
+// Two-phase form, so that a caller can queue the stages that FOLLOW the sort before the host waits for the sorter's
+// one readback (cudpp_api.cpp queues MTF + Huffman speculatively: the GPU never idles behind the wait, and the
+// rare batch with flagged blocks re-runs them):
+//   sa_build_begin   enqueues the bucket sorter and the readback of the flagged-block count (an event marks it);
+//                    with s.sorter != 0 it runs the whole general sort instead (which blocks per round).
+//   sa_build_finish  waits for that event only; if blocks were flagged, enqueues the general sorter for them.
+//                    *nflagged > 0 tells the caller that bwt_out / d_index of those blocks were rewritten.
+hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                          SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index)
 {
     if (n == 0 || n > s.nmax || n > MAX_BLOCK_ELEMS || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
-    if (rounds_out) *rounds_out = 0;
     s.last_flagged = nblk;
+    s.pending = false;
     if (s.sorter != 0) {
         const bool isa = s.force_isa;
         s.force_isa = isa || s.sorter == 2;
-        const hipError_t e = sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, rounds_out,
+        const hipError_t e = sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nullptr,
                                               nullptr, nblk);
         s.force_isa = isa;
         return e;
@@ -1032,11 +1040,32 @@ hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     // bucket sorter first; the suffix array itself is only written when it is the result asked for
     GLC_TRY(fs_build(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa));
     GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 4, s.fs_nflag, 4, hipMemcpyDeviceToHost, st));
-    GLC_TRY(hipStreamSynchronize(st));
+    if (!s.ev_flag) GLC_TRY(hipEventCreateWithFlags(&s.ev_flag, hipEventDisableTiming));
+    GLC_TRY(hipEventRecord(s.ev_flag, st));
+    s.pending = true;
+    return hipSuccess;
+}
+
+hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                           SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *nflagged)
+{
+    if (nflagged) *nflagged = 0;
+    if (!s.pending) return hipSuccess;                       // general sorter only: nothing was deferred
+    s.pending = false;
+    GLC_TRY(hipEventSynchronize(s.ev_flag));
     const uint32_t nflag = s.h_max_cnt[4];
     s.last_flagged = nflag;
     if (nflag == 0) return hipSuccess;
-    return sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, rounds_out, s.fs_lcnt, nflag);
+    if (nflagged) *nflagged = nflag;
+    return sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nullptr, s.fs_lcnt, nflag);
+}
+
+hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                    SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out)
+{
+    if (rounds_out) *rounds_out = 0;
+    GLC_TRY(sa_build_begin(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index));
+    return sa_build_finish(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nullptr);
 }
 
 // per-block exclusive scan of [tile][512] histograms (used by the decoder's LF construction)

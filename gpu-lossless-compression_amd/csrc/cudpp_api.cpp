@@ -269,33 +269,44 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     const uint32_t k = p->calls++ & 1u;
     hipStream_t s2 = st;                                       // stream of the MTF + Huffman stages
     if (p->pipelined) {
-        // The sort stays on the plan's stream (inputs keep their stream order; sa_build blocks the host
-        // once per round, so the input is consumed when the call returns).  MTF + Huffman move to the
-        // side stream, where they overlap the sort of the NEXT call; the outputs they write are complete
-        // after glcPlanSynchronize / glcCompactStreams / a device synchronize (include/cudpp.h).
+        // The sort stays on the plan's stream (inputs keep their stream order).  MTF + Huffman move to the side
+        // stream, where they overlap the sort of the NEXT call; the outputs they write are complete after
+        // glcPlanSynchronize / glcCompactStreams / a device synchronize (include/cudpp.h).
         e = p->pipeline_init();
         if (e != hipSuccess) return hip_result(e);
         bwt = k ? p->d_bwt2 : p->d_bwt;
         if (p->released_valid[k]) (void)hipStreamWaitEvent(st, p->ev_released[k], 0);   // this BWT half is free again
-        tm.mark(0);
-        e = sa_build(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
-        tm.mark(1);
-        (void)hipEventRecord(p->ev_sorted[k], st);
         s2 = p->side;
-        (void)hipStreamWaitEvent(s2, p->ev_sorted[k], 0);
-        if (p->timing) (void)hipEventRecord(p->ev_s2, s2);
-    } else {
-        tm.mark(0);
-        e = sa_build(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
-        tm.mark(1);
     }
-    if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
-    if (p->timing) (void)hipEventRecord(p->ev[2], s2);
-    if (e == hipSuccess) e = huff_build(s2, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
-                                        compressedStrideWords, p->d_status);
-    if (e == hipSuccess) e = huff_pack(s2, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
-                                       d_compressed, compressedStrideWords);
-    if (p->timing) (void)hipEventRecord(p->ev[3], s2);
+    // The stages after the sort are queued BEFORE the host waits for the sorter's one readback (how many blocks the
+    // bucket sorter handed to the general sorter): the GPU has MTF + Huffman to do while the host wakes up and queues
+    // the next call.  In the rare batch with flagged blocks they run again on the corrected BWT.
+    tm.mark(0);
+    e = sa_build_begin(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
+    tm.mark(1);
+    auto after_sort = [&](const uint32_t *redo_flag) {
+        if (p->pipelined) {
+            (void)hipEventRecord(p->ev_sorted[k], st);
+            (void)hipStreamWaitEvent(s2, p->ev_sorted[k], 0);
+            if (p->timing) (void)hipEventRecord(p->ev_s2, s2);
+        }
+        if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
+        if (p->timing) (void)hipEventRecord(p->ev[2], s2);
+        if (e == hipSuccess) e = huff_build(s2, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
+                                            compressedStrideWords, p->d_status, redo_flag);
+        if (e == hipSuccess) e = huff_pack(s2, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
+                                           d_compressed, compressedStrideWords);
+        if (p->timing) (void)hipEventRecord(p->ev[3], s2);
+    };
+    after_sort(p->sa.sorter == 0 ? p->sa.fs_flag : nullptr);   // blocks flagged by the bucket sorter are encoded again below
+    uint32_t nflag = 0;
+    if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
+    if (e == hipSuccess && nflag) {
+        // sa_build_finish has queued the general sorter for the flagged blocks on st.  Under pipelining the
+        // speculative MTF on s2 may still be reading `bwt` while it is rewritten: harmless, everything that pass
+        // wrote is written again by the pass below, which is ordered after the general sort (ev_sorted).
+        after_sort(nullptr);
+    }
     tm.done();
     if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], s2); p->released_valid[k] = true; p->side_busy = true; }
     return hip_result(e);

@@ -111,6 +111,8 @@ struct SaScratch {
     uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
     uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build that took the general sorter
+    hipEvent_t ev_flag = nullptr;                // marks the readback of fs_nflag (sa_build_begin / sa_build_finish)
+    bool      pending = false;
     KernelProf *prof = nullptr;                  // owned by the plan
 };
 
@@ -124,6 +126,12 @@ void       sa_scratch_free(SaScratch &s);
 hipError_t sa_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
                     SaScratch &s, uint8_t *bwt_out = nullptr, size_t bwt_stride = 0, int *d_index = nullptr,
                     int *rounds_out = nullptr);
+
+// two-phase form of sa_build (see bwt_sa.hip): stages that follow the sort can be queued between the two calls
+hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                          SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index);
+hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                           SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *nflagged);
 
 // the fast path alone (bwt_bucket.hip): enqueues only; flagged blocks are reported in s.fs_lcnt / s.fs_nflag
 hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk, SaScratch &s,
@@ -167,10 +175,12 @@ void       huff_scratch_free(HuffScratch &s);
 
 // sub-block histograms of caller-supplied symbols (stand-alone Huffman entry point)
 hipError_t huff_histogram(hipStream_t st, const uint8_t *sym, size_t stride, uint32_t n, uint32_t nblk, HuffScratch &s);
-// tree + codes + offsets (writes d_hist[b][256], d_offsets[b*offset_stride..], d_size[b])
+// tree + codes + offsets (writes d_hist[b][256], d_offsets[b*offset_stride..], d_size[b]).  redo_flag (optional):
+// blocks with a non-zero entry are going to be encoded again (speculative pass over blocks the bucket sorter has
+// flagged): their status bits are not raised.
 hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
                       uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size,
-                      size_t capacity_words, uint32_t *d_status);
+                      size_t capacity_words, uint32_t *d_status, const uint32_t *redo_flag = nullptr);
 // pack (reads mtf bytes, writes the stream)
 hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
                      HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride,

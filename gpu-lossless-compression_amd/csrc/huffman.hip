@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ lens_out,
                                                     uint32_t *__restrict__ d_offsets, size_t offset_stride,
                                                     uint32_t *__restrict__ d_size, uint64_t capacity_words,
-                                                    uint32_t *__restrict__ d_status)
+                                                    uint32_t *__restrict__ d_status,
+                                                    const uint32_t *__restrict__ redo_flag)
 {
     __shared__ uint32_t s_hist[257];
     __shared__ HuffTreeLds T;
@@ -107,11 +108,11 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
         const uint32_t off = block_excl_add<256>(item, s_tmp, &total);
         if (tid < nsub) {
             d_offsets[(size_t)b * offset_stride + tid] = off;
-            if (wd > HUFF_MAX_WORDS) atomicOr(d_status, ST_BLOCK_OVERFLOW);
+            if (wd > HUFF_MAX_WORDS && !(redo_flag && redo_flag[b])) atomicOr(d_status, ST_BLOCK_OVERFLOW);
         }
         if (tid == 0) {
             d_size[b] = total;
-            if ((uint64_t)total > capacity_words) atomicOr(d_status, ST_CAPACITY);
+            if ((uint64_t)total > capacity_words && !(redo_flag && redo_flag[b])) atomicOr(d_status, ST_CAPACITY);
         }
     }
 }
@@ -303,12 +304,12 @@ hipError_t huff_histogram(hipStream_t st, const uint8_t *sym, size_t stride, uin
 
 hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
                       uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size, size_t capacity_words,
-                      uint32_t *d_status)
+                      uint32_t *d_status, const uint32_t *redo_flag)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const int pi = s.prof ? s.prof->begin(PROF_HUFF_BUILD, st) : -1;
     hipLaunchKernelGGL(k_huff_build, dim3(nblk), dim3(256), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
-                       s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status);
+                       s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status, redo_flag);
     if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
 }
