@@ -472,13 +472,16 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
 }
 
 // blocks the fast path gave up on -> live counts for the general sorter
+// (`redo` is a per-call copy of the flags for the stages queued speculatively behind the sort: under stage
+//  pipelining the next call clears `flag` while they may still be reading)
 __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint32_t nblk, uint32_t *__restrict__ lcnt,
-                            uint32_t *__restrict__ nflag)
+                            uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nblk) {
         const uint32_t f = flag[b] ? n : 0u;
         lcnt[b] = f;
+        redo[b] = f;
         if (f) atomicAdd(nflag, 1u);
     }
 }
@@ -514,7 +517,8 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_ties, dim3(8, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
-    hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag);
+    hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
+                       s.fs_redo[s.parity & 1]);
     return hipGetLastError();
 }
 

@@ -828,6 +828,8 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.fs_base, (size_t)rows * FS_MAXNB * 4));
     GLC_TRY(A((void **)&s.fs_flag, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_lcnt, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.fs_redo[0], (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.fs_redo[1], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_nflag, 8));
     s.fs_wl_cap = nmax / 8 < 1024 ? 1024 : nmax / 8;
     GLC_TRY(A((void **)&s.fs_wl, (size_t)rows * s.fs_wl_cap * 16));
@@ -851,7 +853,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
+    void *ps[] = {s.keyA, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);

@@ -282,6 +282,7 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     // bucket sorter handed to the general sorter): the GPU has MTF + Huffman to do while the host wakes up and queues
     // the next call.  In the rare batch with flagged blocks they run again on the corrected BWT.
     tm.mark(0);
+    p->sa.parity = k;
     e = sa_build_begin(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
     tm.mark(1);
     auto after_sort = [&](const uint32_t *redo_flag) {
@@ -298,7 +299,7 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
                                            d_compressed, compressedStrideWords);
         if (p->timing) (void)hipEventRecord(p->ev[3], s2);
     };
-    after_sort(p->sa.sorter == 0 ? p->sa.fs_flag : nullptr);   // blocks flagged by the bucket sorter are encoded again below
+    after_sort(p->sa.sorter == 0 ? p->sa.fs_redo[k] : nullptr);   // blocks flagged by the bucket sorter are encoded again below
     uint32_t nflag = 0;
     if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
     if (e == hipSuccess && nflag) {

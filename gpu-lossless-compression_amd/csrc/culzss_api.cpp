@@ -30,6 +30,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     int cap = 0;                                // buf_length the scratch below was sized for
     uint8_t *d_packed = nullptr;
+    uint8_t *d_in = nullptr, *d_cand = nullptr; // the slot's own input / candidate buffers (see compression_kernel_wrapper)
     int *d_size = nullptr;
     void *d_work = nullptr;
     uint8_t *h_packed = nullptr;                // pinned
@@ -74,11 +75,13 @@ void init_locked()
 void free_slot(Slot &s)
 {
     if (s.d_packed) (void)hipFree(s.d_packed);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_cand) (void)hipFree(s.d_cand);
     if (s.d_size) (void)hipFree(s.d_size);
     if (s.d_work) (void)hipFree(s.d_work);
     if (s.h_packed) (void)hipHostFree(s.h_packed);
     if (s.h_size) (void)hipHostFree(s.h_size);
-    s.d_packed = nullptr; s.d_size = nullptr; s.d_work = nullptr; s.h_packed = nullptr; s.h_size = nullptr;
+    s.d_packed = nullptr; s.d_in = nullptr; s.d_cand = nullptr; s.d_size = nullptr; s.d_work = nullptr; s.h_packed = nullptr; s.h_size = nullptr;
     s.cap = 0; s.valid = false;
 }
 
@@ -88,6 +91,8 @@ bool ensure_slot(Slot &s, int buf_length)
     free_slot(s);
     const size_t stride = lzss_pack_stride(buf_length);
     if (!ok(hipMalloc((void **)&s.d_packed, stride), "slot packed")) return false;
+    if (!ok(hipMalloc((void **)&s.d_in, (size_t)buf_length), "slot in")) return false;
+    if (!ok(hipMalloc((void **)&s.d_cand, (size_t)2 * buf_length), "slot candidates")) return false;
     if (!ok(hipMalloc((void **)&s.d_size, sizeof(int)), "slot size")) return false;
     if (!ok(hipMalloc(&s.d_work, lzss_work_bytes(buf_length, 1)), "slot work")) return false;
     if (!ok(hipHostMalloc((void **)&s.h_packed, stride, hipHostMallocDefault), "slot pinned")) return false;
@@ -176,11 +181,16 @@ int compression_kernel_wrapper(unsigned char *buffer, int buf_length, unsigned c
     if (!ensure_slot(s, buf_length)) return 0;
     hipStream_t st = s.stream;
     const size_t stride = lzss_pack_stride(buf_length);
-    if (!ok(hipMemcpyAsync(in_d, buffer, (size_t)buf_length, hipMemcpyHostToDevice, st), "H2D")) return 0;
+    // The reference's pipeline hands EVERY ring slot the same in_d / out_d (culzss.c:85-86,108) and queues the slots
+    // on different streams without waiting (gpu_compress.cu:426-460): slot s+1's copy-in can overwrite what slot
+    // s's kernel is still reading.  The caller's device buffers are therefore accepted but not used: each slot
+    // stages through buffers of its own.
+    (void)in_d; (void)out_d;
+    if (!ok(hipMemcpyAsync(s.d_in, buffer, (size_t)buf_length, hipMemcpyHostToDevice, st), "H2D")) return 0;
     (void)hipEventRecord(s.e0, st);
-    if (!ok(lzss_encode(st, in_d, buf_length, 1, out_d, s.d_packed, s.d_size, s.d_work), "encode")) return 0;
+    if (!ok(lzss_encode(st, s.d_in, buf_length, 1, s.d_cand, s.d_packed, s.d_size, s.d_work), "encode")) return 0;
     (void)hipEventRecord(s.e1, st);
-    if (!ok(hipMemcpyAsync(compressed_buffer, out_d, (size_t)2 * buf_length, hipMemcpyDeviceToHost, st), "D2H cand")) return 0;
+    if (!ok(hipMemcpyAsync(compressed_buffer, s.d_cand, (size_t)2 * buf_length, hipMemcpyDeviceToHost, st), "D2H cand")) return 0;
     if (!ok(hipMemcpyAsync(s.h_packed, s.d_packed, stride, hipMemcpyDeviceToHost, st), "D2H packed")) return 0;
     if (!ok(hipMemcpyAsync(s.h_size, s.d_size, sizeof(int), hipMemcpyDeviceToHost, st), "D2H size")) return 0;
     s.key = compressed_buffer; s.len = buf_length; s.valid = true;

@@ -106,6 +106,8 @@ struct SaScratch {
     uint32_t *fs_fill = nullptr, *fs_base = nullptr;   // [rows][FS_MAXNB] bucket fill / rank base
     uint32_t *fs_flag = nullptr;                 // [rows] 1 = a bucket overflowed, 2 = deep (equal codes beyond the depth cap)
     uint32_t *fs_lcnt = nullptr;                 // [rows] n for flagged blocks, 0 otherwise
+    uint32_t *fs_redo[2] = {nullptr, nullptr};   // [rows] copies of fs_lcnt, one per call parity (read by the speculative Huffman pass)
+    uint32_t  parity = 0;                        // set by the caller before sa_build_begin
     uint32_t *fs_nflag = nullptr;                // [1] number of flagged blocks
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
     uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
