@@ -628,7 +628,7 @@ def main():
                 # (ISA of k_mtf_encode<true>); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 op
                 issued = per_launch_units / 64.0 * 162.0 / (avg * 1e-3)
                 ktab[name]["valu_issue_frac"] = round(issued / (1024 * 2.4e9 / 4), 3)
-                ktab[name]["bound"] = "VALU issue (162 wave64 VALU instructions per 64 symbols)"
+                ktab[name]["bound"] = "VALU issue + LDS latency at 4-5 waves per SIMD (162 wave64 VALU instructions per 64 symbols)"
         dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
         d = ktab.get(dom, {})
         traffic, tsrc = None, None
