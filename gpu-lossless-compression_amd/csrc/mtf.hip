@@ -213,13 +213,18 @@ __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__re
 //     killed timestamps + per-word prefix counts in LDS answers
 //     #{j < base : P[j] < P[i]} with two LDS reads and a popcount; the j <= P[i]
 //     part of it is exactly P[i]+1.
-//   * j in the same batch:   T = #{k < lane : P[k] < P[lane]} by sliding the P values
-//     up one lane per step (DPP) and counting -- the cost that sets the batch size:
-//     a 64-lane batch needs 63 steps (126 VALU for 64 symbols, half of the kernel,
-//     which is VALU-bound).  A batch is therefore a ROW of 16 lanes: every wave works
-//     on FOUR chunks at once, one per DPP row, so the slide is 15 steps of row_shr:1
-//     (which never crosses a row) for the same 64 symbols, and each row keeps its own
-//     last-occurrence table, bitmap and prefix counts.  1.76 -> ~1.1 ms per 256 MiB.
+//   * j in the same batch:   T = #{k < lane : P[k] < P[lane]} by meeting the P values of
+//     the lanes below through DPP shifts and counting -- the cost that sets the batch
+//     size: a 64-lane batch needs 63 steps.  A batch is therefore a ROW of 16 lanes: every
+//     wave works on FOUR chunks at once, one per DPP row, 15 steps of row_shr:k (which
+//     never crosses a row) for the same 64 symbols -- each step one v_sub_co_u32_dpp whose
+//     borrow a v_addc accumulates -- and each row keeps its own tables.
+//   * previous occurrence:   one table entry per symbol holds its last position (high half)
+//     and the lanes of the current batch that carry it (low half): every lane ORs its bit
+//     in, reads the entry back, and the last lane of a symbol stores the new position with
+//     the lane bits cleared.  (Finding the lanes with a ballot per symbol bit costs ~50 VALU
+//     per batch; the kernel runs at >90 % of both the VALU issue rate and the LDS
+//     instruction rate, so every instruction of either kind shows.)
 constexpr int MTF_ROWS = 4;                                 // chunks per wave (one per 16-lane DPP row)
 constexpr int MTF_NWORDS = 80;                              // bitmap words per chunk: 68 used, 5 per lane of the row
 
@@ -231,10 +236,14 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
                                                               uint8_t *__restrict__ out, size_t out_stride,
                                                               uint32_t *__restrict__ sub_hist)
 {
-    __shared__ uint32_t s_hist[WITH_HIST ? MTF_WAVES * MTF_ROWS : 1][128];   // two 16-bit counters per word (a chunk has <= 4096 symbols)
-    __shared__ int16_t s_last[MTF_WAVES * MTF_ROWS][256];
-    __shared__ unsigned long long s_bm[MTF_WAVES * MTF_ROWS][MTF_NWORDS];
-    __shared__ uint16_t s_cum[MTF_WAVES * MTF_ROWS][MTF_NWORDS];
+    // slot strides are padded so that the four rows of a wave, which run in lockstep and favour the same symbols, ranks and
+    // bitmap words, do not meet in the same LDS banks
+    __shared__ uint32_t s_hist[WITH_HIST ? MTF_WAVES * MTF_ROWS : 1][128 + 8];   // 16-bit counters: rank r in word r & 127, half r >> 7
+    __shared__ uint32_t s_tab[MTF_WAVES * MTF_ROWS][256 + 8];                    // per symbol: last occurrence + 256 << 16 | lanes of the batch holding it
+    __shared__ unsigned long long s_bm[MTF_WAVES * MTF_ROWS][MTF_NWORDS + 4];
+    // prefix counts of bitmap word 5 q + k at entry 8 q + k: a lane's five counts are one aligned 16-byte store (packed
+    // ten bytes apart they were an unaligned 8-byte store, which alone cost a quarter of the kernel)
+    __shared__ __attribute__((aligned(16))) uint16_t s_cum[MTF_WAVES * MTF_ROWS][16 * 8 + 16];
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63, lr = l & 15, row = l >> 4;
     const uint32_t w = threadIdx.x >> 6, slot = w * MTF_ROWS + row;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
@@ -246,59 +255,68 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
     const uint32_t Cmax = min(n, chunk0 * MTF_CHUNK + MTF_CHUNK) - chunk0 * MTF_CHUNK;   // the wave's first chunk is its longest
     const uint8_t *src = in + (size_t)b * in_stride + lo;
     uint8_t *dst = out + (size_t)b * out_stride + lo;
-    int16_t *last = s_last[slot];
+    uint32_t *tab = s_tab[slot];
     unsigned long long *bm = s_bm[slot];
     uint16_t *cum = s_cum[slot];
     {
         const uint4 lw = reinterpret_cast<const uint4 *>(lists + ((size_t)b * max_chunks + (live ? chunk : chunk0)) * 256)[lr];
         const uint32_t q[4] = {lw.x, lw.y, lw.z, lw.w};
 #pragma unroll
-        for (int j = 0; j < 16; j++) last[(q[j >> 2] >> (8 * (j & 3))) & 0xFF] = (int16_t)(-1 - (int)(16 * lr + j));
+        for (int j = 0; j < 16; j++) tab[(q[j >> 2] >> (8 * (j & 3))) & 0xFF] = (255u - (16 * lr + j)) << 16;   // time -1-q, biased by 256
 #pragma unroll
-        for (int k = 0; k < 5; k++) { bm[5 * lr + k] = 0; cum[5 * lr + k] = 0; }
+        for (int k = 0; k < 5; k++) { bm[5 * lr + k] = 0; cum[8 * lr + k] = 0; }
         if (WITH_HIST) for (int i = lr; i < 128; i += 16) s_hist[slot][i] = 0;
         __builtin_amdgcn_wave_barrier();
     }
-    const uint64_t rowmask = 0xFFFFull << (16 * row);
-    const uint64_t lt_mask = (1ull << l) - 1ull;
+    const uint32_t mybit = 1u << lr, below = mybit - 1u;
     uint32_t sym_next = src[lr < C ? lr : 0u];
     for (uint32_t base = 0; base < Cmax; base += 16) {
         const uint32_t i = base + lr;
         const bool valid = i < C;
-        const uint32_t sym = valid ? sym_next : 0u;
+        const uint32_t sym = sym_next;
         sym_next = src[i + 16 < C ? i + 16 : 0u];                                // in flight during this batch
-        // lanes of this row holding the same symbol
-        const uint64_t peers = wave_match<8>(sym, __ballot(valid)) & rowmask;
-        const uint64_t before = peers & lt_mask;
+        // lanes of this row holding the same symbol: every lane ORs its bit into the symbol's entry, then reads it
+        // back (LDS operations of a wave execute in order; OR is commutative, so no lane order is relied on)
+        if (valid) atomicOr(&tab[sym], mybit);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t e = tab[sym];
+        const uint32_t before = e & below;
         const bool hasprev = before != 0;
-        const int p = (63 - __builtin_clzll(before | 1ull)) & 15;                // previous lane of the row with my symbol
-        const bool last_in_batch = (peers >> l) == 1ull;
-        const int P = hasprev ? (int)base + p : (int)last[sym];
-        // T = #{k < lr : P[k] < P[lr]}: the (biased, strictly positive) P values slide up one lane per step
-        // (DPP row_shr:1, lanes with no source read 0), so lane lr meets P[lr-1], ... P[0]; counting the
-        // LARGER ones lets the zero fill drop out: T = lr - G
-        const uint32_t Pb = (uint32_t)(P + 257);
-        uint32_t G = 0, slide = Pb;
-#pragma unroll
-        for (int k = 0; k < 15; k++) {
-            slide = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)slide, 0x111, 0xf, 0xf, true);
-            G += (slide > Pb) ? 1u : 0u;
-        }
-        const uint32_t T = lr - G;
+        const uint32_t p = 31u - (uint32_t)__builtin_clz(before | 1u);           // previous lane of the row with my symbol
+        const bool last_in_batch = ((e & 0xFFFFu) >> lr) == 1u;
+        // biased timestamp of the previous occurrence: Pb = P + 257 > 0
+        const uint32_t Pb = hasprev ? base + p + 257u : (e >> 16) + 1u;
+        // T = #{k < lr : P[k] < P[lr]}: lane lr meets P[lr-1], ... P[0] through DPP row_shr:1..15; each step is
+        // (shifted P) - P with the borrow added up, and the 15 - lr steps that have no source lane read 0 < Pb
+        uint32_t G = 0, t0;
+#define GLC_SLIDE(K)                                                                                                \
+        "v_sub_co_u32_dpp %1, vcc, %2, %2 row_shr:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+        asm volatile(GLC_SLIDE(1) GLC_SLIDE(2) GLC_SLIDE(3) GLC_SLIDE(4) GLC_SLIDE(5) GLC_SLIDE(6) GLC_SLIDE(7) GLC_SLIDE(8)
+                     GLC_SLIDE(9) GLC_SLIDE(10) GLC_SLIDE(11) GLC_SLIDE(12) GLC_SLIDE(13) GLC_SLIDE(14) GLC_SLIDE(15)
+                     : "+v"(G), "=&v"(t0) : "v"(Pb) : "vcc");
+#undef GLC_SLIDE
+        const uint32_t T = G + lr - 15u;
+        const uint32_t bitx = Pb - 1u;                                           // P + 256: index into the killed-timestamp bitmap
         uint32_t o;
-        if (hasprev) o = T - (uint32_t)(p + 1);
+        if (hasprev) o = T - (p + 1u);
         else {
-            const uint32_t bitx = (uint32_t)(P + 256), wd = bitx >> 6, r = bitx & 63;
-            const uint32_t kb = cum[wd] + (uint32_t)__popcll(bm[wd] & ((1ull << r) - 1ull));
-            o = T + kb - (uint32_t)(P + 1);           // signed: virtual P adds the -1-P start-list symbols ahead of x
+            const uint32_t wd = bitx >> 6, r = bitx & 63;
+            const uint32_t kb = cum[wd + 3u * ((wd * 205u) >> 10)] + (uint32_t)__popcll(bm[wd] & ((1ull << r) - 1ull));   // wd / 5 for wd < 70
+            o = T + kb + 255u - bitx;                 // T + kb - (P + 1): virtual P adds the -1-P start-list symbols ahead of x
         }
         __builtin_amdgcn_wave_barrier();
+        {   // timestamps of this batch killed inside the batch = the lanes that are not the last of their symbol: one
+            // 16-bit store per row (nothing else can have touched that field yet) instead of same-word atomics
+            const uint64_t nl = __ballot(valid && !last_in_batch);
+            const uint32_t half = (row & 2) ? (uint32_t)(nl >> 32) : (uint32_t)nl;
+            if (lr == 0) reinterpret_cast<uint16_t *>(bm)[(base + 256u) >> 4] = (uint16_t)(half >> (16 * (row & 1)));
+        }
         if (valid) {
             dst[i] = (uint8_t)o;
-            if (WITH_HIST) atomicAdd(&s_hist[slot][(o & 0xFF) >> 1], 1u << (16 * (o & 1)));
-            const uint32_t bitx = (uint32_t)(P + 256);
-            atomicOr(&bm[bitx >> 6], 1ull << (bitx & 63));                       // timestamp P is killed by i
-            if (last_in_batch) last[sym] = (int16_t)i;
+            if (WITH_HIST) atomicAdd(&s_hist[slot][o & 127], 1u << ((o >> 3) & 16));
+            if (!hasprev) atomicOr(&bm[bitx >> 6], 1ull << (bitx & 63));                       // timestamp P is killed by i
+            if (last_in_batch) tab[sym] = (i + 256u) << 16;                      // new last occurrence, lane bits cleared
         }
         __builtin_amdgcn_wave_barrier();
         // prefix counts of the killed-timestamp bitmap: 5 words per lane, scan across the row
@@ -311,16 +329,15 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
             inc += GLC_DPP(inc, 0x112, 0xf);
             inc += GLC_DPP(inc, 0x114, 0xf);
             inc += GLC_DPP(inc, 0x118, 0xf);
-            uint32_t run = inc - s;
-#pragma unroll
-            for (int k = 0; k < 5; k++) { cum[5 * lr + k] = (uint16_t)run; run += c[k]; }
+            const uint32_t r0 = inc - s, r1 = r0 + c[0], r2 = r1 + c[1], r3 = r2 + c[2], r4 = r3 + c[3];
+            *reinterpret_cast<uint4 *>(cum + 8 * lr) = make_uint4(r0 | (r1 << 16), r2 | (r3 << 16), r4, 0u);
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (WITH_HIST && live) {
         __builtin_amdgcn_wave_barrier();
         uint32_t *H = sub_hist + ((size_t)b * max_chunks + chunk) * 256;
-        for (int i = lr; i < 256; i += 16) H[i] = (s_hist[slot][i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        for (int i = lr; i < 256; i += 16) H[i] = (s_hist[slot][i & 127] >> (16 * (i >> 7))) & 0xFFFFu;
     }
 }
 
