@@ -47,9 +47,10 @@ constexpr uint32_t FS_BIN_BITS = 12, FS_BINS = 1u << FS_BIN_BITS;
 constexpr uint32_t FS_MAX_GROUP = 512;              // longest run of equal codes ranked by direct count
 constexpr uint64_t FS_LOW_MASK = (1ull << 28) - 1;  // [index : 20 | bwt : 8]
 
+// at least 16 buckets: k_fs_sort compares bits 28..59 of the words, so the four bits above must be bucket number
 uint32_t fs_bucket_log2(uint32_t n)
 {
-    uint32_t l = 0;
+    uint32_t l = 4;
     while (((uint64_t)FS_AVG << l) < n && l < FS_MAXNB_LOG2) l++;
     return l;
 }
@@ -237,9 +238,7 @@ __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict
 // ---------------------------------------------------------------------------
 // LDS diet (40.7 KB: FOUR workgroups per CU, 8 waves per SIMD, where 52 KB allowed three): the bin counters are
 // 16-bit pairs (a bucket holds < 4096 words), the sorted words are capped at FS_FILLMAX (a fuller bucket flags its
-// block), and the BWT byte of an element is written over byte 0 of the word at its final position instead of into
-// a staging array -- every thread has its own words in registers by then, and the codes other threads still
-// compare live in bits 28..63.
+// block), and the BWT bytes are staged in the counter array once the bin starts are dead.
 __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, const uint64_t *__restrict__ keys,
                                                     size_t kstride, const uint32_t *__restrict__ fill,
                                                     const uint32_t *__restrict__ fbase, uint32_t *__restrict__ flag,
@@ -248,12 +247,12 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
                                                     size_t sa_stride, uint4 *__restrict__ wl, uint32_t wl_cap,
                                                     uint32_t *__restrict__ wl_count)
 {
-    __shared__ uint64_t s_w[FS_FILLMAX];
-    __shared__ uint32_t s_cp[FS_BINS / 2];                     // bin counters, then bin starts: two 16-bit values per word
+    __shared__ uint64_t s_w[FS_FILLMAX + 4];                   // + 4 sentinels behind the last word
+    __shared__ uint32_t s_cp[FS_BINS / 2 + 1];                 // bin counters, then bin starts (two 16-bit values per word), then BWT bytes
     __shared__ uint32_t s_tmp[FSS_NT / 64 + 1];
     __shared__ uint32_t s_deep, s_wl;
     uint16_t *s16 = reinterpret_cast<uint16_t *>(s_cp);
-    uint8_t *s_b = reinterpret_cast<uint8_t *>(s_w);
+    uint8_t *s_cb = reinterpret_cast<uint8_t *>(s_cp);
     const uint32_t b = blockIdx.y, bk = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) { s_deep = flag[b]; s_wl = 0; }              // (one read: another bucket may flag the block meanwhile)
     for (uint32_t i = tid; i < FS_BINS / 2; i += FSS_NT) s_cp[i] = 0;
@@ -267,6 +266,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
         w[r] = ~0ull;
         if (r * FSS_NT < c && c <= FS_FILLMAX && i < c) w[r] = K[i];
     }
+    if (tid < 4 && c <= FS_FILLMAX) s_w[c + tid] = ~0ull;      // what the rank step reads past the last bin compares as larger
     __syncthreads();
     if (s_deep || c == 0) return;                              // flagged: the block goes through the general sorter
     // 1. counting sort on the 12 bits below the bucket number (arrival order inside a bin: any order will do)
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
             s_cp[tid * PW + k] = lo | (hi << 16);
             run = hi + (v[k] >> 16);
         }
+        if (tid == FSS_NT - 1) s_cp[FS_BINS / 2] = c;          // end of the last bin
     }
     __syncthreads();
 #pragma unroll
@@ -302,70 +303,74 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
         if (i < c) s_w[s16[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] = w[r];
     }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < FSS_ITEMS; r++) {                      // own words (byte 0 of a slot is overwritten below)
-        if (r * FSS_NT >= c) continue;
-        const uint32_t p = r * FSS_NT + tid;
-        w[r] = p < c ? s_w[p] : ~0ull;
-    }
-    __syncthreads();
-    // 2. final position = bin start + number of smaller codes in the bin.  Elements with equal codes form a
-    //    group [gp, gp + gs) whose internal order is not known yet.
-    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
+    // 2. final position = bin start + number of smaller codes in the bin (thread = the words at positions r NT + tid
+    //    of the bin-sorted array).  A bin holds ~1.5 words seen from one of them: the four words from the bin start
+    //    are compared in straight-line code with no bounds at all -- what lies behind the bin's end is a larger code
+    //    or a sentinel -- and only a bin of more than four walks the rest in a loop.  Words with EQUAL codes form a
+    //    group [gp, gp + gs) whose internal order is not known yet: they take a second, exact look (rare).
     uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
     uint32_t pos[FSS_ITEMS], grp[FSS_ITEMS];                   // grp = group start << 16 | group size (0: not tied)
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
         const uint32_t p = r * FSS_NT + tid;
-        pos[r] = 0; grp[r] = 0;
+        pos[r] = 0xFFFFFFFFu; grp[r] = 0;
         if (r * FSS_NT >= c) continue;
         if (p < c) {
-            const uint64_t wv = w[r];
+            const uint64_t wv = s_w[p];
+            w[r] = wv;
             const uint32_t key = (uint32_t)(wv >> 28);         // inside a bin only the low 32 bits of the code can differ
             const uint32_t bin = (uint32_t)(wv >> bshift) & (FS_BINS - 1);
-            const uint32_t gs = s16[bin], ge = bin + 1 < FS_BINS ? (uint32_t)s16[bin + 1] : c;
+            const uint32_t gs = s16[bin], ge = s16[bin + 1];
             if (ge - gs > FS_MAX_GROUP) { s_deep = 1; }
             else {
-                // a bin holds ~1.5 words seen from one of them: the first four are compared in straight-line code
-                // (four LDS reads in flight, no loop set-up, no exec juggling -- the compiler's 4x-unrolled loop with
-                // its remainder code cost ~100 VALU + 60 SALU per 64 elements), the rare rest in a plain loop
-                uint32_t less = 0, eqb = 0, eqt = 0;
+                uint32_t less = 0, eqt = 0;
+                const uint2 *B = reinterpret_cast<const uint2 *>(s_w) + gs;
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {
-                    const uint32_t q = gs + t;
-                    const bool in = q < ge;
-                    const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[in ? q : gs];
+                    const uint2 wq = B[t];
                     const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
-                    less += (in && kq < key) ? 1u : 0u;
-                    eqt += (in && kq == key) ? 1u : 0u;
-                    eqb += (in && kq == key && q < p) ? 1u : 0u;
+                    less += kq < key ? 1u : 0u;
+                    eqt += kq == key ? 1u : 0u;
                 }
                 if (ge - gs > 4) {
 #pragma clang loop unroll(disable)
                     for (uint32_t q = gs + 4; q < ge; q++) {
                         const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[q];
                         const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
-                        less += kq < key; eqt += kq == key; eqb += (kq == key) & (q < p);
+                        less += kq < key; eqt += kq == key;
                     }
                 }
-                pos[r] = gs + less + eqb;
                 const uint32_t idx = (uint32_t)(wv >> 8) & 0xFFFFFu;
-                if (eqt > 1) grp[r] = ((gs + less) << 16) | eqt;
-                else {
-                    s_b[8 * pos[r]] = (uint8_t)wv;
-                    if (SAo) SAo[pos[r]] = idx;
-                    if (idx == 0 && d_index) d_index[b] = (int)(R0 + pos[r]);
+                uint32_t at = gs + less;
+                if (eqt > 1) {                                 // exact: members of my group inside the bin, and those before me
+                    uint32_t eqb = 0; eqt = 0;
+#pragma clang loop unroll(disable)
+                    for (uint32_t q = gs; q < ge; q++) {
+                        const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[q];
+                        const bool e = __builtin_amdgcn_alignbit(wq.y, wq.x, 28) == key;
+                        eqt += e; eqb += e & (q < p);
+                    }
+                    if (eqt > 1) { grp[r] = (at << 16) | eqt; at += eqb; }
+                }
+                pos[r] = at;
+                if (!grp[r]) {
+                    if (SAo) SAo[at] = idx;
+                    if (idx == 0 && d_index) d_index[b] = (int)(R0 + at);
                 }
             }
         }
     }
-    __syncthreads();                                           // s_cp (bin starts) is dead from here
+    __syncthreads();                                           // s_cp (bin starts) is dead from here: it takes the BWT bytes
     if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    // rows R0 .. R0 + c of the block's BWT are staged so that aligned dwords of LDS are aligned dwords of the output
+    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
     // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup
     //    (an atomic per group on a shared counter serialised the whole kernel: +2.4 ms per 256 blocks).
     bool any = false;
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
+        if (pos[r] != 0xFFFFFFFFu) s_cb[shift + pos[r]] = (uint8_t)w[r];      // (rows of tied groups are rewritten by k_fs_ties)
         if (grp[r]) {
             any = true;
             const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu;
@@ -392,17 +397,17 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
             }
         }
     }
-    // 4. rows R0 .. R0 + c of the block's BWT (rows of tied groups are rewritten by k_fs_ties)
+    // 4. the rows
     if (O) {
-        const uint32_t head = min(c, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u)) & 3u));
-        const uint32_t nq = (c - head) / 4;
-        if (tid < head) O[tid] = s_b[8 * tid];
-        for (uint32_t p = head + 4 * nq + tid; p < c; p += FSS_NT) O[p] = s_b[8 * p];
-        for (uint32_t q = tid; q < nq; q += FSS_NT) {
-            const uint32_t p = head + 4 * q;
-            const uint32_t v = (uint32_t)s_b[8 * p] | ((uint32_t)s_b[8 * p + 8] << 8) | ((uint32_t)s_b[8 * p + 16] << 16) |
-                               ((uint32_t)s_b[8 * p + 24] << 24);
-            *reinterpret_cast<uint32_t *>(O + p) = v;
+        const uint32_t end = shift + c;                        // staged bytes [shift, end)
+        for (uint32_t q = tid; 4 * q < end; q += FSS_NT) {
+            const uint32_t v = s_cp[q];
+            if (4 * q >= shift && 4 * q + 4 <= end) *reinterpret_cast<uint32_t *>(O - shift + 4 * q) = v;
+            else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (4 * q + k >= shift && 4 * q + k < end) O[4 * q + k - shift] = (uint8_t)(v >> (8 * k));
+            }
         }
     }
 }
