@@ -121,12 +121,72 @@ __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// suffix comparison in the text (runs of equal codes; the sample tier's splitters)
+// ---------------------------------------------------------------------------
+constexpr uint32_t FS_LCP_CAP = 512;                           // a longer common prefix flags the block as deep
+
+__device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3) * 8;
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+    return ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
+}
+
+// suffix a < suffix b ?  (a != b; the shorter of two suffixes that agree to the end of one is the smaller)
+__device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep)
+{
+    uint32_t k = 0;
+    for (;;) {
+        const uint32_t m = max(a, b) + k;
+        if (m + 12 <= n) {
+            const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
+            if (va != vb) return va < vb;
+            k += 8;
+        } else {
+            if (a + k >= n) return true;
+            if (b + k >= n) return false;
+            const uint32_t ca = T[a + k], cb = T[b + k];
+            if (ca != cb) return ca < cb;
+            k++;
+        }
+        if (k > FS_LCP_CAP) { *deep = true; return false; }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // bucketing pass
 // ---------------------------------------------------------------------------
+// SPLIT = the sample tier's form: blocks come from a list, and the bucket of a word is found among the block's
+// splitter suffixes (code first, text on equal codes) instead of in the top bits of the code.
+__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, uint32_t nb, uint64_t w, const uint8_t *T, uint32_t n,
+                                              bool *deep)
+{
+    const uint64_t cw = w >> 28;
+    const uint32_t iw = (uint32_t)(w >> 8) & 0xFFFFFu;
+    uint32_t lo = 0, hi = nb;                                  // the answer is in [lo, hi): splitter[lo] <= w < splitter[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t sw = sp[mid], cs = sw >> 28;
+        bool le;                                               // splitter[mid] <= w ?
+        if (cs != cw) le = cs < cw;
+        else {
+            const uint32_t is = (uint32_t)(sw >> 8) & 0xFFFFFu;
+            le = is == iw || !fs_suffix_less(T, n, iw, is, deep);
+        }
+        if (le) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                     uint32_t nbl, const uint2 *__restrict__ tab,
                                                     uint64_t *__restrict__ keys, size_t kstride,
-                                                    uint32_t *__restrict__ fill, uint32_t *__restrict__ flag)
+                                                    uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
+                                                    const uint32_t *__restrict__ list, const uint64_t *__restrict__ split)
 {
     __shared__ uint32_t s_cnt[FS_MAXNB], s_start[FS_MAXNB], s_gbase[FS_MAXNB];
     __shared__ uint64_t s_w[FSP_TILE];
@@ -135,9 +195,11 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     // (38 KB instead of 44 KB of LDS: 4 workgroups per CU instead of 3)
     uint2 *s_tab = reinterpret_cast<uint2 *>(s_w);
     uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_w) + 256 * sizeof(uint2);   // s_txt[k] = T[base - 1 + k]; 16-byte aligned
-    const uint32_t b = blockIdx.y, tid = threadIdx.x, base = blockIdx.x * FSP_TILE;
+    const uint32_t b = SPLIT ? list[blockIdx.y] : blockIdx.y, tid = threadIdx.x, base = blockIdx.x * FSP_TILE;
     if (base >= n) return;
     const uint8_t *T = text + (size_t)b * stride;
+    uint64_t *s_split = s_w + 1024;                            // (SPLIT) behind the table and the staged text, dead with them
+    if (SPLIT) for (uint32_t i = tid; i < (1u << nbl); i += FSP_NT) s_split[i] = split[(size_t)b * FS_MAXNB + i];
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
     if (tid < FS_MAXNB) s_cnt[tid] = 0;
     const bool edge = base + FSP_TILE + 16 > n;
@@ -185,7 +247,12 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
         const uint64_t X = ((uint64_t)e[j].x << 32) + (uint64_t)e[j].y * y;
         const uint32_t gi = gi0 + j;
         w[j] = (X & ~FS_LOW_MASK) | ((uint64_t)gi << 8) | FS_BYTE(j);
-        const uint32_t bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
+        uint32_t bk;
+        if (SPLIT) {
+            bool deep = false;
+            bk = gi < n ? ss_bucket(s_split, 1u << nbl, w[j], T, n, &deep) : 0u;
+            if (deep) atomicOr(&flag[b], 2u);
+        } else bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
         br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
     }
 #undef FS_BYTE
@@ -212,7 +279,13 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
         const uint32_t p = r * FSP_NT + tid;
         if (p < tile_n) {
             const uint64_t ww = s_w[p];
-            const uint32_t d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
+            uint32_t d;
+            if (SPLIT) {                                       // bucket of position p: the last one that starts at or before p
+                uint32_t lo = 0, hi = 1u << nbl;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= p) lo = mid; else hi = mid; }
+                d = lo;
+                while (d + 1 < (1u << nbl) && s_start[d + 1] <= p) d++;    // (empty buckets share a start: take the last)
+            } else d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
             const uint32_t off = s_gbase[d] + (p - s_start[d]);
             if (off < FS_CAP) K[(size_t)d * FS_CAP + off] = ww;
         }
@@ -221,10 +294,10 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
 
 // rank base of every bucket (exclusive scan of the fills); a bucket past its slot flags the block
 __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict__ fill, uint32_t *__restrict__ fbase,
-                                                      uint32_t *__restrict__ flag)
+                                                      uint32_t *__restrict__ flag, const uint32_t *__restrict__ list)
 {
     __shared__ uint32_t s_tmp[FS_MAXNB / 64 + 1];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
     const uint32_t f = fill[(size_t)b * FS_MAXNB + tid];
     if (f > FS_FILLMAX) atomicOr(&flag[b], 1u);
     fbase[(size_t)b * FS_MAXNB + tid] = block_excl_add<FS_MAXNB>(f, s_tmp);
@@ -417,39 +490,6 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
 // 8 bytes at a time) and writes its row.  Equal codes do not certify equal symbols: the comparison starts at
 // the first symbol.
 // ---------------------------------------------------------------------------
-constexpr uint32_t FS_LCP_CAP = 512;                           // a longer common prefix flags the block as deep
-
-__device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
-{
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3) * 8;
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-    return ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
-}
-
-// suffix a < suffix b ?  (a != b; the shorter of two suffixes that agree to the end of one is the smaller)
-__device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep)
-{
-    uint32_t k = 0;
-    for (;;) {
-        const uint32_t m = max(a, b) + k;
-        if (m + 12 <= n) {
-            const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
-            if (va != vb) return va < vb;
-            k += 8;
-        } else {
-            if (a + k >= n) return true;
-            if (b + k >= n) return false;
-            const uint32_t ca = T[a + k], cb = T[b + k];
-            if (ca != cb) return ca < cb;
-            k++;
-        }
-        if (k > FS_LCP_CAP) { *deep = true; return false; }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                  const uint4 *__restrict__ wl, uint32_t wl_cap,
                                                  const uint32_t *__restrict__ wl_count, uint32_t *__restrict__ flag,
@@ -480,14 +520,442 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
 // (`redo` is a per-call copy of the flags for the stages queued speculatively behind the sort: under stage
 //  pipelining the next call clears `flag` while they may still be reading)
 __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint32_t nblk, uint32_t *__restrict__ lcnt,
-                            uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo)
+                            uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo, uint32_t *__restrict__ list)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nblk) {
         const uint32_t f = flag[b] ? n : 0u;
         lcnt[b] = f;
         redo[b] = f;
-        if (f) atomicAdd(nflag, 1u);
+        if (f) list[atomicAdd(nflag, 1u)] = b;                 // (any order)
+    }
+}
+
+// ===========================================================================
+// second tier: string sample sort of the blocks the bucket sorter flagged
+// ===========================================================================
+// Text, logs and other data with context make the order-0 code lumpy -- a frequent 6-gram puts thousands of suffixes
+// on ONE code, so fixed bucket boundaries overflow and runs of equal codes are long.  For those blocks the buckets
+// are cut at SPLITTER SUFFIXES instead: 32 samples per bucket, sorted exactly (code, then text), every 32nd is the
+// first suffix of a bucket, so buckets hold ~2048 +- 20 % suffixes whatever the distribution -- a code shared by
+// 10000 suffixes is simply spread over five buckets, cut by text comparison.  A bucket is then sorted in LDS in
+// rounds of 5 symbols read from the text, starting behind the common prefix of the bucket's two splitters
+// (everything between two suffixes shares their common prefix); see k_ss_sort.
+// Same words, same slots, same outputs as the first tier; only very deep repeats are left to the general sorter.
+constexpr int SSA_NT = 1024;                                   // k_ss_sample: threads
+constexpr uint32_t SS_PER_BUCKET = 32, SS_MAXS = FS_MAXNB * SS_PER_BUCKET;
+constexpr uint32_t SS_L0_CAP = 1024;                           // longest splitter prefix skipped at once
+
+__device__ __forceinline__ uint64_t fs_code_at(const uint2 *tab, const uint8_t *T, uint32_t n, uint32_t i)
+{
+    uint2 e[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) e[k] = i + k < n ? tab[T[i + k]] : make_uint2(0u, 0u);
+    uint32_t y = e[5].x;
+#pragma unroll
+    for (int d = 4; d >= 1; d--) y = e[d].x + __umulhi(e[d].y, y);
+    return ((uint64_t)e[0].x << 32) + (uint64_t)e[0].y * y;
+}
+
+// a < b for sample words [code : 36 | index : 20 | 0 : 8]; ~0 = padding, larger than everything
+__device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8_t *T, uint32_t n, bool *deep)
+{
+    if (a == ~0ull) return false;
+    if (b == ~0ull) return true;
+    const uint64_t ca = a >> 28, cb = b >> 28;
+    if (ca != cb) return ca < cb;
+    const uint32_t ia = (uint32_t)(a >> 8) & 0xFFFFFu, ib = (uint32_t)(b >> 8) & 0xFFFFFu;
+    if (ia == ib) return false;
+    return fs_suffix_less(T, n, ia, ib, deep);
+}
+
+__global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                      uint32_t nbl, const uint2 *__restrict__ tab,
+                                                      const uint32_t *__restrict__ list, uint64_t *__restrict__ split,
+                                                      uint32_t *__restrict__ flag)
+{
+    __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
+    __shared__ uint2 s_tab[256];
+    __shared__ uint32_t s_deep;
+    const uint32_t b = list[blockIdx.x], tid = threadIdx.x, nb = 1u << nbl;
+    const uint8_t *T = text + (size_t)b * stride;
+    const uint32_t S = min(nb * SS_PER_BUCKET, n);
+    uint32_t S2 = 1;
+    while (S2 < S) S2 <<= 1;
+    if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
+    if (tid == 0) s_deep = 0;
+    __syncthreads();
+    for (uint32_t j = tid; j < S2; j += SSA_NT) {
+        uint64_t w = ~0ull;
+        if (j < S) {
+            const uint32_t i = (uint32_t)(((uint64_t)j * n) / S);
+            w = (fs_code_at(s_tab, T, n, i) & ~FS_LOW_MASK) | ((uint64_t)i << 8);
+        }
+        s_s[j] = w;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= S2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < S2 / 2; t += SSA_NT) {
+                const uint32_t low = t & (j - 1), i = ((t - low) << 1) + low, q = i + j;
+                const uint64_t a = s_s[i], c = s_s[q];
+                bool deep = false;
+                const bool up = (i & k) == 0;                  // ascending run?
+                const bool swap = up ? ss_word_less(c, a, T, n, &deep) : ss_word_less(a, c, T, n, &deep);
+                if (deep) s_deep = 1;
+                if (swap) { s_s[i] = c; s_s[q] = a; }
+            }
+            __syncthreads();
+            if (s_deep) break;                                 // (uniform: read after the barrier, written before it)
+        }
+        if (s_deep) break;
+    }
+    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    for (uint32_t k = tid; k < nb; k += SSA_NT)
+        split[(size_t)b * FS_MAXNB + k] = k ? s_s[(uint32_t)(((uint64_t)k * S) / nb)] : 0ull;
+}
+
+// 7 symbols from position i as 9-bit digits (symbol + 1; 0 behind the end of the block: the shorter suffix is smaller)
+constexpr uint32_t SS_STEP = 7;
+
+__device__ __forceinline__ uint64_t ss_symkey(const uint8_t *T, uint32_t n, uint32_t i)
+{
+    uint64_t k = 0;
+    if (i + 12 <= n) {
+        const uint64_t be = fs_load_be64(T + i);
+#pragma unroll
+        for (int j = 0; j < (int)SS_STEP; j++) k = (k << 9) | (((be >> (56 - 8 * j)) & 0xFFu) + 1u);
+    } else {
+#pragma unroll
+        for (int j = 0; j < (int)SS_STEP; j++) k = (k << 9) | (i + j < n ? (uint64_t)T[i + j] + 1u : 0ull);
+    }
+    return k;
+}
+
+// suffix a < suffix b, both known to agree in their first `from` symbols
+__device__ __forceinline__ bool ss_suffix_less_from(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, uint32_t from,
+                                                    bool *deep)
+{
+    uint32_t k = from;
+    for (;;) {
+        const uint32_t m = max(a, b) + k;
+        if (m + 12 <= n) {
+            const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
+            if (va != vb) return va < vb;
+            k += 8;
+        } else {
+            if (a + k >= n) return true;
+            if (b + k >= n) return false;
+            const uint32_t ca = T[a + k], cb = T[b + k];
+            if (ca != cb) return ca < cb;
+            k++;
+        }
+        if (k - from > FS_LCP_CAP) { *deep = true; return false; }
+    }
+}
+
+constexpr int SSS_NT = 512, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
+constexpr uint32_t SS_MOVED = 0x80000000u;                     // s_seg: position holds a suffix moved in this round: | wave slot << 8 | bin
+constexpr uint32_t SS_SMALL = 48;                              // runs up to this size are ranked by direct count
+constexpr uint32_t SS_FINISH = 8;                              // once no run is longer, the suffixes themselves are compared
+constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
+
+// sorts one key per lane across the wave (ascending by lane)
+__device__ __forceinline__ uint64_t wave_sort_u64(uint64_t k, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)k, (int)j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(k >> 32), (int)j);
+            const uint64_t o = ((uint64_t)hi << 32) | lo;
+            const bool up = (lane & kk) == 0, lower = (lane & j) == 0;
+            const uint64_t mn = o < k ? o : k, mx = o < k ? k : o;
+            k = (up == lower) ? mn : mx;
+        }
+    }
+    return k;
+}
+
+// One workgroup per bucket; the suffixes are ordered in rounds of 7 symbols read from the text.  A RUN is a range of
+// positions whose suffixes agree in everything looked at so far; the whole bucket is the first run.  In a round
+// every member of a run gets the key of its next 7 symbols and is ranked inside its run:
+//   * a short run by direct count (a member reads the keys of its run),
+//   * a long run through 64 PIVOTS -- keys of 64 of its members, sorted by one wave -- which cut it into the bins
+//     "between two pivots" / "equal to a pivot": whatever the key distribution is (text is anything but uniform),
+//     the between-bins are small, and a key that hundreds of members share is almost surely a pivot, whose bin
+//     needs no ranking at all; members count into the bins with LDS atomics and are ranked inside their bin.
+// Members with equal keys form the runs of the next round; once all runs are very short the suffixes themselves
+// are compared.  Nothing here depends on the symbol statistics.
+__global__ __launch_bounds__(SSS_NT, 4) void k_ss_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                    uint32_t nbl, const uint64_t *__restrict__ keys, size_t kstride,
+                                                    const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
+                                                    uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
+                                                    const uint64_t *__restrict__ split, uint8_t *__restrict__ bwt_out,
+                                                    size_t bwt_stride, int *__restrict__ d_index,
+                                                    uint32_t *__restrict__ sa_out, size_t sa_stride)
+{
+    __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position (this round); at the end the BWT bytes
+    __shared__ uint32_t s_v[FS_FILLMAX];                       // index << 8 | BWT byte of the suffix at a position
+    __shared__ uint32_t s_seg[FS_FILLMAX];                     // run a position belongs to: start | end << 16  (or SS_MOVED | ...)
+    __shared__ uint64_t s_piv[SSS_WAVES][SS_NPIV];
+    __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end)
+    __shared__ uint32_t s_big[FS_FILLMAX / SS_SMALL + 2];      // the long runs of this round (start | end << 16)
+    __shared__ uint32_t s_deep, s_l0, s_maxrun, s_nbig;
+    const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x, nb = 1u << nbl;
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    const uint8_t *T = text + (size_t)b * stride;
+    const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
+    const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
+    const uint64_t *SP = split + (size_t)b * FS_MAXNB;
+    if (tid == 0) {
+        s_deep = flag[b];
+        s_maxrun = c;
+        // every suffix of the bucket lies between its two splitters and shares their common prefix
+        uint32_t l0 = 0;
+        if (bk >= 1 && bk + 1 < nb && c > 1) {
+            const uint32_t ia = (uint32_t)(SP[bk] >> 8) & 0xFFFFFu, ib = (uint32_t)(SP[bk + 1] >> 8) & 0xFFFFFu;
+            if (ia != ib) {
+                const uint32_t m = max(ia, ib);
+                while (l0 < SS_L0_CAP && m + l0 + 12 <= n) {
+                    const uint64_t x = fs_load_be64(T + ia + l0) ^ fs_load_be64(T + ib + l0);
+                    if (x) { l0 += (uint32_t)__builtin_clzll(x) >> 3; break; }
+                    l0 += 8;
+                }
+            }
+        }
+        s_l0 = l0;
+    }
+    const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+    if (c <= FS_FILLMAX) {
+        for (uint32_t i = tid; i < c; i += SSS_NT) {
+            s_v[i] = (uint32_t)(K[i] & FS_LOW_MASK);
+            s_seg[i] = c << 16;                                // one run: the whole bucket
+        }
+    }
+    __syncthreads();
+    if (s_deep || c == 0 || c > FS_FILLMAX) return;
+    const uint32_t l0 = s_l0;
+    uint32_t depth = l0;
+#ifdef SS_DBG
+    const bool dbg = blockIdx.y == 0 && (bk == 1 || bk == 100 || bk == 300) && tid == 0;
+    long long ts[24]; uint32_t mr[24], nbg[24]; int nts = 0;
+#endif
+    for (;;) {
+        const uint32_t maxrun = s_maxrun;                      // of the previous round (uniform: read behind a barrier)
+#ifdef SS_DBG
+        if (nts < 24) { ts[nts] = wall_clock64(); mr[nts] = maxrun; nbg[nts] = s_nbig; nts++; }
+#endif
+        if (maxrun <= 1) break;
+        __syncthreads();
+        if (depth - l0 > FS_LCP_CAP) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+        if (maxrun <= SS_FINISH) {
+            // every run is very short: each member counts the members of its run that are smaller, by comparing the suffixes
+            uint32_t np[SSS_ITEMS], vv[SSS_ITEMS];
+            bool deep = false;
+#pragma unroll
+            for (int r = 0; r < SSS_ITEMS; r++) {
+                const uint32_t p = r * SSS_NT + tid;
+                np[r] = 0xFFFFFFFFu;
+                if (r * SSS_NT >= c) continue;
+                if (p < c) {
+                    const uint32_t g = s_seg[p], ss = g & 0xFFFFu, se = g >> 16;
+                    if (se - ss > 1) {
+                        vv[r] = s_v[p];
+                        uint32_t less = 0;
+                        for (uint32_t q = ss; q < se; q++)
+                            if (q != p) less += ss_suffix_less_from(T, n, s_v[q] >> 8, vv[r] >> 8, depth, &deep) ? 1u : 0u;
+                        np[r] = ss + less;
+                    }
+                }
+            }
+            if (__syncthreads_or((int)deep)) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+#pragma unroll
+            for (int r = 0; r < SSS_ITEMS; r++)
+                if (np[r] != 0xFFFFFFFFu) s_v[np[r]] = vv[r];
+            __syncthreads();
+            break;
+        }
+        if (tid == 0) { s_maxrun = 0; s_nbig = 0; }
+        // A. keys of the undecided suffixes (thread = the positions r NT + tid), left at their positions
+        uint64_t key[SSS_ITEMS];
+        uint32_t vv[SSS_ITEMS], sg[SSS_ITEMS];                 // sg: run of the member | 1 << 30 (0 = decided)
+#pragma unroll
+        for (int r = 0; r < SSS_ITEMS; r++) {
+            const uint32_t p = r * SSS_NT + tid;
+            sg[r] = 0;
+            if (r * SSS_NT >= c) continue;
+            if (p < c) {
+                const uint32_t g = s_seg[p], ss = g & 0xFFFFu;
+                if ((g >> 16) - ss > 1) {
+                    sg[r] = g | 0x40000000u;
+                    vv[r] = s_v[p];
+                    key[r] = ss_symkey(T, n, (vv[r] >> 8) + depth);
+                    s_k[p] = key[r];
+                }
+            }
+        }
+        __syncthreads();
+        // B. short runs: rank by direct count; long runs: register
+        uint32_t np[SSS_ITEMS], ns[SSS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SSS_ITEMS; r++) {
+            const uint32_t p = r * SSS_NT + tid;
+            np[r] = 0xFFFFFFFFu;
+            if (sg[r]) {
+                const uint32_t ss = sg[r] & 0xFFFFu, se = (sg[r] >> 16) & 0x3FFFu;
+                if (se - ss <= SS_SMALL) {
+                    uint32_t less = 0, eqt = 0, eqb = 0;
+#pragma clang loop unroll(disable)
+                    for (uint32_t q = ss; q < se; q++) {
+                        const uint64_t kq = s_k[q];
+                        less += kq < key[r]; eqt += kq == key[r]; eqb += (kq == key[r]) & (q < p);
+                    }
+                    np[r] = ss + less + eqb;
+                    ns[r] = (ss + less) | ((ss + less + eqt) << 16);
+                    if (eqt > 1) atomicMax(&s_maxrun, eqt);
+                } else if (p == ss) s_big[atomicAdd(&s_nbig, 1u)] = ss | (se << 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SSS_ITEMS; r++)
+            if (np[r] != 0xFFFFFFFFu) { s_v[np[r]] = vv[r]; s_seg[np[r]] = ns[r]; sg[r] = 0; }
+        // C. long runs, one per wave at a time
+        const uint32_t nbig = s_nbig;
+        for (uint32_t g0 = 0; g0 < nbig; g0 += SSS_WAVES) {
+            __syncthreads();
+            {   // pivots of this wave's run, sorted; counters cleared
+                const uint32_t gi = g0 + wv;
+                if (gi < nbig) {
+                    const uint32_t rs = s_big[gi] & 0xFFFFu, rsz = (s_big[gi] >> 16) - rs;
+                    const uint64_t pk = wave_sort_u64(s_k[rs + (lane * rsz) / SS_NPIV], lane);
+                    s_piv[wv][lane] = pk;
+                }
+                for (uint32_t i = lane; i < SS_NBIN + 3; i += 64) s_cnt[wv][i] = 0;
+            }
+            __syncthreads();
+            // members of these runs: bin among the pivots
+            uint32_t bin[SSS_ITEMS], rk[SSS_ITEMS], slot[SSS_ITEMS];
+#pragma unroll
+            for (int r = 0; r < SSS_ITEMS; r++) {
+                slot[r] = 0xFFFFFFFFu;
+                if (sg[r]) {
+                    const uint32_t me = (sg[r] & 0xFFFFu) | (((sg[r] >> 16) & 0x3FFFu) << 16);
+                    for (uint32_t w = 0; w < SSS_WAVES; w++)
+                        if (g0 + w < nbig && s_big[g0 + w] == me) slot[r] = w;
+                    if (slot[r] != 0xFFFFFFFFu) {
+                        const uint64_t *P = s_piv[slot[r]];
+                        uint32_t lo = 0, hi = SS_NPIV;         // first pivot >= key
+                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P[mid] < key[r]) lo = mid + 1; else hi = mid; }
+                        bin[r] = 2 * lo + ((lo < SS_NPIV && P[lo] == key[r]) ? 1u : 0u);
+                        rk[r] = atomicAdd(&s_cnt[slot[r]][bin[r]], 1u);
+                    }
+                }
+            }
+            __syncthreads();
+            {   // bin starts of this wave's run: exclusive scan of its counters, offset by the run's start
+                const uint32_t gi = g0 + wv;
+                if (gi < nbig) {
+                    const uint32_t rs = s_big[gi] & 0xFFFFu;
+                    uint32_t c3[3], tot = 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; c3[k] = i < SS_NBIN ? s_cnt[wv][i] : 0u; tot += c3[k]; }
+                    uint32_t run = rs + wave_incl_add(tot) - tot;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; if (i <= SS_NBIN) s_cnt[wv][i] = run; run += c3[k]; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SSS_ITEMS; r++) {
+                if (slot[r] != 0xFFFFFFFFu) {
+                    const uint32_t q = s_cnt[slot[r]][bin[r]] + rk[r];
+                    s_k[q] = key[r]; s_v[q] = vv[r]; s_seg[q] = SS_MOVED | (slot[r] << 8) | bin[r];
+                    sg[r] = 0;
+                }
+            }
+            __syncthreads();
+            // position inside the bin (thread = the positions again): a pivot's bin is a finished run of equal keys
+            uint32_t mp[SSS_ITEMS], ms[SSS_ITEMS], mv[SSS_ITEMS];
+#pragma unroll
+            for (int r = 0; r < SSS_ITEMS; r++) {
+                const uint32_t p = r * SSS_NT + tid;
+                mp[r] = 0xFFFFFFFFu;
+                if (r * SSS_NT >= c) continue;
+                if (p < c) {
+                    const uint32_t g = s_seg[p];
+                    if (g & SS_MOVED) {
+                        const uint32_t w = (g >> 8) & 7u, bn = g & 0xFFu, gs = s_cnt[w][bn], ge = s_cnt[w][bn + 1];
+                        mv[r] = s_v[p];
+                        if (bn & 1) { mp[r] = p; ms[r] = gs | (ge << 16); if (ge - gs > 1) atomicMax(&s_maxrun, ge - gs); }
+                        else {
+                            const uint64_t kv = s_k[p];
+                            uint32_t less = 0, eqt = 0, eqb = 0;
+#pragma clang loop unroll(disable)
+                            for (uint32_t q = gs; q < ge; q++) {
+                                const uint64_t kq = s_k[q];
+                                less += kq < kv; eqt += kq == kv; eqb += (kq == kv) & (q < p);
+                            }
+                            mp[r] = gs + less + eqb;
+                            ms[r] = (gs + less) | ((gs + less + eqt) << 16);
+                            if (eqt > 1) atomicMax(&s_maxrun, eqt);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < SSS_ITEMS; r++)
+                if (mp[r] != 0xFFFFFFFFu) { s_v[mp[r]] = mv[r]; s_seg[mp[r]] = ms[r]; }
+        }
+        __syncthreads();
+        depth += SS_STEP;
+    }
+#ifdef SS_DBG
+    if (dbg) { ts[nts] = wall_clock64(); for (int i = 1; i <= nts; i++) printf("bk %u c %u l0 %u round %d maxrun-before %u nbig %u dt %lld\n", bk, c, l0, i, mr[i - 1], i < nts ? nbg[i] : 0, ts[i] - ts[i - 1]); }
+#endif
+    uint8_t *s_cb = reinterpret_cast<uint8_t *>(s_k);
+    uint32_t *s_cp = reinterpret_cast<uint32_t *>(s_k);
+    // rows R0 .. R0 + c
+    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
+    uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SSS_ITEMS; r++) {
+        const uint32_t p = r * SSS_NT + tid;
+        if (p < c) {
+            const uint32_t v = s_v[p], idx = v >> 8;
+            s_cb[shift + p] = (uint8_t)v;
+            if (SAo) SAo[p] = idx;
+            if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
+        }
+    }
+    __syncthreads();
+    if (O) {
+        const uint32_t end = shift + c;
+        for (uint32_t q = tid; 4 * q < end; q += SSS_NT) {
+            const uint32_t v = s_cp[q];
+            if (4 * q >= shift && 4 * q + 4 <= end) *reinterpret_cast<uint32_t *>(O - shift + 4 * q) = v;
+            else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (4 * q + k >= shift && 4 * q + k < end) O[4 * q + k - shift] = (uint8_t)(v >> (8 * k));
+            }
+        }
+    }
+}
+
+// what this tier gave up on keeps its live count for the general sorter
+__global__ void k_ss_finish(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ list, uint32_t nflag,
+                            uint32_t n, uint32_t *__restrict__ lcnt, uint32_t *__restrict__ nleft)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nflag) {
+        const uint32_t b = list[j], f = flag[b] ? n : 0u;
+        lcnt[b] = f;
+        if (f) atomicAdd(nleft, 1u);
     }
 }
 
@@ -503,7 +971,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     GLC_TRY(hipMemsetAsync(s.fs_hist, 0, (size_t)nblk * 256 * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)nblk * FS_MAXNB * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_flag, 0, (size_t)nblk * 4, st));
-    GLC_TRY(hipMemsetAsync(s.fs_nflag, 0, 4, st));
+    GLC_TRY(hipMemsetAsync(s.fs_nflag, 0, 8, st));
     GLC_TRY(hipMemsetAsync(s.fs_wlcnt, 0, (size_t)nblk * 4, st));
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
@@ -512,10 +980,11 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab);
     pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
-    hipLaunchKernelGGL(k_fs_part, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
-                       nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag);
+    hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
+                       nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag, (const uint32_t *)nullptr,
+                       (const uint64_t *)nullptr);
     if (pi >= 0) s.prof->end(pi, units, st);
-    hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag);
+    hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag, (const uint32_t *)nullptr);
     pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
     hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, n, nbl, s.keyA, s.fs_kstride, s.fs_fill, s.fs_base,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt);
@@ -523,7 +992,26 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_ties, dim3(8, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
-                       s.fs_redo[s.parity & 1]);
+                       s.fs_redo[s.parity & 1], s.ss_list);
+    return hipGetLastError();
+}
+
+hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nflag, SaScratch &s,
+                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out)
+{
+    const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
+    GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
+    GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
+    hipLaunchKernelGGL(k_ss_sample, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, s.ss_list,
+                       s.ss_split, s.ss_flag);
+    hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
+                       n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split);
+    hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
+    hipLaunchKernelGGL(k_ss_sort, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
+                       s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_split, bwt_out, bwt_stride, d_index, sa_out,
+                       (size_t)s.nmax);
+    hipLaunchKernelGGL(k_ss_finish, dim3((nflag + 255) / 256), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, n, s.fs_lcnt,
+                       s.fs_nflag + 1);
     return hipGetLastError();
 }
 

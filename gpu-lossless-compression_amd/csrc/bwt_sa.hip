@@ -831,6 +831,9 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.fs_redo[0], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_redo[1], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_nflag, 8));
+    GLC_TRY(A((void **)&s.ss_list, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.ss_split, (size_t)rows * FS_MAXNB * 8));
+    GLC_TRY(A((void **)&s.ss_flag, (size_t)rows * 4));
     s.fs_wl_cap = nmax / 8 < 1024 ? 1024 : nmax / 8;
     GLC_TRY(A((void **)&s.fs_wl, (size_t)rows * s.fs_wl_cap * 16));
     GLC_TRY(A((void **)&s.fs_wlcnt, (size_t)rows * 4));
@@ -853,7 +856,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
+    void *ps[] = {s.keyA, s.ss_list, s.ss_split, s.ss_flag, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
@@ -1055,10 +1058,21 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
     if (!s.pending) return hipSuccess;                       // general sorter only: nothing was deferred
     s.pending = false;
     GLC_TRY(hipEventSynchronize(s.ev_flag));
-    const uint32_t nflag = s.h_max_cnt[4];
+    uint32_t nflag = s.h_max_cnt[4];
     s.last_flagged = nflag;
+    s.last_general = 0;
     if (nflag == 0) return hipSuccess;
     if (nflagged) *nflagged = nflag;
+    if (s.sorter != 3) {
+        // second tier: string sample sort of the flagged blocks; what it gives up on (very deep repeats) is counted again
+        GLC_TRY(ss_build(st, text, text_stride, n, nflag, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa));
+        GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 5, s.fs_nflag + 1, 4, hipMemcpyDeviceToHost, st));
+        GLC_TRY(hipEventRecord(s.ev_flag, st));
+        GLC_TRY(hipEventSynchronize(s.ev_flag));
+        nflag = s.h_max_cnt[5];
+        if (nflag == 0) return hipSuccess;
+    }
+    s.last_general = nflag;
     return sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nullptr, s.fs_lcnt, nflag);
 }
 

@@ -526,7 +526,7 @@ CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode)
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     SaScratch *s = sa_of(p);
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
-    if (mode < 0 || mode > 2) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (mode < 0 || mode > 3) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     s->sorter = mode;
     return CUDPP_SUCCESS;
 }
@@ -538,6 +538,17 @@ CUDPPResult glcPlanLastSortStats(CUDPPHandle planHandle, unsigned int *flaggedBl
     SaScratch *s = sa_of(p);
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
     *flaggedBlocks = s->last_flagged;
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcPlanLastSortStatsEx(CUDPPHandle planHandle, unsigned int *out2)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out2) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    out2[0] = s->last_flagged;
+    out2[1] = s->last_general;
     return CUDPP_SUCCESS;
 }
 

@@ -98,8 +98,9 @@ struct SaScratch {
     size_t    bytes = 0;
     bool      force_isa = false;                 // tests: skip text refinement, prefix doubling from round 1
     // fast path (bwt_bucket.hip); its words live in keyA/keyB (one allocation, fs_kstride words per block)
-    int       sorter = 0;                        // 0 = bucket sorter, general sorter for the blocks it flags;
-                                                 // 1 = general sorter only; 2 = general sorter, prefix doubling only
+    int       sorter = 0;                        // 0 = bucket sorter, then sample sorter, then general sorter for what each flags;
+                                                 // 1 = general sorter only; 2 = general sorter, prefix doubling only;
+                                                 // 3 = bucket sorter, then general sorter (no sample sorter)
     size_t    fs_kstride = 0;
     uint32_t *fs_hist = nullptr;                 // [rows][256] symbol counts
     uint2    *fs_tab = nullptr;                  // [rows][256] {C, p} scaled to 2^32
@@ -112,7 +113,12 @@ struct SaScratch {
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
     uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
     uint32_t  fs_wl_cap = 0;
-    uint32_t  last_flagged = 0;                  // blocks of the last sa_build that took the general sorter
+    uint32_t  last_flagged = 0;                  // blocks of the last sa_build the bucket sorter gave up on
+    uint32_t  last_general = 0;                  // ... of which the sample sorter gave up on too (general sorter)
+    // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
+    uint32_t *ss_list = nullptr;                 // [rows] their block numbers
+    uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]
+    uint32_t *ss_flag = nullptr;                 // [rows] this tier's give-up flags
     hipEvent_t ev_flag = nullptr;                // marks the readback of fs_nflag (sa_build_begin / sa_build_finish)
     bool      pending = false;
     KernelProf *prof = nullptr;                  // owned by the plan
@@ -139,6 +145,10 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
 hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk, SaScratch &s,
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out);
 uint32_t   fs_bucket_log2(uint32_t n);
+// second tier for the nflag blocks listed in s.ss_list: enqueues only; blocks it gives up on keep n in s.fs_lcnt
+// (the others get 0) and are counted in s.fs_nflag[1]
+hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nflag, SaScratch &s,
+                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out);
 
 // copy SA to the cudppSuffixArray layout (out[0]=n, out[1..n]=SA)
 hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out);

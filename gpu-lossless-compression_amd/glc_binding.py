@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
@@ -96,6 +96,7 @@ def lib():
     L.glcHuffmanEncodeBatch.argtypes = [sz, vp, vp, vp, sz, vp, vp, sz, sz, sz]
     L.glcPlanSetSorter.argtypes = [sz, C.c_int]
     L.glcPlanLastSortStats.argtypes = [sz, C.POINTER(C.c_uint)]
+    L.glcPlanLastSortStatsEx.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
     L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
     L.glcPlanKernelProfile.argtypes = [sz, C.POINTER(C.c_double)]
@@ -239,6 +240,12 @@ class Plan:
         a = C.c_uint(0)
         _chk("glcPlanLastSortStats", lib().glcPlanLastSortStats(self.handle, C.byref(a)))
         return a.value
+
+    def last_sort_stats(self):
+        """(blocks the bucket sorter gave up on, blocks the sample sorter gave up on too) of the last call"""
+        a = (C.c_uint * 2)()
+        _chk("glcPlanLastSortStatsEx", lib().glcPlanLastSortStatsEx(self.handle, a))
+        return a[0], a[1]
 
     def enable_timing(self, mode=1):
         """0 off, 1 stage events, 3 stage events + dominant-kernel events"""

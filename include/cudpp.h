@@ -216,13 +216,17 @@ CUDPPResult glcHuffmanEncodeBatch(CUDPPHandle planHandle, const unsigned char *d
                                   unsigned int *d_compressed, size_t compressedStrideWords, size_t numElements,
                                   size_t numBlocks);
 
-/* Suffix sorter selection (plans of CUDPP_COMPRESS / CUDPP_BWT / CUDPP_SA).  0 (default): the bucket sorter
- * (one bucketing pass + in-LDS sort), with the general sorter for the blocks it flags as too repetitive;
- * 1: general sorter only; 2: general sorter, prefix doubling from the first refinement round.  All three
+/* Suffix sorter selection (plans of CUDPP_COMPRESS / CUDPP_BWT / CUDPP_SA).  0 (default): three tiers -- the
+ * bucket sorter (one bucketing pass + in-LDS sort; i.i.d.-like data), for the blocks it flags the sample sorter
+ * (buckets cut at sampled splitter suffixes, runs of equal codes refined from the text; text, logs), and for
+ * what that flags (repeats deeper than ~500 symbols) the general sorter; 1: general sorter only; 2: general
+ * sorter, prefix doubling from the first refinement round; 3: bucket sorter, then general sorter.  All
  * produce the same bytes (the suffix array of a block is unique); the knob exists for tests and A/B timing. */
 CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode);
-/* number of blocks of the plan's last call that went through the general sorter */
+/* number of blocks of the plan's last call the bucket sorter gave up on (0 for i.i.d.-like data) */
 CUDPPResult glcPlanLastSortStats(CUDPPHandle planHandle, unsigned int *flaggedBlocks);
+/* out2[0] = the same count, out2[1] = how many of those the sample sorter gave up on too (general sorter) */
+CUDPPResult glcPlanLastSortStatsEx(CUDPPHandle planHandle, unsigned int *out2);
 
 /* Result collection: packs the strided per-block streams of a batched compress
  * back to back.  d_outOffsets has numBlocks+1 entries (word offsets; the last is

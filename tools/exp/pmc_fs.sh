@@ -1,6 +1,6 @@
 # instruction counts + duration of the bucket-sorter kernels (one rocprofv3 --pmc pass, --kernel-trace only)
 cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/pm; timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/tools/probe_bwt.py 256 2 > /tmp/l.txt 2>&1
+rm -rf /tmp/pm; timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --kernel-trace -d /tmp/pm -o p -- python $GRAFT_REPO_ROOT/tools/probe_bwt.py 256 2 > /tmp/l.txt 2>&1
 python - <<PY
 import sqlite3,glob
 db=glob.glob("/tmp/pm/**/*.db",recursive=True)
