@@ -615,20 +615,26 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         split[(size_t)b * FS_MAXNB + k] = k ? s_s[(uint32_t)(((uint64_t)k * S) / nb)] : 0ull;
 }
 
-// 7 symbols from position i as 9-bit digits (symbol + 1; 0 behind the end of the block: the shorter suffix is smaller)
+// 7 symbols from position i as 9-bit digits (symbol + 1; 0 behind the end of the block: the shorter suffix is smaller).
+// Two steps so that the loads of all of a thread's suffixes are in flight together: ss_sym_load returns the 8 bytes
+// at T + i (big-endian), or the symbols already as digits when the suffix ends within 12 bytes (bit 63 marks that).
 constexpr uint32_t SS_STEP = 7;
 
-__device__ __forceinline__ uint64_t ss_symkey(const uint8_t *T, uint32_t n, uint32_t i)
+__device__ __forceinline__ uint64_t ss_sym_load(const uint8_t *T, uint32_t n, uint32_t i)
 {
+    if (i + 12 <= n) return fs_load_be64(T + i) >> 1;          // (bit 63 clear; the dropped bit belongs to the 8th byte)
     uint64_t k = 0;
-    if (i + 12 <= n) {
-        const uint64_t be = fs_load_be64(T + i);
 #pragma unroll
-        for (int j = 0; j < (int)SS_STEP; j++) k = (k << 9) | (((be >> (56 - 8 * j)) & 0xFFu) + 1u);
-    } else {
+    for (int j = 0; j < (int)SS_STEP; j++) k = (k << 9) | (i + j < n ? (uint64_t)T[i + j] + 1u : 0ull);
+    return k | (1ull << 63);
+}
+
+__device__ __forceinline__ uint64_t ss_sym_key(uint64_t raw)
+{
+    if (raw >> 63) return raw & ~(1ull << 63);
+    uint64_t k = 0;
 #pragma unroll
-        for (int j = 0; j < (int)SS_STEP; j++) k = (k << 9) | (i + j < n ? (uint64_t)T[i + j] + 1u : 0ull);
-    }
+    for (int j = 0; j < (int)SS_STEP; j++) k = (k << 9) | (((raw >> (55 - 8 * j)) & 0xFFu) + 1u);
     return k;
 }
 
@@ -654,7 +660,7 @@ __device__ __forceinline__ bool ss_suffix_less_from(const uint8_t *T, uint32_t n
     }
 }
 
-constexpr int SSS_NT = 512, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
+constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
 constexpr uint32_t SS_MOVED = 0x80000000u;                     // s_seg: position holds a suffix moved in this round: | wave slot << 8 | bin
 constexpr uint32_t SS_SMALL = 48;                              // runs up to this size are ranked by direct count
 constexpr uint32_t SS_FINISH = 8;                              // once no run is longer, the suffixes themselves are compared
@@ -687,7 +693,7 @@ __device__ __forceinline__ uint64_t wave_sort_u64(uint64_t k, uint32_t lane)
 //     needs no ranking at all; members count into the bins with LDS atomics and are ranked inside their bin.
 // Members with equal keys form the runs of the next round; once all runs are very short the suffixes themselves
 // are compared.  Nothing here depends on the symbol statistics.
-__global__ __launch_bounds__(SSS_NT, 4) void k_ss_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+__global__ __launch_bounds__(SSS_NT) void k_ss_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                     uint32_t nbl, const uint64_t *__restrict__ keys, size_t kstride,
                                                     const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
                                                     uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
@@ -790,11 +796,13 @@ __global__ __launch_bounds__(SSS_NT, 4) void k_ss_sort(const uint8_t *__restrict
                 if ((g >> 16) - ss > 1) {
                     sg[r] = g | 0x40000000u;
                     vv[r] = s_v[p];
-                    key[r] = ss_symkey(T, n, (vv[r] >> 8) + depth);
-                    s_k[p] = key[r];
+                    key[r] = ss_sym_load(T, n, (vv[r] >> 8) + depth);
                 }
             }
         }
+#pragma unroll
+        for (int r = 0; r < SSS_ITEMS; r++)
+            if (sg[r]) { key[r] = ss_sym_key(key[r]); s_k[r * SSS_NT + tid] = key[r]; }
         __syncthreads();
         // B. short runs: rank by direct count; long runs: register
         uint32_t np[SSS_ITEMS], ns[SSS_ITEMS];
@@ -806,7 +814,7 @@ __global__ __launch_bounds__(SSS_NT, 4) void k_ss_sort(const uint8_t *__restrict
                 const uint32_t ss = sg[r] & 0xFFFFu, se = (sg[r] >> 16) & 0x3FFFu;
                 if (se - ss <= SS_SMALL) {
                     uint32_t less = 0, eqt = 0, eqb = 0;
-#pragma clang loop unroll(disable)
+#pragma unroll 4
                     for (uint32_t q = ss; q < se; q++) {
                         const uint64_t kq = s_k[q];
                         less += kq < key[r]; eqt += kq == key[r]; eqb += (kq == key[r]) & (q < p);
@@ -886,13 +894,13 @@ __global__ __launch_bounds__(SSS_NT, 4) void k_ss_sort(const uint8_t *__restrict
                 if (p < c) {
                     const uint32_t g = s_seg[p];
                     if (g & SS_MOVED) {
-                        const uint32_t w = (g >> 8) & 7u, bn = g & 0xFFu, gs = s_cnt[w][bn], ge = s_cnt[w][bn + 1];
+                        const uint32_t w = (g >> 8) & (SSS_WAVES - 1), bn = g & 0xFFu, gs = s_cnt[w][bn], ge = s_cnt[w][bn + 1];
                         mv[r] = s_v[p];
                         if (bn & 1) { mp[r] = p; ms[r] = gs | (ge << 16); if (ge - gs > 1) atomicMax(&s_maxrun, ge - gs); }
                         else {
                             const uint64_t kv = s_k[p];
                             uint32_t less = 0, eqt = 0, eqb = 0;
-#pragma clang loop unroll(disable)
+#pragma unroll 4
                             for (uint32_t q = gs; q < ge; q++) {
                                 const uint64_t kq = s_k[q];
                                 less += kq < kv; eqt += kq == kv; eqb += (kq == kv) & (q < p);
