@@ -34,6 +34,7 @@
 // = 19 B of HBM traffic per input byte (23 with the suffix array) where the 5-pass LSD sorter moves ~105.
 #include "glc_device.h"
 #include "glc_internal.h"
+#include "huff_tree.h"                                         // wave_min_u64
 #include <stdlib.h>
 
 namespace glc {
@@ -661,10 +662,12 @@ __device__ __forceinline__ bool ss_suffix_less_from(const uint8_t *T, uint32_t n
 }
 
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
-constexpr uint32_t SS_MOVED = 0x80000000u;                     // s_seg: position holds a suffix moved in this round: | wave slot << 8 | bin
-constexpr uint32_t SS_SMALL = 48;                              // runs up to this size are ranked by direct count
-constexpr uint32_t SS_FINISH = 8;                              // once no run is longer, the suffixes themselves are compared
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
+constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
+constexpr uint32_t SS_MAXSTEP = FS_LCP_CAP / SS_STEP + 1;      // rounds of a run before the block is given up as deep
+
+// run descriptor of a position: start : 12 | end : 12 | rounds done : 8   (a decided position: end = start + 1)
+__device__ __forceinline__ uint32_t ss_run(uint32_t ss, uint32_t se, uint32_t st) { return ss | (se << 12) | (st << 24); }
 
 // sorts one key per lane across the wave (ascending by lane)
 __device__ __forceinline__ uint64_t wave_sort_u64(uint64_t k, uint32_t lane)
@@ -683,17 +686,38 @@ __device__ __forceinline__ uint64_t wave_sort_u64(uint64_t k, uint32_t lane)
     return k;
 }
 
+// bin of a key among 64 sorted pivots held one per lane: 2 i = between pivot i-1 and pivot i, 2 i + 1 = equal to pivot i
+// (the first of equal pivots).  All lanes must call it together.
+__device__ __forceinline__ uint32_t ss_pivot_bin(uint64_t piv, uint64_t key)
+{
+    uint32_t lo = 0, hi = SS_NPIV;                             // first pivot >= key
+#pragma unroll
+    for (int it = 0; it < 7; it++) {
+        const uint32_t mid = (lo + hi) >> 1, m = mid < SS_NPIV ? mid : SS_NPIV - 1;
+        const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)piv, (int)m), phi = (uint32_t)__shfl((int)(uint32_t)(piv >> 32), (int)m);
+        const uint64_t pm = ((uint64_t)phi << 32) | plo;
+        if (lo < hi) { if (pm < key) lo = mid + 1; else hi = mid; }
+    }
+    const uint32_t l = lo < SS_NPIV ? lo : SS_NPIV - 1;
+    const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)piv, (int)l), phi = (uint32_t)__shfl((int)(uint32_t)(piv >> 32), (int)l);
+    const uint64_t pl = ((uint64_t)phi << 32) | plo;
+    return 2 * lo + ((lo < SS_NPIV && pl == key) ? 1u : 0u);
+}
+
 // One workgroup per bucket; the suffixes are ordered in rounds of 7 symbols read from the text.  A RUN is a range of
-// positions whose suffixes agree in everything looked at so far; the whole bucket is the first run.  In a round
-// every member of a run gets the key of its next 7 symbols and is ranked inside its run:
-//   * a short run by direct count (a member reads the keys of its run),
-//   * a long run through 64 PIVOTS -- keys of 64 of its members, sorted by one wave -- which cut it into the bins
-//     "between two pivots" / "equal to a pivot": whatever the key distribution is (text is anything but uniform),
-//     the between-bins are small, and a key that hundreds of members share is almost surely a pivot, whose bin
-//     needs no ranking at all; members count into the bins with LDS atomics and are ranked inside their bin.
-// Members with equal keys form the runs of the next round; once all runs are very short the suffixes themselves
-// are compared.  Nothing here depends on the symbol statistics.
-__global__ __launch_bounds__(SSS_NT) void k_ss_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+// positions whose suffixes agree in everything looked at so far (each run carries its own depth); the whole
+// bucket is the first run.
+//   * A LONG run is cut with 64 PIVOTS -- keys of 64 of its members, sorted by one wave -- into the bins "between
+//     two pivots" (runs at the same depth, ~1/65 of the size whatever the key distribution is: text is anything
+//     but uniform) and "equal to a pivot" (runs one round deeper; a key that hundreds of members share is almost
+//     surely a pivot).  Members count into the bins with LDS atomics.  The first cut is made by the whole
+//     workgroup.
+//   * After it every WAVE owns a range of positions and works alone, with no workgroup barrier: windows of up to
+//     256 positions are finished in registers (4 per lane; a member reads the keys of its run and counts the
+//     smaller ones; equal keys = a run of the next round), longer runs are cut again by the wave.
+// 32 waves per CU, each a chain of LDS and L2 latencies, keep the CU busy between them.  Nothing here depends on
+// the symbol statistics.
+__global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                     uint32_t nbl, const uint64_t *__restrict__ keys, size_t kstride,
                                                     const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
                                                     uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
@@ -701,13 +725,12 @@ __global__ __launch_bounds__(SSS_NT) void k_ss_sort(const uint8_t *__restrict__ 
                                                     size_t bwt_stride, int *__restrict__ d_index,
                                                     uint32_t *__restrict__ sa_out, size_t sa_stride)
 {
-    __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position (this round); at the end the BWT bytes
+    __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position; scratch of a cut; at the end the BWT bytes
     __shared__ uint32_t s_v[FS_FILLMAX];                       // index << 8 | BWT byte of the suffix at a position
-    __shared__ uint32_t s_seg[FS_FILLMAX];                     // run a position belongs to: start | end << 16  (or SS_MOVED | ...)
-    __shared__ uint64_t s_piv[SSS_WAVES][SS_NPIV];
-    __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end)
-    __shared__ uint32_t s_big[FS_FILLMAX / SS_SMALL + 2];      // the long runs of this round (start | end << 16)
-    __shared__ uint32_t s_deep, s_l0, s_maxrun, s_nbig;
+    __shared__ uint32_t s_seg[FS_FILLMAX];                     // run of a position (ss_run)
+    __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end), of the cut a wave is making
+    __shared__ uint64_t s_piv0[SS_NPIV];                       // pivots of the first cut
+    __shared__ uint32_t s_deep, s_l0;
     const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x, nb = 1u << nbl;
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint8_t *T = text + (size_t)b * stride;
@@ -716,7 +739,6 @@ __global__ __launch_bounds__(SSS_NT) void k_ss_sort(const uint8_t *__restrict__ 
     const uint64_t *SP = split + (size_t)b * FS_MAXNB;
     if (tid == 0) {
         s_deep = flag[b];
-        s_maxrun = c;
         // every suffix of the bucket lies between its two splitters and shares their common prefix
         uint32_t l0 = 0;
         if (bk >= 1 && bk + 1 < nb && c > 1) {
@@ -733,196 +755,197 @@ __global__ __launch_bounds__(SSS_NT) void k_ss_sort(const uint8_t *__restrict__ 
         s_l0 = l0;
     }
     const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
-    if (c <= FS_FILLMAX) {
-        for (uint32_t i = tid; i < c; i += SSS_NT) {
-            s_v[i] = (uint32_t)(K[i] & FS_LOW_MASK);
-            s_seg[i] = c << 16;                                // one run: the whole bucket
-        }
+    // ---- first cut, by the whole workgroup (thread = the positions r NT + tid) ----
+    uint32_t vv[SSS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SSS_ITEMS; r++) {
+        const uint32_t p = r * SSS_NT + tid;
+        vv[r] = (c <= FS_FILLMAX && p < c) ? (uint32_t)(K[p] & FS_LOW_MASK) : 0u;
     }
+    for (uint32_t i = tid; i < SSS_WAVES * (SS_NBIN + 3); i += SSS_NT) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     if (s_deep || c == 0 || c > FS_FILLMAX) return;
     const uint32_t l0 = s_l0;
-    uint32_t depth = l0;
-#ifdef SS_DBG
-    const bool dbg = blockIdx.y == 0 && (bk == 1 || bk == 100 || bk == 300) && tid == 0;
-    long long ts[24]; uint32_t mr[24], nbg[24]; int nts = 0;
-#endif
-    for (;;) {
-        const uint32_t maxrun = s_maxrun;                      // of the previous round (uniform: read behind a barrier)
-#ifdef SS_DBG
-        if (nts < 24) { ts[nts] = wall_clock64(); mr[nts] = maxrun; nbg[nts] = s_nbig; nts++; }
-#endif
-        if (maxrun <= 1) break;
-        __syncthreads();
-        if (depth - l0 > FS_LCP_CAP) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-        if (maxrun <= SS_FINISH) {
-            // every run is very short: each member counts the members of its run that are smaller, by comparing the suffixes
-            uint32_t np[SSS_ITEMS], vv[SSS_ITEMS];
-            bool deep = false;
-#pragma unroll
-            for (int r = 0; r < SSS_ITEMS; r++) {
-                const uint32_t p = r * SSS_NT + tid;
-                np[r] = 0xFFFFFFFFu;
-                if (r * SSS_NT >= c) continue;
-                if (p < c) {
-                    const uint32_t g = s_seg[p], ss = g & 0xFFFFu, se = g >> 16;
-                    if (se - ss > 1) {
-                        vv[r] = s_v[p];
-                        uint32_t less = 0;
-                        for (uint32_t q = ss; q < se; q++)
-                            if (q != p) less += ss_suffix_less_from(T, n, s_v[q] >> 8, vv[r] >> 8, depth, &deep) ? 1u : 0u;
-                        np[r] = ss + less;
-                    }
-                }
-            }
-            if (__syncthreads_or((int)deep)) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-#pragma unroll
-            for (int r = 0; r < SSS_ITEMS; r++)
-                if (np[r] != 0xFFFFFFFFu) s_v[np[r]] = vv[r];
-            __syncthreads();
-            break;
-        }
-        if (tid == 0) { s_maxrun = 0; s_nbig = 0; }
-        // A. keys of the undecided suffixes (thread = the positions r NT + tid), left at their positions
+    if (c == 1) { if (tid == 0) { s_v[0] = vv[0]; s_seg[0] = ss_run(0, 1, 0); } }
+    else {
         uint64_t key[SSS_ITEMS];
-        uint32_t vv[SSS_ITEMS], sg[SSS_ITEMS];                 // sg: run of the member | 1 << 30 (0 = decided)
 #pragma unroll
         for (int r = 0; r < SSS_ITEMS; r++) {
             const uint32_t p = r * SSS_NT + tid;
-            sg[r] = 0;
+            key[r] = p < c ? ss_sym_load(T, n, (vv[r] >> 8) + l0) : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < SSS_ITEMS; r++) {
+            const uint32_t p = r * SSS_NT + tid;
+            if (p < c) { key[r] = ss_sym_key(key[r]); s_k[p] = key[r]; }
+        }
+        __syncthreads();
+        if (wv == 0) s_piv0[lane] = wave_sort_u64(s_k[(lane * c) / SS_NPIV], lane);
+        __syncthreads();
+        const uint64_t piv = s_piv0[lane];
+        uint32_t bin[SSS_ITEMS], rk[SSS_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SSS_ITEMS; r++) {
+            const uint32_t p = r * SSS_NT + tid;
+            if (r * SSS_NT >= c) continue;                     // (uniform; ss_pivot_bin shuffles across the whole wave)
+            bin[r] = ss_pivot_bin(piv, key[r]);
+            if (p < c) rk[r] = atomicAdd(&s_cnt[0][bin[r]], 1u);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            uint32_t c3[3], tot = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; c3[k] = i < SS_NBIN ? s_cnt[0][i] : 0u; tot += c3[k]; }
+            uint32_t run = wave_incl_add(tot) - tot;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; if (i <= SS_NBIN) s_cnt[0][i] = run; run += c3[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SSS_ITEMS; r++) {
+            const uint32_t p = r * SSS_NT + tid;
             if (r * SSS_NT >= c) continue;
             if (p < c) {
-                const uint32_t g = s_seg[p], ss = g & 0xFFFFu;
-                if ((g >> 16) - ss > 1) {
-                    sg[r] = g | 0x40000000u;
-                    vv[r] = s_v[p];
-                    key[r] = ss_sym_load(T, n, (vv[r] >> 8) + depth);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < SSS_ITEMS; r++)
-            if (sg[r]) { key[r] = ss_sym_key(key[r]); s_k[r * SSS_NT + tid] = key[r]; }
-        __syncthreads();
-        // B. short runs: rank by direct count; long runs: register
-        uint32_t np[SSS_ITEMS], ns[SSS_ITEMS];
-#pragma unroll
-        for (int r = 0; r < SSS_ITEMS; r++) {
-            const uint32_t p = r * SSS_NT + tid;
-            np[r] = 0xFFFFFFFFu;
-            if (sg[r]) {
-                const uint32_t ss = sg[r] & 0xFFFFu, se = (sg[r] >> 16) & 0x3FFFu;
-                if (se - ss <= SS_SMALL) {
-                    uint32_t less = 0, eqt = 0, eqb = 0;
-#pragma unroll 4
-                    for (uint32_t q = ss; q < se; q++) {
-                        const uint64_t kq = s_k[q];
-                        less += kq < key[r]; eqt += kq == key[r]; eqb += (kq == key[r]) & (q < p);
-                    }
-                    np[r] = ss + less + eqb;
-                    ns[r] = (ss + less) | ((ss + less + eqt) << 16);
-                    if (eqt > 1) atomicMax(&s_maxrun, eqt);
-                } else if (p == ss) s_big[atomicAdd(&s_nbig, 1u)] = ss | (se << 16);
+                const uint32_t gs = s_cnt[0][bin[r]], ge = s_cnt[0][bin[r] + 1], q = gs + rk[r];
+                s_v[q] = vv[r];
+                s_seg[q] = ss_run(gs, ge, bin[r] & 1);         // a pivot's bin: all keys equal, one round done
             }
         }
         __syncthreads();
+        if (tid < SS_NBIN + 3) s_cnt[0][tid] = 0;
+    }
+    __syncthreads();
+    // ---- every wave finishes its share [A, B) of the positions: shares end where a run ends ----
+    {
+        uint32_t A = (uint32_t)(((uint64_t)c * wv) / SSS_WAVES), B = (uint32_t)(((uint64_t)c * (wv + 1)) / SSS_WAVES);
+        if (A > 0 && A < c) { const uint32_t g = s_seg[A]; if ((g & 0xFFFu) < A) A = (g >> 12) & 0xFFFu; }
+        if (B < c) { const uint32_t g = s_seg[B]; if ((g & 0xFFFu) < B) B = (g >> 12) & 0xFFFu; }
+        if (A > B) A = B;
+        uint32_t *cnt = s_cnt[wv];
+        uint32_t pos = A;
+        while (pos < B) {
+            if (s_deep) break;                                 // (another wave gave the block up)
+            // window [pos, W): the runs that start in it and end within SS_WIN positions
+            const uint32_t lim = min(B, pos + SS_WIN);
+            uint32_t g4[4], W = lim;
+            bool und = false;
 #pragma unroll
-        for (int r = 0; r < SSS_ITEMS; r++)
-            if (np[r] != 0xFFFFFFFFu) { s_v[np[r]] = vv[r]; s_seg[np[r]] = ns[r]; sg[r] = 0; }
-        // C. long runs, one per wave at a time
-        const uint32_t nbig = s_nbig;
-        for (uint32_t g0 = 0; g0 < nbig; g0 += SSS_WAVES) {
-            __syncthreads();
-            {   // pivots of this wave's run, sorted; counters cleared
-                const uint32_t gi = g0 + wv;
-                if (gi < nbig) {
-                    const uint32_t rs = s_big[gi] & 0xFFFFu, rsz = (s_big[gi] >> 16) - rs;
-                    const uint64_t pk = wave_sort_u64(s_k[rs + (lane * rsz) / SS_NPIV], lane);
-                    s_piv[wv][lane] = pk;
-                }
-                for (uint32_t i = lane; i < SS_NBIN + 3; i += 64) s_cnt[wv][i] = 0;
-            }
-            __syncthreads();
-            // members of these runs: bin among the pivots
-            uint32_t bin[SSS_ITEMS], rk[SSS_ITEMS], slot[SSS_ITEMS];
-#pragma unroll
-            for (int r = 0; r < SSS_ITEMS; r++) {
-                slot[r] = 0xFFFFFFFFu;
-                if (sg[r]) {
-                    const uint32_t me = (sg[r] & 0xFFFFu) | (((sg[r] >> 16) & 0x3FFFu) << 16);
-                    for (uint32_t w = 0; w < SSS_WAVES; w++)
-                        if (g0 + w < nbig && s_big[g0 + w] == me) slot[r] = w;
-                    if (slot[r] != 0xFFFFFFFFu) {
-                        const uint64_t *P = s_piv[slot[r]];
-                        uint32_t lo = 0, hi = SS_NPIV;         // first pivot >= key
-                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (P[mid] < key[r]) lo = mid + 1; else hi = mid; }
-                        bin[r] = 2 * lo + ((lo < SS_NPIV && P[lo] == key[r]) ? 1u : 0u);
-                        rk[r] = atomicAdd(&s_cnt[slot[r]][bin[r]], 1u);
-                    }
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = pos + lane + 64 * j;
+                g4[j] = p < lim ? s_seg[p] : 0u;
+                if (p < lim) {
+                    const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu;
+                    if (se > lim) W = min(W, ss);              // a run that runs out of the window: the window ends before it
+                    und |= se - ss > 1;
                 }
             }
-            __syncthreads();
-            {   // bin starts of this wave's run: exclusive scan of its counters, offset by the run's start
-                const uint32_t gi = g0 + wv;
-                if (gi < nbig) {
-                    const uint32_t rs = s_big[gi] & 0xFFFFu;
+            W = (uint32_t)wave_min_u64((uint64_t)W);
+            if (W == pos) {
+                // ---- the run at pos is longer than a window: cut it with pivots ----
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g4[0]);
+                const uint32_t ss = g & 0xFFFu, se = (g >> 12) & 0xFFFu, st = g >> 24, gsz = se - ss;
+                if (st > SS_MAXSTEP) { s_deep = 1; break; }
+                for (uint32_t p0 = ss; p0 < se; p0 += 256) {   // keys of the members, 4 loads in flight per lane
+                    uint64_t raw[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const uint32_t p = p0 + lane + 64 * j; raw[j] = p < se ? ss_sym_load(T, n, (s_v[p] >> 8) + l0 + SS_STEP * st) : 0ull; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const uint32_t p = p0 + lane + 64 * j; if (p < se) s_k[p] = ss_sym_key(raw[j]); }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint64_t piv = wave_sort_u64(s_k[ss + (lane * gsz) / SS_NPIV], lane);
+                for (uint32_t p0 = ss; p0 < se; p0 += 64) {    // bin and arrival rank of every member -> s_seg (the run's descriptor is in g)
+                    const uint32_t p = p0 + lane;
+                    const uint32_t bn = ss_pivot_bin(piv, p < se ? s_k[p] : 0ull);
+                    if (p < se) s_seg[p] = bn | (atomicAdd(&cnt[bn], 1u) << 8);
+                }
+                __builtin_amdgcn_wave_barrier();
+                {
                     uint32_t c3[3], tot = 0;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; c3[k] = i < SS_NBIN ? s_cnt[wv][i] : 0u; tot += c3[k]; }
-                    uint32_t run = rs + wave_incl_add(tot) - tot;
+                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; c3[k] = i < SS_NBIN ? cnt[i] : 0u; tot += c3[k]; }
+                    uint32_t run = ss + wave_incl_add(tot) - tot;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; if (i <= SS_NBIN) s_cnt[wv][i] = run; run += c3[k]; }
+                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; if (i <= SS_NBIN) cnt[i] = run; run += c3[k]; }
                 }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < SSS_ITEMS; r++) {
-                if (slot[r] != 0xFFFFFFFFu) {
-                    const uint32_t q = s_cnt[slot[r]][bin[r]] + rk[r];
-                    s_k[q] = key[r]; s_v[q] = vv[r]; s_seg[q] = SS_MOVED | (slot[r] << 8) | bin[r];
-                    sg[r] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t p0 = ss; p0 < se; p0 += 64) {    // to the bins, through s_k (the keys are used up)
+                    const uint32_t p = p0 + lane;
+                    if (p < se) {
+                        const uint32_t x = s_seg[p], bn = x & 0xFFu, gs = cnt[bn], ge = cnt[bn + 1];
+                        s_k[gs + (x >> 8)] = (uint64_t)s_v[p] | ((uint64_t)ss_run(gs, ge, st + (bn & 1)) << 32);
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t p0 = ss; p0 < se; p0 += 64) {
+                    const uint32_t p = p0 + lane;
+                    if (p < se) { const uint64_t x = s_k[p]; s_v[p] = (uint32_t)x; s_seg[p] = (uint32_t)(x >> 32); }
+                }
+                for (uint32_t i = lane; i < SS_NBIN + 3; i += 64) cnt[i] = 0;
+                __builtin_amdgcn_wave_barrier();
+                continue;                                      // look at pos again: the runs there are shorter or deeper now
             }
-            __syncthreads();
-            // position inside the bin (thread = the positions again): a pivot's bin is a finished run of equal keys
-            uint32_t mp[SSS_ITEMS], ms[SSS_ITEMS], mv[SSS_ITEMS];
+            // ---- window [pos, W): rounds in registers until every position is decided ----
+            while (__ballot(und) != 0) {
+                uint64_t key[4];
+                uint32_t v4[4];
+                bool dp = false;
 #pragma unroll
-            for (int r = 0; r < SSS_ITEMS; r++) {
-                const uint32_t p = r * SSS_NT + tid;
-                mp[r] = 0xFFFFFFFFu;
-                if (r * SSS_NT >= c) continue;
-                if (p < c) {
-                    const uint32_t g = s_seg[p];
-                    if (g & SS_MOVED) {
-                        const uint32_t w = (g >> 8) & (SSS_WAVES - 1), bn = g & 0xFFu, gs = s_cnt[w][bn], ge = s_cnt[w][bn + 1];
-                        mv[r] = s_v[p];
-                        if (bn & 1) { mp[r] = p; ms[r] = gs | (ge << 16); if (ge - gs > 1) atomicMax(&s_maxrun, ge - gs); }
-                        else {
-                            const uint64_t kv = s_k[p];
-                            uint32_t less = 0, eqt = 0, eqb = 0;
-#pragma unroll 4
-                            for (uint32_t q = gs; q < ge; q++) {
-                                const uint64_t kq = s_k[q];
-                                less += kq < kv; eqt += kq == kv; eqb += (kq == kv) & (q < p);
-                            }
-                            mp[r] = gs + less + eqb;
-                            ms[r] = (gs + less) | ((gs + less + eqt) << 16);
-                            if (eqt > 1) atomicMax(&s_maxrun, eqt);
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t p = pos + lane + 64 * j;
+                    key[j] = 0; v4[j] = 0;
+                    if (p < W) {
+                        const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
+                        if (se - ss > 1) {
+                            v4[j] = s_v[p];
+                            key[j] = ss_sym_load(T, n, (v4[j] >> 8) + l0 + SS_STEP * st);
+                            dp |= st > SS_MAXSTEP;
                         }
                     }
                 }
-            }
-            __syncthreads();
+                if (__ballot(dp) != 0) { s_deep = 1; break; }
 #pragma unroll
-            for (int r = 0; r < SSS_ITEMS; r++)
-                if (mp[r] != 0xFFFFFFFFu) { s_v[mp[r]] = mv[r]; s_seg[mp[r]] = ms[r]; }
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t p = pos + lane + 64 * j;
+                    if (p < W && ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) { key[j] = ss_sym_key(key[j]); s_k[p] = key[j]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t np[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t p = pos + lane + 64 * j;
+                    np[j] = 0xFFFFFFFFu;
+                    if (p < W) {
+                        const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
+                        if (se - ss > 1) {
+                            uint32_t less = 0, eqt = 0, eqb = 0;
+#pragma unroll 4
+                            for (uint32_t q = ss; q < se; q++) {
+                                const uint64_t kq = s_k[q];
+                                less += kq < key[j]; eqt += kq == key[j]; eqb += (kq == key[j]) & (q < p);
+                            }
+                            np[j] = ss + less + eqb;
+                            g4[j] = ss_run(ss + less, ss + less + eqt, st + 1);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (np[j] != 0xFFFFFFFFu) { s_v[np[j]] = v4[j]; s_seg[np[j]] = g4[j]; }
+                __builtin_amdgcn_wave_barrier();
+                und = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t p = pos + lane + 64 * j;
+                    if (p < W) { g4[j] = s_seg[p]; und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1; }
+                }
+            }
+            pos = W;
         }
-        __syncthreads();
-        depth += SS_STEP;
     }
-#ifdef SS_DBG
-    if (dbg) { ts[nts] = wall_clock64(); for (int i = 1; i <= nts; i++) printf("bk %u c %u l0 %u round %d maxrun-before %u nbig %u dt %lld\n", bk, c, l0, i, mr[i - 1], i < nts ? nbg[i] : 0, ts[i] - ts[i - 1]); }
-#endif
+    __syncthreads();
+    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
     uint8_t *s_cb = reinterpret_cast<uint8_t *>(s_k);
     uint32_t *s_cp = reinterpret_cast<uint32_t *>(s_k);
     // rows R0 .. R0 + c
