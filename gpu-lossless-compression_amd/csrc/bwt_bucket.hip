@@ -47,6 +47,7 @@ constexpr int      FSS_ITEMS = FS_CAP / FSS_NT;     // slots per thread
 constexpr uint32_t FS_BIN_BITS = 12, FS_BINS = 1u << FS_BIN_BITS;
 constexpr uint32_t FS_MAX_GROUP = 512;              // longest run of equal codes ranked by direct count
 constexpr uint64_t FS_LOW_MASK = (1ull << 28) - 1;  // [index : 20 | bwt : 8]
+constexpr uint32_t SS_CELLS = 4096;                 // sample tier: cells of the code space (leading 12 bits) that index the splitters
 
 // at least 16 buckets: k_fs_sort compares bits 28..59 of the words, so the four bits above must be bucket number
 uint32_t fs_bucket_log2(uint32_t n)
@@ -126,14 +127,14 @@ __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ 
 // ---------------------------------------------------------------------------
 constexpr uint32_t FS_LCP_CAP = 512;                           // a longer common prefix flags the block as deep
 
+// 8 bytes at any address as a big-endian number: ONE unaligned 8-byte load (global memory takes any alignment on
+// gfx9+; built from aligned dwords it is three scattered loads per lane, and the gathers of the refinement
+// rounds are bound by the number of addresses the texture path takes per clock)
 __device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
 {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3) * 8;
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-    return ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
+    uint64_t x;
+    __builtin_memcpy(&x, p, 8);
+    return __builtin_bswap64(x);
 }
 
 // suffix a < suffix b ?  (a != b; the shorter of two suffixes that agree to the end of one is the smaller)
@@ -162,12 +163,15 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
 // ---------------------------------------------------------------------------
 // SPLIT = the sample tier's form: blocks come from a list, and the bucket of a word is found among the block's
 // splitter suffixes (code first, text on equal codes) instead of in the top bits of the code.
-__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, uint32_t nb, uint64_t w, const uint8_t *T, uint32_t n,
-                                              bool *deep)
+__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint16_t *cell, uint64_t w, const uint8_t *T,
+                                              uint32_t n, bool *deep)
 {
     const uint64_t cw = w >> 28;
     const uint32_t iw = (uint32_t)(w >> 8) & 0xFFFFFu;
-    uint32_t lo = 0, hi = nb;                                  // the answer is in [lo, hi): splitter[lo] <= w < splitter[hi]
+    // the splitters whose code starts with the same 12 bits are the only ones to look at (cell[x] = first splitter,
+    // counted from 1, whose leading 12 code bits are >= x): mostly none or one
+    const uint32_t x = (uint32_t)(cw >> 24);
+    uint32_t lo = (uint32_t)cell[x] - 1u, hi = cell[x + 1];    // the answer is in [lo, hi): splitter[lo] <= w < splitter[hi]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         const uint64_t sw = sp[mid], cs = sw >> 28;
@@ -187,20 +191,31 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
                                                     uint32_t nbl, const uint2 *__restrict__ tab,
                                                     uint64_t *__restrict__ keys, size_t kstride,
                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
-                                                    const uint32_t *__restrict__ list, const uint64_t *__restrict__ split)
+                                                    const uint32_t *__restrict__ list, const uint64_t *__restrict__ split,
+                                                    const uint16_t *__restrict__ cell)
 {
     __shared__ uint32_t s_cnt[FS_MAXNB], s_start[FS_MAXNB], s_gbase[FS_MAXNB];
     __shared__ uint64_t s_w[FSP_TILE];
     __shared__ uint32_t s_tmp[FSP_NT / 64 + 1];
+    __shared__ uint16_t s_bk[SPLIT ? FSP_TILE : 1];            // (SPLIT) bucket of the word at a position: not in the word's top bits there
     // the symbol table and the staged text are dead before the first word is bucketed: they live inside s_w
     // (38 KB instead of 44 KB of LDS: 4 workgroups per CU instead of 3)
     uint2 *s_tab = reinterpret_cast<uint2 *>(s_w);
     uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_w) + 256 * sizeof(uint2);   // s_txt[k] = T[base - 1 + k]; 16-byte aligned
     const uint32_t b = SPLIT ? list[blockIdx.y] : blockIdx.y, tid = threadIdx.x, base = blockIdx.x * FSP_TILE;
     if (base >= n) return;
+    if (SPLIT) {                                               // given up while sampling: no splitters to search
+        if (tid == 0) s_tmp[0] = flag[b];                      // (one read: other tiles of this launch may flag the block meanwhile)
+        __syncthreads();
+        if (s_tmp[0]) return;
+    }
     const uint8_t *T = text + (size_t)b * stride;
     uint64_t *s_split = s_w + 1024;                            // (SPLIT) behind the table and the staged text, dead with them
-    if (SPLIT) for (uint32_t i = tid; i < (1u << nbl); i += FSP_NT) s_split[i] = split[(size_t)b * FS_MAXNB + i];
+    uint16_t *s_cell = reinterpret_cast<uint16_t *>(s_w + 1024 + FS_MAXNB);
+    if (SPLIT) {
+        for (uint32_t i = tid; i < (1u << nbl); i += FSP_NT) s_split[i] = split[(size_t)b * FS_MAXNB + i];
+        for (uint32_t i = tid; i < SS_CELLS + 2; i += FSP_NT) s_cell[i] = cell[(size_t)b * (SS_CELLS + 2) + i];
+    }
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
     if (tid < FS_MAXNB) s_cnt[tid] = 0;
     const bool edge = base + FSP_TILE + 16 > n;
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
         uint32_t bk;
         if (SPLIT) {
             bool deep = false;
-            bk = gi < n ? ss_bucket(s_split, 1u << nbl, w[j], T, n, &deep) : 0u;
+            bk = gi < n ? ss_bucket(s_split, s_cell, w[j], T, n, &deep) : 0u;
             if (deep) atomicOr(&flag[b], 2u);
         } else bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
         br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
@@ -271,7 +286,11 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < FSP_ITEMS; j++)
-        if (gi0 + j < n) s_w[s_start[br[j] >> 16] + (br[j] & 0xFFFFu)] = w[j];
+        if (gi0 + j < n) {
+            const uint32_t q = s_start[br[j] >> 16] + (br[j] & 0xFFFFu);
+            s_w[q] = w[j];
+            if (SPLIT) s_bk[q] = (uint16_t)(br[j] >> 16);
+        }
     __syncthreads();
     const uint32_t tile_n = min((uint32_t)FSP_TILE, n - base);
     uint64_t *K = keys + (size_t)b * kstride;
@@ -281,11 +300,8 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
         if (p < tile_n) {
             const uint64_t ww = s_w[p];
             uint32_t d;
-            if (SPLIT) {                                       // bucket of position p: the last one that starts at or before p
-                uint32_t lo = 0, hi = 1u << nbl;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= p) lo = mid; else hi = mid; }
-                d = lo;
-                while (d + 1 < (1u << nbl) && s_start[d + 1] <= p) d++;    // (empty buckets share a start: take the last)
+            if (SPLIT) {
+                d = s_bk[p];
             } else d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
             const uint32_t off = s_gbase[d] + (p - s_start[d]);
             if (off < FS_CAP) K[(size_t)d * FS_CAP + off] = ww;
@@ -573,7 +589,7 @@ __device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8
 __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                       uint32_t nbl, const uint2 *__restrict__ tab,
                                                       const uint32_t *__restrict__ list, uint64_t *__restrict__ split,
-                                                      uint32_t *__restrict__ flag)
+                                                      uint16_t *__restrict__ cell, uint32_t *__restrict__ flag)
 {
     __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
     __shared__ uint2 s_tab[256];
@@ -614,6 +630,15 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
     for (uint32_t k = tid; k < nb; k += SSA_NT)
         split[(size_t)b * FS_MAXNB + k] = k ? s_s[(uint32_t)(((uint64_t)k * S) / nb)] : 0ull;
+    // cell[x] = first splitter (counted from 1) whose leading 12 code bits are >= x; nb if there is none
+    for (uint32_t x = tid; x < SS_CELLS + 2; x += SSA_NT) {
+        uint32_t lo = 1, hi = nb;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint32_t)(s_s[(uint32_t)(((uint64_t)mid * S) / nb)] >> 52) < x) lo = mid + 1; else hi = mid;
+        }
+        cell[(size_t)b * (SS_CELLS + 2) + x] = (uint16_t)lo;
+    }
 }
 
 // 7 symbols from position i as 9-bit digits (symbol + 1; 0 behind the end of the block: the shorter suffix is smaller).
@@ -663,6 +688,7 @@ __device__ __forceinline__ bool ss_suffix_less_from(const uint8_t *T, uint32_t n
 
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
+constexpr uint32_t SS_SHARES = 64;                             // shares of a bucket's positions handed out to the waves
 constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
 constexpr uint32_t SS_MAXSTEP = FS_LCP_CAP / SS_STEP + 1;      // rounds of a run before the block is given up as deep
 
@@ -730,7 +756,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
     __shared__ uint32_t s_seg[FS_FILLMAX];                     // run of a position (ss_run)
     __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end), of the cut a wave is making
     __shared__ uint64_t s_piv0[SS_NPIV];                       // pivots of the first cut
-    __shared__ uint32_t s_deep, s_l0;
+    __shared__ uint32_t s_deep, s_l0, s_next, s_bound[SS_SHARES + 1];
     const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x, nb = 1u << nbl;
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint8_t *T = text + (size_t)b * stride;
@@ -739,6 +765,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
     const uint64_t *SP = split + (size_t)b * FS_MAXNB;
     if (tid == 0) {
         s_deep = flag[b];
+        s_next = 0;
         // every suffix of the bucket lies between its two splitters and shares their common prefix
         uint32_t l0 = 0;
         if (bk >= 1 && bk + 1 < nb && c > 1) {
@@ -815,12 +842,20 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
         if (tid < SS_NBIN + 3) s_cnt[0][tid] = 0;
     }
     __syncthreads();
-    // ---- every wave finishes its share [A, B) of the positions: shares end where a run ends ----
-    {
-        uint32_t A = (uint32_t)(((uint64_t)c * wv) / SSS_WAVES), B = (uint32_t)(((uint64_t)c * (wv + 1)) / SSS_WAVES);
+    // ---- the waves finish shares [A, B) of the positions; a share ends where a run ends (fixed now, before any run moves) ----
+    if (tid <= SS_SHARES) {
+        uint32_t A = (uint32_t)(((uint64_t)c * tid) / SS_SHARES);
         if (A > 0 && A < c) { const uint32_t g = s_seg[A]; if ((g & 0xFFFu) < A) A = (g >> 12) & 0xFFFu; }
-        if (B < c) { const uint32_t g = s_seg[B]; if ((g & 0xFFFu) < B) B = (g >> 12) & 0xFFFu; }
-        if (A > B) A = B;
+        s_bound[tid] = A;
+    }
+    __syncthreads();
+    for (;;) {
+        // shares are handed out first come, first served: a wave stuck with a long run does not hold the others up
+        uint32_t ch = 0;
+        if (lane == 0) ch = atomicAdd(&s_next, 1u);
+        ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
+        if (ch >= SS_SHARES) break;
+        const uint32_t A = s_bound[ch], B = s_bound[ch + 1];
         uint32_t *cnt = s_cnt[wv];
         uint32_t pos = A;
         while (pos < B) {
@@ -1013,7 +1048,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
     hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
                        nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag, (const uint32_t *)nullptr,
-                       (const uint64_t *)nullptr);
+                       (const uint64_t *)nullptr, (const uint16_t *)nullptr);
     if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag, (const uint32_t *)nullptr);
     pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
@@ -1034,9 +1069,9 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
     hipLaunchKernelGGL(k_ss_sample, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, s.ss_list,
-                       s.ss_split, s.ss_flag);
+                       s.ss_split, s.ss_cell, s.ss_flag);
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
-                       n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split);
+                       n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_cell);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
     hipLaunchKernelGGL(k_ss_sort, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
                        s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_split, bwt_out, bwt_stride, d_index, sa_out,
