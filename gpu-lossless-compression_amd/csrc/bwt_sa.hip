@@ -1034,8 +1034,9 @@ hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_strid
 {
     if (n == 0 || n > s.nmax || n > MAX_BLOCK_ELEMS || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     s.last_flagged = nblk;
+    s.last_general = nblk;
     s.pending = false;
-    if (s.sorter != 0) {
+    if (s.sorter == 1 || s.sorter == 2) {
         const bool isa = s.force_isa;
         s.force_isa = isa || s.sorter == 2;
         const hipError_t e = sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nullptr,

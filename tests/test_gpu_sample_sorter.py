@@ -1,0 +1,137 @@
+"""The second sorter tier (string sample sort, bwt_bucket.hip k_ss_*): the blocks the bucket sorter flags -- text, logs,
+heavy repeated phrases, low-entropy sources -- must come out bit-exact, on this tier where its design says so
+(glcPlanLastSortStatsEx: how many blocks each tier gave up on), and on the general sorter beyond its depth cap.
+Every case is checked against the oracle and against the other sorter modes (glcPlanSetSorter)."""
+import numpy as np
+import pytest
+
+import datagen
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+N = 1 << 20
+
+
+def _bwt(glc, plan, torch, x, rows=1):
+    n = x.size // rows
+    d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    d_out = torch.zeros(x.size, dtype=torch.uint8, device=d_in.device)
+    d_idx = torch.zeros(rows, dtype=torch.int32, device=d_in.device)
+    assert glc.lib().glcBwtBatch(plan.handle, d_in.data_ptr(), d_out.data_ptr(), d_idx.data_ptr(), n, rows) == 0
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy(), d_idx.cpu().numpy()
+
+
+def _records(n, seed, key_len=24):
+    """log-like records that share a long fixed prefix and differ late: long common prefixes inside every bucket"""
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    i = 0
+    while len(out) < n:
+        out += b"2026-09-28T12:00:00Z host-17 svc-auth[4242]: request completed id=" + (b"%0*d" % (key_len, int(rng.integers(0, 10 ** 9)))) + b"\n"
+        i += 1
+    return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+
+
+def _phrases(n, seed, nphrases=40, plen=90):
+    """a few long phrases repeated thousands of times between random separators: runs of equal keys hundreds long, for a dozen rounds"""
+    rng = np.random.default_rng(seed)
+    ph = [bytes(rng.integers(97, 123, plen, dtype=np.uint8)) for _ in range(nphrases)]
+    out = bytearray()
+    while len(out) < n:
+        out += ph[int(rng.integers(0, nphrases))] + bytes(rng.integers(48, 58, 3, dtype=np.uint8))
+    return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
+
+
+CASES = {
+    # name: (generator, blocks the bucket sorter gives up on, blocks the sample sorter gives up on)   None = either
+    "text": (lambda: datagen.text_bytes(N), 1, 0),
+    "log": (lambda: datagen.log_bytes(N), 1, 0),
+    "records_long_prefix": (lambda: _records(N, 21), 1, 0),
+    "phrases": (lambda: _phrases(N, 22), 1, 0),
+    "two_symbols_iid": (lambda: np.random.default_rng(2).integers(0, 2, N, dtype=np.uint8) * 255, 1, 0),
+    "dna": (lambda: np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(23).integers(0, 4, N)], 1, 0),
+    "text_then_zipf": (lambda: np.concatenate([datagen.text_bytes(N // 2, seed=24), datagen.zipf_bytes(N // 2, seed=25)]), 1, 0),
+    # beyond the depth cap of the tier (~500 symbols past the common prefix of a bucket): the general sorter takes over
+    "zeros": (lambda: np.zeros(N, dtype=np.uint8), 1, 1),
+    "period_3": (lambda: np.tile(np.frombuffer(b"abc", dtype=np.uint8), N // 3 + 1)[:N], 1, 1),
+    "chunk_repeated_16x": (lambda: np.tile(np.random.default_rng(9).integers(0, 256, N // 16, dtype=np.uint8), 16), 1, 1),
+    "text_with_a_long_run": (lambda: np.concatenate([datagen.text_bytes(N // 2, seed=26), np.full(6000, 32, dtype=np.uint8),
+                                                     datagen.text_bytes(N // 2 - 6000, seed=27)]), 1, 1),
+}
+
+
+@pytest.fixture(scope="module")
+def ctx(glc, cuda):
+    c = glc.Cudpp()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", list(CASES.keys()))
+def test_sample_sorter_cases(glc, ctx, cuda, name):
+    import torch
+    gen, flagged1, flagged2 = CASES[name]
+    x = gen()
+    want, widx = O.bwt(x)
+    with glc.Plan(ctx, glc.CUDPP_BWT, N, rows=1) as plan:
+        got, gidx = _bwt(glc, plan, torch, x)
+        assert int(gidx[0]) == widx and np.array_equal(got, want), name
+        assert plan.last_sort_stats() == (flagged1, flagged2), "%s: tiers gave up on %r" % (name, plan.last_sort_stats())
+        plan.set_sorter(3)                                     # bucket sorter, then the general sorter: same bytes
+        g3, i3 = _bwt(glc, plan, torch, x)
+        assert int(i3[0]) == widx and np.array_equal(g3, want), "%s without the sample tier" % name
+        assert plan.last_sort_stats() == (flagged1, flagged1)
+        plan.set_sorter(0)
+        g0, i0 = _bwt(glc, plan, torch, x)                     # and the plan is reusable afterwards
+        assert int(i0[0]) == widx and np.array_equal(g0, want)
+
+
+@pytest.mark.parametrize("n", [40, 1000, 2049, 4097, 65537, 300001, 1048575])
+def test_sample_sorter_block_sizes(glc, ctx, cuda, n):
+    """number of samples, splitters and buckets change with n; the last bytes exercise the end-of-block keys"""
+    import torch
+    x = datagen.text_bytes(n + 8, seed=n)[:n]
+    want, widx = O.bwt(x)
+    with glc.Plan(ctx, glc.CUDPP_BWT, n, rows=1) as plan:
+        got, gidx = _bwt(glc, plan, torch, x)
+        assert int(gidx[0]) == widx and np.array_equal(got, want)
+        f1, f2 = plan.last_sort_stats()
+        assert f2 == 0 and f1 <= 1
+
+
+def test_sample_sorter_mixed_batch(glc, ctx, cuda):
+    """one batch, all three tiers at work: every block must carry its own tier's result"""
+    import torch
+    blocks = [datagen.text_bytes(N, seed=31), datagen.zipf_bytes(N, seed=32), np.zeros(N, dtype=np.uint8),
+              datagen.log_bytes(N, seed=33), datagen.float_bytes(N, seed=34), _phrases(N, 35),
+              np.tile(np.frombuffer(b"xy", dtype=np.uint8), N // 2), datagen.text_bytes(N, seed=36)]
+    x = np.concatenate(blocks)
+    with glc.Plan(ctx, glc.CUDPP_BWT, N, rows=len(blocks)) as plan:
+        for rep in range(2):                                   # twice: scratch of the first call must not leak into the second
+            got, gidx = _bwt(glc, plan, torch, x, rows=len(blocks))
+            assert plan.last_sort_stats() == (6, 2)
+            for i, blk in enumerate(blocks):
+                want, widx = O.bwt(blk)
+                assert int(gidx[i]) == widx and np.array_equal(got[i * N:(i + 1) * N], want), "block %d (call %d)" % (i, rep)
+
+
+def test_compress_text_round_trip(glc, ctx, cuda):
+    """whole pipeline on text (the speculative MTF + Huffman pass is redone for the flagged blocks): stream decodes to the input"""
+    import torch
+    rows = 4
+    x = np.concatenate([datagen.text_bytes(N, seed=41), datagen.log_bytes(N, seed=42), datagen.zipf_bytes(N, seed=43), _records(N, 44)])
+    d_in = torch.from_numpy(x).cuda()
+    with glc.Plan(ctx, glc.CUDPP_COMPRESS, N, rows=rows) as plan:
+        comp = glc.compress_batch(plan, d_in, N, rows)
+        plan.synchronize()
+        assert plan.last_sort_stats() == (3, 0)
+        back = glc.decompress_batch(plan, comp, N, rows)
+        torch.cuda.synchronize()
+        assert np.array_equal(back.cpu().numpy(), x)
+        for i in range(rows):                                  # and it is the reference's stream: same words as the oracle's
+            want = O.compress(x[i * N:(i + 1) * N])
+            size = int(comp["size"][i].item())
+            assert size == want["size"] and int(comp["bwt_index"][i].item()) == want["bwt_index"]
+            words = comp["words"][i * comp["stride"]:i * comp["stride"] + size].cpu().numpy().view(np.uint32)
+            assert np.array_equal(words, want["words"]), "block %d" % i
