@@ -17,6 +17,7 @@ The same JSON line carries, measured in the same run on rank 0 at N = 1 (SURVEY.
     single_call                  what a drop-in caller of the reference API gets: cudppCompress, one 1 MiB block
     culzss                       configs[2]: 4 GiB log-style ASCII through the CULZSS path, device resident
     hd_decode                    configs[4] (one GPU's share): CUHD-shaped Huffman-only decode
+    text_like                    configs[0]-style text and log lines through cudppCompress (sample-sorter tier)
     stream_read_ceiling_GBps     a trivial 16-byte-per-lane read kernel over the input, this box, this run
     cpu_baseline                 oracle port (1 core / all effective cores), libbz2 -9 encode + decode (1 / all),
                                  the reference's serial LZSS (oracle/_ref/lzss_serial) for config 3
@@ -191,6 +192,42 @@ def leg_single_call(torch, glc, dev, d_block, iters=20):
             "ms_per_call_median": round(med * 1e3, 4), "GBps": round(n / med / 1e9, 4),
             "ms_host_in_call": round(t_call * 1e3, 4), "calls": iters,
             "host_syncs_per_call": "1 inside (flagged-block count of the bucket sorter) + the caller's wait"}
+
+
+def leg_text_like(torch, glc, dev, rows=256, distinct=8, iters=3):
+    """configs[0]-style data through the same entry point: order-1 word-model text and log lines (tests/datagen.py),
+    `distinct` different 1 MiB blocks tiled to a batch of `rows`.  These blocks leave the bucket sorter (their
+    order-0 code is lumpy) for the sample sorter; the figure includes the bucket sorter's wasted attempt and the
+    MTF + Huffman pass queued behind it speculatively and redone."""
+    import numpy as np
+    import datagen
+    n = MiB
+    out_res = {}
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
+        for name, gen in (("text", datagen.text_bytes), ("log", datagen.log_bytes)):
+            x = gen(n * distinct).reshape(distinct, n)
+            d_in = torch.from_numpy(np.tile(x, (rows // distinct, 1))).to(dev).contiguous().view(-1)
+            out = glc.compress_batch(plan, d_in, n, rows)
+            plan.synchronize()
+            ts = []
+            for _ in range(iters):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                glc.compress_batch_into(plan, d_in, n, rows, out)
+                plan.synchronize()
+                ts.append(time.perf_counter() - t0)
+            f1, f2 = plan.last_sort_stats()
+            back = glc.decompress_batch(plan, out, n, rows)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(back, d_in))
+            words = int(out["size"].sum().item())
+            out_res[name] = {"GBps": round(n * rows / min(ts) / 1e9, 2), "ms_per_batch": round(min(ts) * 1e3, 3),
+                             "ratio": round(n * rows / (4.0 * words), 3), "blocks": rows,
+                             "blocks_left_by_bucket_sorter": f1, "blocks_left_by_sample_sorter": f2, "round_trip_ok": ok}
+            del d_in, out, back
+    out_res["note"] = ("cudppCompress path (glcCompressBatch, one plan, %d blocks per call) on %d distinct synthetic 1 MiB blocks "
+                       "tiled; best of %d calls incl. the host wait" % (rows, distinct, iters))
+    return out_res
 
 
 def leg_culzss(torch, glc, dev, gib, iters=3):
@@ -702,6 +739,7 @@ def main():
             torch.cuda.empty_cache()
         if args.hd_mib > 0:
             res["hd_decode"] = leg_hd(torch, glc, dev, args.hd_mib)
+        res["text_like"] = leg_text_like(torch, glc, dev)
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sample_host, log_sample)
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:

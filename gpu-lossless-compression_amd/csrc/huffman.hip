@@ -54,8 +54,17 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
     // ---- total histogram (huffman_build_tree_kernel merges partial histograms,
     //      compress_kernel.cuh:2284-2299; EOF gets count 1, :2250) ----
     {
-        uint32_t c = 0;
-        for (uint32_t s = 0; s < nsub; s++) c += SH[(size_t)s * 256 + tid];
+        // 16 loads in flight per thread: one workgroup per CU is all this kernel has, and a load-wait-add loop over
+        // the 256 partial histograms was ~150 us of latency
+        uint32_t c = 0, s = 0;
+        for (; s + 16 <= nsub; s += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = SH[(size_t)(s + k) * 256 + tid];
+#pragma unroll
+            for (int k = 0; k < 16; k++) c += v[k];
+        }
+        for (; s < nsub; s++) c += SH[(size_t)s * 256 + tid];
         s_hist[tid] = c;
         d_hist[(size_t)b * 256 + tid] = c;
         s_code[tid] = 0; s_len[tid] = 0;
@@ -91,14 +100,26 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
     }
 
     // ---- words per 4096-symbol block = ceil(sub_hist . len / 32) ----
-    for (uint32_t s = w; s < 256; s += 4) {
-        uint32_t bits = 0;
-        if (s < nsub) {
+    {
+        uint32_t ln[4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) bits += SH[(size_t)s * 256 + r * 64 + l] * s_len[r * 64 + l];
+        for (int r = 0; r < 4; r++) ln[r] = s_len[r * 64 + l];
+        for (uint32_t s0 = w; s0 < 256; s0 += 16) {            // four sub-blocks of this wave at a time: 16 loads in flight
+            uint32_t h[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sb = s0 + 4 * k;
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[k][r] = sb < nsub ? SH[(size_t)sb * 256 + r * 64 + l] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sb = s0 + 4 * k;
+                uint32_t bits = h[k][0] * ln[0] + h[k][1] * ln[1] + h[k][2] * ln[2] + h[k][3] * ln[3];
+                bits = wave_sum(bits);
+                if (l == 0) s_words[sb] = (sb < nsub) ? (bits + 31) / 32 : 0u;
+            }
         }
-        bits = wave_sum(bits);
-        if (l == 0) s_words[s] = (s < nsub) ? (bits + 31) / 32 : 0u;
     }
     __syncthreads();
     {
