@@ -299,15 +299,20 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
                                            d_compressed, compressedStrideWords);
         if (p->timing) (void)hipEventRecord(p->ev[3], s2);
     };
-    after_sort(p->sa.sorter == 0 ? p->sa.fs_redo[k] : nullptr);   // blocks flagged by the bucket sorter are encoded again below
+    // ... unless most blocks of the plan's previous call were flagged (text-like input tends to stay text-like): then
+    // the speculative pass would be thrown away, and the stages are queued once, after the sort is final.
+    const bool tiers = p->sa.sorter == 0 || p->sa.sorter == 3;
+    const bool speculate = !tiers || !p->sa.expect_flagged;
+    if (speculate) after_sort(tiers ? p->sa.fs_redo[k] : nullptr);   // blocks flagged by the bucket sorter are encoded again below
     uint32_t nflag = 0;
     if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
-    if (e == hipSuccess && nflag) {
-        // sa_build_finish has queued the general sorter for the flagged blocks on st.  Under pipelining the
+    if (e == hipSuccess && (nflag || !speculate)) {
+        // sa_build_finish has queued the other sorters for the flagged blocks on st.  Under pipelining the
         // speculative MTF on s2 may still be reading `bwt` while it is rewritten: harmless, everything that pass
-        // wrote is written again by the pass below, which is ordered after the general sort (ev_sorted).
+        // wrote is written again by the pass below, which is ordered after the last sort (ev_sorted).
         after_sort(nullptr);
     }
+    if (tiers) p->sa.expect_flagged = 2 * nflag > nb;
     tm.done();
     if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], s2); p->released_valid[k] = true; p->side_busy = true; }
     return hip_result(e);

@@ -115,6 +115,7 @@ struct SaScratch {
     uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build the bucket sorter gave up on
     uint32_t  last_general = 0;                  // ... of which the sample sorter gave up on too (general sorter)
+    bool      expect_flagged = false;            // most blocks of the previous call were flagged: no speculative stages behind the sort
     // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
     uint32_t *ss_list = nullptr;                 // [rows] their block numbers
     uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]
