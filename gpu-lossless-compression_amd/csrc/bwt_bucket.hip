@@ -730,28 +730,29 @@ __device__ __forceinline__ uint32_t ss_pivot_bin(uint64_t piv, uint64_t key)
     return 2 * lo + ((lo < SS_NPIV && pl == key) ? 1u : 0u);
 }
 
-// One workgroup per bucket; the suffixes are ordered in rounds of 7 symbols read from the text.  A RUN is a range of
-// positions whose suffixes agree in everything looked at so far (each run carries its own depth); the whole
-// bucket is the first run.
-//   * A LONG run is cut with 64 PIVOTS -- keys of 64 of its members, sorted by one wave -- into the bins "between
-//     two pivots" (runs at the same depth, ~1/65 of the size whatever the key distribution is: text is anything
-//     but uniform) and "equal to a pivot" (runs one round deeper; a key that hundreds of members share is almost
-//     surely a pivot).  Members count into the bins with LDS atomics.  The first cut is made by the whole
-//     workgroup.
-//   * After it every WAVE owns a range of positions and works alone, with no workgroup barrier: windows of up to
-//     256 positions are finished in registers (4 per lane; a member reads the keys of its run and counts the
-//     smaller ones; equal keys = a run of the next round), longer runs are cut again by the wave.
-// 32 waves per CU, each a chain of LDS and L2 latencies, keep the CU busy between them.  Nothing here depends on
-// the symbol statistics.
-__global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
-                                                    uint32_t nbl, const uint64_t *__restrict__ keys, size_t kstride,
+// The sort of a bucket, in two kernels.  The suffixes are ordered in rounds of 7 symbols read from the text.  A RUN is
+// a range of positions whose suffixes agree in everything looked at so far (each run carries its own depth); the
+// whole bucket is the first run.
+//   k_ss_cut     (one workgroup per bucket, everything in LDS) cuts LONG runs with 64 PIVOTS -- keys of 64 of the
+//                run's members, sorted by one wave -- into the bins "between two pivots" (runs at the same depth, ~1/65
+//                of the size whatever the key distribution is: text is anything but uniform) and "equal to a pivot"
+//                (runs one round deeper; a key that hundreds of members share is almost surely a pivot).  Members
+//                count into the bins with LDS atomics.  The first cut is made by the whole workgroup, later ones
+//                (runs still longer than a window) by single waves.  The words go back to their slot as
+//                [run descriptor : 32 | index : 20 | bwt : 8 ...].
+//   k_ss_windows (four waves per bucket, each on its own) finishes WINDOWS of up to 256 positions in registers, 4 per
+//                lane: gather 8 bytes, write the key, count the smaller keys of the run, move; equal keys = a run of
+//                the next round.  Waves take shares of the bucket from a counter and never wait for each other:
+//                when this was the tail of the cutting kernel, the slowest of 16 waves took 3x the mean and the
+//                other 15 sat on 73 KB of LDS meanwhile.
+// Nothing here depends on the symbol statistics.
+__global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                    uint32_t nbl, uint64_t *__restrict__ keys, size_t kstride,
                                                     const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
                                                     uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
-                                                    const uint64_t *__restrict__ split, uint8_t *__restrict__ bwt_out,
-                                                    size_t bwt_stride, int *__restrict__ d_index,
-                                                    uint32_t *__restrict__ sa_out, size_t sa_stride)
+                                                    const uint64_t *__restrict__ split, uint32_t *__restrict__ l0_out)
 {
-    __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position; scratch of a cut; at the end the BWT bytes
+    __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position; scratch of a cut
     __shared__ uint32_t s_v[FS_FILLMAX];                       // index << 8 | BWT byte of the suffix at a position
     __shared__ uint32_t s_seg[FS_FILLMAX];                     // run of a position (ss_run)
     __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end), of the cut a wave is making
@@ -781,7 +782,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
         }
         s_l0 = l0;
     }
-    const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+    uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
     // ---- first cut, by the whole workgroup (thread = the positions r NT + tid) ----
     uint32_t vv[SSS_ITEMS];
 #pragma unroll
@@ -920,6 +921,85 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
                 __builtin_amdgcn_wave_barrier();
                 continue;                                      // look at pos again: the runs there are shorter or deeper now
             }
+            // (windows are finished by k_ss_windows)
+            pos = W;
+        }
+    }
+    __syncthreads();
+    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    // the bucket goes back to its slot in run order: [run : 32 | index : 20 | bwt : 8 ...] (bits 28..31 unused)
+    for (uint32_t p = tid; p < c; p += SSS_NT) K[p] = (uint64_t)s_v[p] | ((uint64_t)s_seg[p] << 32);
+    if (tid == 0) l0_out[(size_t)b * FS_MAXNB + bk] = l0;
+}
+
+constexpr int SSW_NT = 256, SSW_WAVES = SSW_NT / 64;
+
+__global__ __launch_bounds__(SSW_NT, 8) void k_ss_windows(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                          const uint64_t *__restrict__ keys, size_t kstride,
+                                                          const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
+                                                          uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
+                                                          const uint32_t *__restrict__ l0_in, uint8_t *__restrict__ bwt_out,
+                                                          size_t bwt_stride, int *__restrict__ d_index,
+                                                          uint32_t *__restrict__ sa_out, size_t sa_stride)
+{
+    __shared__ uint64_t s_kw[SSW_WAVES][SS_WIN];               // per wave: keys of its window
+    __shared__ uint32_t s_vw[SSW_WAVES][SS_WIN];               // index << 8 | BWT byte
+    __shared__ uint32_t s_sw[SSW_WAVES][SS_WIN];               // run descriptors (bucket positions)
+    __shared__ uint32_t s_bound[SS_SHARES + 1], s_next, s_deep;
+    const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    const uint8_t *T = text + (size_t)b * stride;
+    const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
+    const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
+    const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+    if (tid == 0) { s_deep = flag[b]; s_next = 0; }
+    __syncthreads();
+    if (s_deep || c == 0 || c > FS_FILLMAX) return;
+    const uint32_t l0 = l0_in[(size_t)b * FS_MAXNB + bk];
+    // shares [A, B) of the positions; a share ends where a run ends
+    if (tid <= SS_SHARES) {
+        uint32_t A = (uint32_t)(((uint64_t)c * tid) / SS_SHARES);
+        if (A > 0 && A < c) { const uint32_t g = (uint32_t)(K[A] >> 32); if ((g & 0xFFFu) < A) A = (g >> 12) & 0xFFFu; }
+        s_bound[tid] = A;
+    }
+    __syncthreads();
+    uint64_t *KW = s_kw[wv];
+    uint32_t *VW = s_vw[wv], *SW = s_sw[wv];
+    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
+    uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
+    for (;;) {
+        uint32_t ch = 0;
+        if (lane == 0) ch = atomicAdd(&s_next, 1u);
+        ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
+        if (ch >= SS_SHARES) break;
+        const uint32_t A = s_bound[ch], B = s_bound[ch + 1];
+        uint32_t pos = A;
+        while (pos < B) {
+            if (s_deep) break;
+            // window [pos, W): the runs that start in it and end within SS_WIN positions
+            const uint32_t lim = min(B, pos + SS_WIN);
+            uint32_t g4[4], x4[4], W = lim;
+            bool und = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = pos + lane + 64 * j;
+                const uint64_t x = p < lim ? K[p] : 0ull;
+                g4[j] = (uint32_t)(x >> 32); x4[j] = (uint32_t)x & (uint32_t)FS_LOW_MASK;
+                if (p < lim) {
+                    const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu;
+                    if (se > lim) W = min(W, ss);              // a run that runs out of the window: the window ends before it
+                    und |= se - ss > 1;
+                }
+            }
+            W = (uint32_t)wave_min_u64((uint64_t)W);
+            if (W == pos) { s_deep = 1; break; }               // (k_ss_cut leaves no run longer than a window)
+            und = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = pos + lane + 64 * j;
+                if (p < W) { VW[p - pos] = x4[j]; SW[p - pos] = g4[j]; und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1; }
+            }
+            __builtin_amdgcn_wave_barrier();
             // ---- window [pos, W): rounds in registers until every position is decided ----
             while (__ballot(und) != 0) {
                 uint64_t key[4];
@@ -932,7 +1012,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
                     if (p < W) {
                         const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
                         if (se - ss > 1) {
-                            v4[j] = s_v[p];
+                            v4[j] = VW[p - pos];
                             key[j] = ss_sym_load(T, n, (v4[j] >> 8) + l0 + SS_STEP * st);
                             dp |= st > SS_MAXSTEP;
                         }
@@ -942,7 +1022,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t p = pos + lane + 64 * j;
-                    if (p < W && ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) { key[j] = ss_sym_key(key[j]); s_k[p] = key[j]; }
+                    if (p < W && ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) { key[j] = ss_sym_key(key[j]); KW[p - pos] = key[j]; }
                 }
                 __builtin_amdgcn_wave_barrier();
                 uint32_t np[4];
@@ -956,7 +1036,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
                             uint32_t less = 0, eqt = 0, eqb = 0;
 #pragma unroll 4
                             for (uint32_t q = ss; q < se; q++) {
-                                const uint64_t kq = s_k[q];
+                                const uint64_t kq = KW[q - pos];
                                 less += kq < key[j]; eqt += kq == key[j]; eqb += (kq == key[j]) & (q < p);
                             }
                             np[j] = ss + less + eqb;
@@ -967,50 +1047,33 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_sort(const uint8_t *__restrict
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (np[j] != 0xFFFFFFFFu) { s_v[np[j]] = v4[j]; s_seg[np[j]] = g4[j]; }
+                    if (np[j] != 0xFFFFFFFFu) { VW[np[j] - pos] = v4[j]; SW[np[j] - pos] = g4[j]; }
                 __builtin_amdgcn_wave_barrier();
                 und = false;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t p = pos + lane + 64 * j;
-                    if (p < W) { g4[j] = s_seg[p]; und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1; }
+                    if (p < W) { g4[j] = SW[p - pos]; und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1; }
                 }
             }
+            // rows R0 + pos .. R0 + W
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t p = pos + lane + 64 * j;
+                if (p < W) {
+                    const uint32_t v = VW[p - pos], idx = v >> 8;
+                    if (O) O[p] = (uint8_t)v;
+                    if (SAo) SAo[p] = idx;
+                    if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
             pos = W;
         }
     }
     __syncthreads();
-    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-    uint8_t *s_cb = reinterpret_cast<uint8_t *>(s_k);
-    uint32_t *s_cp = reinterpret_cast<uint32_t *>(s_k);
-    // rows R0 .. R0 + c
-    uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
-    uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
-    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < SSS_ITEMS; r++) {
-        const uint32_t p = r * SSS_NT + tid;
-        if (p < c) {
-            const uint32_t v = s_v[p], idx = v >> 8;
-            s_cb[shift + p] = (uint8_t)v;
-            if (SAo) SAo[p] = idx;
-            if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
-        }
-    }
-    __syncthreads();
-    if (O) {
-        const uint32_t end = shift + c;
-        for (uint32_t q = tid; 4 * q < end; q += SSS_NT) {
-            const uint32_t v = s_cp[q];
-            if (4 * q >= shift && 4 * q + 4 <= end) *reinterpret_cast<uint32_t *>(O - shift + 4 * q) = v;
-            else {
-#pragma unroll
-                for (uint32_t k = 0; k < 4; k++)
-                    if (4 * q + k >= shift && 4 * q + k < end) O[4 * q + k - shift] = (uint8_t)(v >> (8 * k));
-            }
-        }
-    }
+    if (s_deep && tid == 0) atomicOr(&flag[b], 2u);
 }
 
 // what this tier gave up on keeps its live count for the general sorter
@@ -1073,8 +1136,10 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
                        n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_cell);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
-    hipLaunchKernelGGL(k_ss_sort, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_split, bwt_out, bwt_stride, d_index, sa_out,
+    hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
+                       s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_split, s.ss_l0);
+    hipLaunchKernelGGL(k_ss_windows, dim3(nb, nflag), dim3(SSW_NT), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+                       s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
                        (size_t)s.nmax);
     hipLaunchKernelGGL(k_ss_finish, dim3((nflag + 255) / 256), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, n, s.fs_lcnt,
                        s.fs_nflag + 1);

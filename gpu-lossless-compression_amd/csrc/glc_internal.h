@@ -120,6 +120,7 @@ struct SaScratch {
     uint32_t *ss_list = nullptr;                 // [rows] their block numbers
     uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]
     uint32_t *ss_flag = nullptr;                 // [rows] this tier's give-up flags
+    uint32_t *ss_l0 = nullptr;                   // [rows][FS_MAXNB] common prefix of a bucket's two splitters
     uint16_t *ss_cell = nullptr;                 // [rows][4098] first splitter of every cell of the code space
     hipEvent_t ev_flag = nullptr;                // marks the readback of fs_nflag (sa_build_begin / sa_build_finish)
     bool      pending = false;
