@@ -757,7 +757,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     __shared__ uint32_t s_seg[FS_FILLMAX];                     // run of a position (ss_run)
     __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end), of the cut a wave is making
     __shared__ uint64_t s_piv0[SS_NPIV];                       // pivots of the first cut
-    __shared__ uint32_t s_deep, s_l0, s_next, s_bound[SS_SHARES + 1];
+    __shared__ uint32_t s_deep, s_l0, s_next, s_nlong, s_bound[SS_NBIN + 1];
     const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x, nb = 1u << nbl;
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint8_t *T = text + (size_t)b * stride;
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     const uint64_t *SP = split + (size_t)b * FS_MAXNB;
     if (tid == 0) {
         s_deep = flag[b];
-        s_next = 0;
+        s_next = 0; s_nlong = 0;
         // every suffix of the bucket lies between its two splitters and shares their common prefix
         uint32_t l0 = 0;
         if (bk >= 1 && bk + 1 < nb && c > 1) {
@@ -840,23 +840,23 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
             }
         }
         __syncthreads();
+        // bins still longer than a window (a key shared by hundreds of suffixes, or an unlucky gap between pivots)
+        if (tid < SS_NBIN) {
+            const uint32_t gs = s_cnt[0][tid], ge = s_cnt[0][tid + 1];
+            if (ge - gs > SS_WIN) s_bound[atomicAdd(&s_nlong, 1u)] = gs | (ge << 16);
+        }
+        __syncthreads();
         if (tid < SS_NBIN + 3) s_cnt[0][tid] = 0;
     }
     __syncthreads();
-    // ---- the waves finish shares [A, B) of the positions; a share ends where a run ends (fixed now, before any run moves) ----
-    if (tid <= SS_SHARES) {
-        uint32_t A = (uint32_t)(((uint64_t)c * tid) / SS_SHARES);
-        if (A > 0 && A < c) { const uint32_t g = s_seg[A]; if ((g & 0xFFFu) < A) A = (g >> 12) & 0xFFFu; }
-        s_bound[tid] = A;
-    }
-    __syncthreads();
+    // ---- such bins are cut again, each by one wave, until no run in them is longer than a window ----
+    const uint32_t nlong = s_nlong;
     for (;;) {
-        // shares are handed out first come, first served: a wave stuck with a long run does not hold the others up
         uint32_t ch = 0;
         if (lane == 0) ch = atomicAdd(&s_next, 1u);
         ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
-        if (ch >= SS_SHARES) break;
-        const uint32_t A = s_bound[ch], B = s_bound[ch + 1];
+        if (ch >= nlong) break;
+        const uint32_t A = s_bound[ch] & 0xFFFFu, B = s_bound[ch] >> 16;
         uint32_t *cnt = s_cnt[wv];
         uint32_t pos = A;
         while (pos < B) {
