@@ -932,50 +932,45 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     if (tid == 0) l0_out[(size_t)b * FS_MAXNB + bk] = l0;
 }
 
-constexpr int SSW_NT = 256, SSW_WAVES = SSW_NT / 64;
+constexpr int SSW_PER_BUCKET = 4;                              // one-wave workgroups per bucket; wave w takes shares w, w + 4, ...
 
-__global__ __launch_bounds__(SSW_NT, 8) void k_ss_windows(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
-                                                          const uint64_t *__restrict__ keys, size_t kstride,
-                                                          const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
-                                                          uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
-                                                          const uint32_t *__restrict__ l0_in, uint8_t *__restrict__ bwt_out,
-                                                          size_t bwt_stride, int *__restrict__ d_index,
-                                                          uint32_t *__restrict__ sa_out, size_t sa_stride)
+__global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                      const uint64_t *__restrict__ keys, size_t kstride,
+                                                      const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
+                                                      uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
+                                                      const uint32_t *__restrict__ l0_in, uint8_t *__restrict__ bwt_out,
+                                                      size_t bwt_stride, int *__restrict__ d_index,
+                                                      uint32_t *__restrict__ sa_out, size_t sa_stride)
 {
-    __shared__ uint64_t s_kw[SSW_WAVES][SS_WIN];               // per wave: keys of its window
-    __shared__ uint32_t s_vw[SSW_WAVES][SS_WIN];               // index << 8 | BWT byte
-    __shared__ uint32_t s_sw[SSW_WAVES][SS_WIN];               // run descriptors (bucket positions)
-    __shared__ uint32_t s_bound[SS_SHARES + 1], s_next, s_deep;
-    const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wv = tid >> 6;
+    __shared__ uint64_t s_kw[SS_WIN];                          // keys of the window
+    __shared__ uint32_t s_vw[SS_WIN];                          // index << 8 | BWT byte
+    __shared__ uint32_t s_sw[SS_WIN];                          // run descriptors (bucket positions)
+    __shared__ uint32_t s_bound[SS_SHARES + 1];
+    const uint32_t b = list[blockIdx.y], bk = blockIdx.x / SSW_PER_BUCKET, w0 = blockIdx.x % SSW_PER_BUCKET;
+    const uint32_t lane = threadIdx.x;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
     const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
     const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
-    if (tid == 0) { s_deep = flag[b]; s_next = 0; }
-    __syncthreads();
-    if (s_deep || c == 0 || c > FS_FILLMAX) return;
+    bool deep = flag[b] != 0;                                  // (set by earlier kernels only, or by other waves: then it does not matter what this one does)
+    if (deep || c == 0 || c > FS_FILLMAX) return;
     const uint32_t l0 = l0_in[(size_t)b * FS_MAXNB + bk];
     // shares [A, B) of the positions; a share ends where a run ends
-    if (tid <= SS_SHARES) {
-        uint32_t A = (uint32_t)(((uint64_t)c * tid) / SS_SHARES);
+    for (uint32_t t = lane; t <= SS_SHARES; t += 64) {
+        uint32_t A = (uint32_t)(((uint64_t)c * t) / SS_SHARES);
         if (A > 0 && A < c) { const uint32_t g = (uint32_t)(K[A] >> 32); if ((g & 0xFFFu) < A) A = (g >> 12) & 0xFFFu; }
-        s_bound[tid] = A;
+        s_bound[t] = A;
     }
-    __syncthreads();
-    uint64_t *KW = s_kw[wv];
-    uint32_t *VW = s_vw[wv], *SW = s_sw[wv];
+    __builtin_amdgcn_wave_barrier();
+    uint64_t *KW = s_kw;
+    uint32_t *VW = s_vw, *SW = s_sw;
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
     uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
-    for (;;) {
-        uint32_t ch = 0;
-        if (lane == 0) ch = atomicAdd(&s_next, 1u);
-        ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
-        if (ch >= SS_SHARES) break;
+    for (uint32_t ch = w0; ch < SS_SHARES; ch += SSW_PER_BUCKET) {
         const uint32_t A = s_bound[ch], B = s_bound[ch + 1];
         uint32_t pos = A;
         while (pos < B) {
-            if (s_deep) break;
+            if (deep) break;
             // window [pos, W): the runs that start in it and end within SS_WIN positions
             const uint32_t lim = min(B, pos + SS_WIN);
             uint32_t g4[4], x4[4], W = lim;
@@ -992,7 +987,7 @@ __global__ __launch_bounds__(SSW_NT, 8) void k_ss_windows(const uint8_t *__restr
                 }
             }
             W = (uint32_t)wave_min_u64((uint64_t)W);
-            if (W == pos) { s_deep = 1; break; }               // (k_ss_cut leaves no run longer than a window)
+            if (W == pos) { deep = true; break; }               // (k_ss_cut leaves no run longer than a window)
             und = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1018,7 +1013,7 @@ __global__ __launch_bounds__(SSW_NT, 8) void k_ss_windows(const uint8_t *__restr
                         }
                     }
                 }
-                if (__ballot(dp) != 0) { s_deep = 1; break; }
+                if (__ballot(dp) != 0) { deep = true; break; }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t p = pos + lane + 64 * j;
@@ -1072,8 +1067,7 @@ __global__ __launch_bounds__(SSW_NT, 8) void k_ss_windows(const uint8_t *__restr
             pos = W;
         }
     }
-    __syncthreads();
-    if (s_deep && tid == 0) atomicOr(&flag[b], 2u);
+    if (deep && lane == 0) atomicOr(&flag[b], 2u);
 }
 
 // what this tier gave up on keeps its live count for the general sorter
@@ -1138,7 +1132,7 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
     hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
                        s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_split, s.ss_l0);
-    hipLaunchKernelGGL(k_ss_windows, dim3(nb, nflag), dim3(SSW_NT), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+    hipLaunchKernelGGL(k_ss_windows, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                        s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
                        (size_t)s.nmax);
     hipLaunchKernelGGL(k_ss_finish, dim3((nflag + 255) / 256), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, n, s.fs_lcnt,
