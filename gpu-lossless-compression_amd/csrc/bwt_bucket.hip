@@ -5,7 +5,8 @@
 //   cudppSuffixArrayDispatch / ComputeSA     (cudpp-inpar/src/cudpp/app/sa_app.cu:125-298,365-391)
 //   bwt_compute_final_kernel                 (kernel/compress_kernel.cuh:55-74)
 // for data whose suffixes separate within a few dozen symbols (i.i.d. bytes, float data: configs 2 and 4).
-// Blocks it cannot finish are flagged and go through the general sorter in bwt_sa.hip.
+// Blocks it cannot finish are flagged and go on to the second tier in this file, a string sample sort for text-like
+// data (k_ss_*, further down); what that cannot finish either goes through the general sorter in bwt_sa.hip.
 //
 // Idea.  A suffix is mapped to X = the arithmetic code of its first 6 symbols under the block's own
 // order-0 symbol statistics:
@@ -557,7 +558,7 @@ __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint3
 // first suffix of a bucket, so buckets hold ~2048 +- 20 % suffixes whatever the distribution -- a code shared by
 // 10000 suffixes is simply spread over five buckets, cut by text comparison.  A bucket is then sorted in LDS in
 // rounds of 5 symbols read from the text, starting behind the common prefix of the bucket's two splitters
-// (everything between two suffixes shares their common prefix); see k_ss_sort.
+// (everything between two suffixes shares their common prefix); see k_ss_cut / k_ss_windows.
 // Same words, same slots, same outputs as the first tier; only very deep repeats are left to the general sorter.
 constexpr int SSA_NT = 1024;                                   // k_ss_sample: threads
 constexpr uint32_t SS_PER_BUCKET = 32, SS_MAXS = FS_MAXNB * SS_PER_BUCKET;
