@@ -606,7 +606,10 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     for (uint32_t j = tid; j < S2; j += SSA_NT) {
         uint64_t w = ~0ull;
         if (j < S) {
-            const uint32_t i = (uint32_t)(((uint64_t)j * n) / S);
+            // one sample per stride of n / S positions, at a hashed offset inside it: evenly spaced samples (every 64th
+            // suffix of a 1 MiB block) would only ever see one phase of data with a period, e.g. byte 0 of every float
+            const uint32_t lo = (uint32_t)(((uint64_t)j * n) / S), hi = (uint32_t)(((uint64_t)(j + 1) * n) / S);
+            const uint32_t i = lo + ((j * 2654435761u) >> 12) % (hi - lo);
             w = (fs_code_at(s_tab, T, n, i) & ~FS_LOW_MASK) | ((uint64_t)i << 8);
         }
         s_s[j] = w;
@@ -1103,6 +1106,13 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                        s.fs_hist);
     if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab);
+    if (s.skip_tier1) {
+        // most blocks of the plan's previous call were flagged: no attempt, every block goes to the sample sorter
+        GLC_TRY(hipMemsetAsync(s.fs_flag, 1, (size_t)nblk * 4, st));
+        hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
+                           s.fs_redo[s.parity & 1], s.ss_list);
+        return hipGetLastError();
+    }
     pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
     hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
                        nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag, (const uint32_t *)nullptr,

@@ -1046,6 +1046,7 @@ hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_strid
         return e;
     }
     // bucket sorter first; the suffix array itself is only written when it is the result asked for
+    s.skip_tier1 = s.sorter == 4;                            // the caller knows its data is text-like: no bucket-sorter attempt
     GLC_TRY(fs_build(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa));
     GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 4, s.fs_nflag, 4, hipMemcpyDeviceToHost, st));
     if (!s.ev_flag) GLC_TRY(hipEventCreateWithFlags(&s.ev_flag, hipEventDisableTiming));
@@ -1064,6 +1065,7 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
     uint32_t nflag = s.h_max_cnt[4];
     s.last_flagged = nflag;
     s.last_general = 0;
+    s.expect_flagged = 2 * nflag > nblk;
     if (nflag == 0) return hipSuccess;
     if (nflagged) *nflagged = nflag;
     if (s.sorter != 3) {

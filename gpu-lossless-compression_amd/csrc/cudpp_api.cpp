@@ -301,8 +301,8 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     };
     // ... unless most blocks of the plan's previous call were flagged (text-like input tends to stay text-like): then
     // the speculative pass would be thrown away, and the stages are queued once, after the sort is final.
-    const bool tiers = p->sa.sorter == 0 || p->sa.sorter == 3;
-    const bool speculate = !tiers || !p->sa.expect_flagged;
+    const bool tiers = p->sa.sorter == 0 || p->sa.sorter == 3 || p->sa.sorter == 4;
+    const bool speculate = !tiers || (!p->sa.expect_flagged && p->sa.sorter != 4);
     if (speculate) after_sort(tiers ? p->sa.fs_redo[k] : nullptr);   // blocks flagged by the bucket sorter are encoded again below
     uint32_t nflag = 0;
     if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
@@ -312,7 +312,6 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
         // wrote is written again by the pass below, which is ordered after the last sort (ev_sorted).
         after_sort(nullptr);
     }
-    if (tiers) p->sa.expect_flagged = 2 * nflag > nb;
     tm.done();
     if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], s2); p->released_valid[k] = true; p->side_busy = true; }
     return hip_result(e);
@@ -531,7 +530,7 @@ CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode)
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     SaScratch *s = sa_of(p);
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
-    if (mode < 0 || mode > 3) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (mode < 0 || mode > 4) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     s->sorter = mode;
     return CUDPP_SUCCESS;
 }

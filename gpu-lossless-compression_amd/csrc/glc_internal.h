@@ -100,7 +100,8 @@ struct SaScratch {
     // fast path (bwt_bucket.hip); its words live in keyA/keyB (one allocation, fs_kstride words per block)
     int       sorter = 0;                        // 0 = bucket sorter, then sample sorter, then general sorter for what each flags;
                                                  // 1 = general sorter only; 2 = general sorter, prefix doubling only;
-                                                 // 3 = bucket sorter, then general sorter (no sample sorter)
+                                                 // 3 = bucket sorter, then general sorter (no sample sorter);
+                                                 // 4 = sample sorter first (a caller that knows its data is text-like)
     size_t    fs_kstride = 0;
     uint32_t *fs_hist = nullptr;                 // [rows][256] symbol counts
     uint2    *fs_tab = nullptr;                  // [rows][256] {C, p} scaled to 2^32
@@ -115,7 +116,8 @@ struct SaScratch {
     uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build the bucket sorter gave up on
     uint32_t  last_general = 0;                  // ... of which the sample sorter gave up on too (general sorter)
-    bool      expect_flagged = false;            // most blocks of the previous call were flagged: no speculative stages behind the sort
+    bool      expect_flagged = false;            // most blocks of the previous call were flagged: no speculative stages behind the sort,
+    bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
     // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
     uint32_t *ss_list = nullptr;                 // [rows] their block numbers
     uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]

@@ -220,7 +220,8 @@ CUDPPResult glcHuffmanEncodeBatch(CUDPPHandle planHandle, const unsigned char *d
  * bucket sorter (one bucketing pass + in-LDS sort; i.i.d.-like data), for the blocks it flags the sample sorter
  * (buckets cut at sampled splitter suffixes, runs of equal codes refined from the text; text, logs), and for
  * what that flags (repeats deeper than ~500 symbols) the general sorter; 1: general sorter only; 2: general
- * sorter, prefix doubling from the first refinement round; 3: bucket sorter, then general sorter.  All
+ * sorter, prefix doubling from the first refinement round; 3: bucket sorter, then general sorter; 4: sample
+ * sorter first, for a caller that knows its data is text-like (saves the bucket sorter's wasted attempt).  All
  * produce the same bytes (the suffix array of a block is unique); the knob exists for tests and A/B timing. */
 CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode);
 /* number of blocks of the plan's last call the bucket sorter gave up on (0 for i.i.d.-like data) */

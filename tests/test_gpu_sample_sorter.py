@@ -82,6 +82,10 @@ def test_sample_sorter_cases(glc, ctx, cuda, name):
         g3, i3 = _bwt(glc, plan, torch, x)
         assert int(i3[0]) == widx and np.array_equal(g3, want), "%s without the sample tier" % name
         assert plan.last_sort_stats() == (flagged1, flagged1)
+        plan.set_sorter(4)                                     # sample sorter first (the caller's hint): same bytes, no attempt
+        g4, i4 = _bwt(glc, plan, torch, x)
+        assert int(i4[0]) == widx and np.array_equal(g4, want), "%s with the sample sorter first" % name
+        assert plan.last_sort_stats() == (1, flagged2)
         plan.set_sorter(0)
         g0, i0 = _bwt(glc, plan, torch, x)                     # and the plan is reusable afterwards
         assert int(i0[0]) == widx and np.array_equal(g0, want)
@@ -114,6 +118,19 @@ def test_sample_sorter_mixed_batch(glc, ctx, cuda):
             for i, blk in enumerate(blocks):
                 want, widx = O.bwt(blk)
                 assert int(gidx[i]) == widx and np.array_equal(got[i * N:(i + 1) * N], want), "block %d (call %d)" % (i, rep)
+
+
+def test_sample_sorter_first_on_iid_data(glc, ctx, cuda):
+    """the hint on data that did not need it: slower, same bytes"""
+    import torch
+    x = np.concatenate([datagen.zipf_bytes(N, seed=51), datagen.float_bytes(N, seed=52)])
+    with glc.Plan(ctx, glc.CUDPP_BWT, N, rows=2) as plan:
+        plan.set_sorter(4)
+        got, gidx = _bwt(glc, plan, torch, x, rows=2)
+        assert plan.last_sort_stats() == (2, 0)
+        for i in range(2):
+            want, widx = O.bwt(x[i * N:(i + 1) * N])
+            assert int(gidx[i]) == widx and np.array_equal(got[i * N:(i + 1) * N], want)
 
 
 def test_compress_text_round_trip(glc, ctx, cuda):

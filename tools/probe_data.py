@@ -8,11 +8,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 import numpy as np, torch, datagen
 glc = bench._load("glc_binding", os.path.join(ROOT, "gpu-lossless-compression_amd", "glc_binding.py"))
+sorter = int(os.environ.get("GLC_SORTER", "0"))
 classes = sys.argv[1:] or ["zipf", "float", "text", "log"]
 dev = torch.device("cuda:0")
 n, rows, distinct = 1 << 20, 256, 8
 gen = {"zipf": datagen.zipf_bytes, "float": datagen.float_bytes, "text": datagen.text_bytes, "log": datagen.log_bytes}
 with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
+    plan.set_sorter(sorter)
     for name in classes:
         x = gen[name](n * distinct).reshape(distinct, n)
         d_in = torch.from_numpy(np.tile(x, (rows // distinct, 1))).to(dev).contiguous()
