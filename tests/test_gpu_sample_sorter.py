@@ -133,6 +133,25 @@ def test_sample_sorter_first_on_iid_data(glc, ctx, cuda):
             assert int(gidx[i]) == widx and np.array_equal(got[i * N:(i + 1) * N], want)
 
 
+@pytest.mark.parametrize("mode", [0, 3, 4])
+def test_suffix_array_of_text(glc, ctx, cuda, mode):
+    """cudppSuffixArray on text: the tiers write the suffix array itself (not only BWT bytes); a deep block in the same
+    plan afterwards takes the general sorter's"""
+    import torch
+    n = 300000
+    with glc.Plan(ctx, glc.CUDPP_SA, n) as plan:
+        plan.set_sorter(mode)
+        for x, general in ((datagen.text_bytes(n, seed=61), 0), (np.tile(np.frombuffer(b"abcd", dtype=np.uint8), n // 4), 1),
+                           (datagen.log_bytes(n, seed=62), 0)):
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.zeros(n + 1, dtype=torch.int32, device=d_in.device)
+            assert glc.lib().cudppSuffixArray(plan.handle, d_in.data_ptr(), d_out.data_ptr(), n) == glc.CUDPP_SUCCESS
+            got = d_out.cpu().numpy().view(np.uint32)
+            want = O.suffix_array(x)
+            assert got[0] == n and np.array_equal(got[1:], want)
+            assert plan.last_sort_stats()[1] == (1 if mode == 3 else general)
+
+
 def test_compress_text_round_trip(glc, ctx, cuda):
     """whole pipeline on text (the speculative MTF + Huffman pass is redone for the flagged blocks): stream decodes to the input"""
     import torch
