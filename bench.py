@@ -427,7 +427,7 @@ def main():
     batches = list(range(0, nblocks, rows))
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=nplans)
-    flagged = [0]
+    flagged = [0, 0]
 
     def run_threads(fn, nthreads):
         nthreads = max(1, min(nthreads, nplans))
@@ -447,7 +447,9 @@ def main():
                                     out["size"].data_ptr() + 4 * b0, out["words"].data_ptr() + 4 * stride * b0, stride, n, nb)
             if rc != 0:
                 raise RuntimeError("glcCompressBatch -> %d" % rc)
-            flagged[0] += pl.last_flagged_blocks()
+            st2 = pl.last_sort_stats()
+            flagged[0] += st2[0]
+            flagged[1] += st2[1]
         pl.synchronize()
 
     def encode_all():
@@ -478,7 +480,7 @@ def main():
     for pl in plans:
         pl.synchronize()
         pl.enable_timing(3)
-    flagged[0] = 0
+    flagged[0] = flagged[1] = 0
     barrier()
     step_s = []
     t0 = time.perf_counter()
@@ -692,9 +694,10 @@ def main():
                        "block_bytes": n, "blocks_per_gpu": nblocks, "batch_rows": rows,
                        "plans_per_gpu": nplans, "encode_host_threads": min(args.enc_threads, nplans),
                        "decode_host_threads": min(args.dec_threads, nplans),
-                       "suffix_sorter": {0: "bucket sorter (general sorter for flagged blocks)", 1: "general sorter only",
-                                         2: "general sorter, prefix doubling only"}[args.sorter],
-                       "blocks_sent_to_general_sorter": flagged[0],
+                       "suffix_sorter": {0: "bucket sorter; sample sorter for the blocks it flags; general sorter for what that flags",
+                                         1: "general sorter only", 2: "general sorter, prefix doubling only",
+                                         3: "bucket sorter, then general sorter", 4: "sample sorter first"}[args.sorter],
+                       "blocks_left_by_bucket_sorter": flagged[0], "blocks_left_by_sample_sorter": flagged[1],
                        "stage_pipelining": {"encode": bool(args.enc_pipeline), "decode": not args.no_dec_pipeline},
                        "parallelism": "blocks round-robin over %d GPU(s), no data-path collective" % world},
             "compression_ratio": round(ratio, 4),

@@ -692,6 +692,7 @@ __device__ __forceinline__ bool ss_suffix_less_from(const uint8_t *T, uint32_t n
 
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
+constexpr uint32_t SS_NPL = 4, SS_NPIV0 = 64 * SS_NPL;         // first cut: 256 pivots
 constexpr uint32_t SS_SHARES = 64;                             // shares of a bucket's positions handed out to the waves
 constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
 constexpr uint32_t SS_MAXSTEP = FS_LCP_CAP / SS_STEP + 1;      // rounds of a run before the block is given up as deep
@@ -760,7 +761,8 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     __shared__ uint32_t s_v[FS_FILLMAX];                       // index << 8 | BWT byte of the suffix at a position
     __shared__ uint32_t s_seg[FS_FILLMAX];                     // run of a position (ss_run)
     __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end), of the cut a wave is making
-    __shared__ uint64_t s_piv0[SS_NPIV];                       // pivots of the first cut
+    __shared__ uint64_t s_piv0[SS_NPIV0];                      // pivots of the first cut, sorted
+    __shared__ uint64_t s_pl[SS_NPL][64];                      // ... as the four sorted lists they are merged from
     __shared__ uint32_t s_deep, s_l0, s_next, s_nlong, s_bound[SS_NBIN + 1];
     const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x, nb = 1u << nbl;
     const uint32_t lane = tid & 63, wv = tid >> 6;
@@ -812,45 +814,69 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
             if (p < c) { key[r] = ss_sym_key(key[r]); s_k[p] = key[r]; }
         }
         __syncthreads();
-        if (wv == 0) s_piv0[lane] = wave_sort_u64(s_k[(lane * c) / SS_NPIV], lane);
+        // 256 pivots for the first cut (bins of ~c / 513: the windows count inside runs directly, quadratic in their
+        // length, and with 64 pivots that counting was what k_ss_windows spent its time on): four waves sort 64 sampled
+        // keys each, every pivot then finds its place among the other three lists
+        if (wv < SS_NPL) s_pl[wv][lane] = wave_sort_u64(s_k[(uint32_t)(((uint64_t)(wv * 64 + lane) * c) / SS_NPIV0)], lane);
         __syncthreads();
-        const uint64_t piv = s_piv0[lane];
+        if (tid < SS_NPIV0) {
+            const uint32_t w = tid >> 6;
+            const uint64_t kv = s_pl[w][lane];
+            uint32_t rank = lane;
+#pragma unroll
+            for (uint32_t ow = 0; ow < SS_NPL; ow++) {
+                if (ow == w) continue;
+                uint32_t lo = 0, hi = 64;                      // elements of list ow that come before kv (ties: the lower list first)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint64_t x = s_pl[ow][mid];
+                    if (x < kv || (x == kv && ow < w)) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            s_piv0[rank] = kv;
+        }
+        __syncthreads();
+        uint32_t *cnt0 = &s_cnt[0][0];                         // (the counter rows of all waves as one array: 2 * 256 + 3 entries)
         uint32_t bin[SSS_ITEMS], rk[SSS_ITEMS];
 #pragma unroll
         for (int r = 0; r < SSS_ITEMS; r++) {
             const uint32_t p = r * SSS_NT + tid;
-            if (r * SSS_NT >= c) continue;                     // (uniform; ss_pivot_bin shuffles across the whole wave)
-            bin[r] = ss_pivot_bin(piv, key[r]);
-            if (p < c) rk[r] = atomicAdd(&s_cnt[0][bin[r]], 1u);
+            if (p < c) {
+                uint32_t lo = 0, hi = SS_NPIV0;                // first pivot >= key
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_piv0[mid] < key[r]) lo = mid + 1; else hi = mid; }
+                bin[r] = 2 * lo + ((lo < SS_NPIV0 && s_piv0[lo] == key[r]) ? 1u : 0u);
+                rk[r] = atomicAdd(&cnt0[bin[r]], 1u);
+            }
         }
         __syncthreads();
         if (wv == 0) {
-            uint32_t c3[3], tot = 0;
+            constexpr int PER = (2 * SS_NPIV0 + 2 + 63) / 64;     // 514 starts + the end
+            uint32_t cc[PER], tot = 0;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; c3[k] = i < SS_NBIN ? s_cnt[0][i] : 0u; tot += c3[k]; }
+            for (int k = 0; k < PER; k++) { const uint32_t i = PER * lane + k; cc[k] = i < 2 * SS_NPIV0 + 1 ? cnt0[i] : 0u; tot += cc[k]; }
             uint32_t run = wave_incl_add(tot) - tot;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; if (i <= SS_NBIN) s_cnt[0][i] = run; run += c3[k]; }
+            for (int k = 0; k < PER; k++) { const uint32_t i = PER * lane + k; if (i <= 2 * SS_NPIV0 + 1) cnt0[i] = run; run += cc[k]; }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SSS_ITEMS; r++) {
             const uint32_t p = r * SSS_NT + tid;
-            if (r * SSS_NT >= c) continue;
             if (p < c) {
-                const uint32_t gs = s_cnt[0][bin[r]], ge = s_cnt[0][bin[r] + 1], q = gs + rk[r];
+                const uint32_t gs = cnt0[bin[r]], ge = cnt0[bin[r] + 1], q = gs + rk[r];
                 s_v[q] = vv[r];
                 s_seg[q] = ss_run(gs, ge, bin[r] & 1);         // a pivot's bin: all keys equal, one round done
             }
         }
         __syncthreads();
         // bins still longer than a window (a key shared by hundreds of suffixes, or an unlucky gap between pivots)
-        if (tid < SS_NBIN) {
-            const uint32_t gs = s_cnt[0][tid], ge = s_cnt[0][tid + 1];
+        if (tid < 2 * SS_NPIV0 + 1) {
+            const uint32_t gs = cnt0[tid], ge = cnt0[tid + 1];
             if (ge - gs > SS_WIN) s_bound[atomicAdd(&s_nlong, 1u)] = gs | (ge << 16);
         }
         __syncthreads();
-        if (tid < SS_NBIN + 3) s_cnt[0][tid] = 0;
+        for (uint32_t i = tid; i < SSS_WAVES * (SS_NBIN + 3); i += SSS_NT) cnt0[i] = 0;
     }
     __syncthreads();
     // ---- such bins are cut again, each by one wave, until no run in them is longer than a window ----
