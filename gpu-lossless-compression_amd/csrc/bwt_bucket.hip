@@ -668,28 +668,6 @@ __device__ __forceinline__ uint64_t ss_sym_key(uint64_t raw)
     return k;
 }
 
-// suffix a < suffix b, both known to agree in their first `from` symbols
-__device__ __forceinline__ bool ss_suffix_less_from(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, uint32_t from,
-                                                    bool *deep)
-{
-    uint32_t k = from;
-    for (;;) {
-        const uint32_t m = max(a, b) + k;
-        if (m + 12 <= n) {
-            const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
-            if (va != vb) return va < vb;
-            k += 8;
-        } else {
-            if (a + k >= n) return true;
-            if (b + k >= n) return false;
-            const uint32_t ca = T[a + k], cb = T[b + k];
-            if (ca != cb) return ca < cb;
-            k++;
-        }
-        if (k - from > FS_LCP_CAP) { *deep = true; return false; }
-    }
-}
-
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
 constexpr uint32_t SS_NPL = 4, SS_NPIV0 = 64 * SS_NPL;         // first cut: 256 pivots
@@ -753,7 +731,7 @@ __device__ __forceinline__ uint32_t ss_pivot_bin(uint64_t piv, uint64_t key)
 // Nothing here depends on the symbol statistics.
 __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                     uint32_t nbl, uint64_t *__restrict__ keys, size_t kstride,
-                                                    const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
+                                                    const uint32_t *__restrict__ fill,
                                                     uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
                                                     const uint64_t *__restrict__ split, uint32_t *__restrict__ l0_out)
 {
@@ -768,7 +746,6 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
-    const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
     const uint64_t *SP = split + (size_t)b * FS_MAXNB;
     if (tid == 0) {
         s_deep = flag[b];
@@ -894,7 +871,6 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
             // window [pos, W): the runs that start in it and end within SS_WIN positions
             const uint32_t lim = min(B, pos + SS_WIN);
             uint32_t g4[4], W = lim;
-            bool und = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t p = pos + lane + 64 * j;
@@ -902,7 +878,6 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
                 if (p < lim) {
                     const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu;
                     if (se > lim) W = min(W, ss);              // a run that runs out of the window: the window ends before it
-                    und |= se - ss > 1;
                 }
             }
             W = (uint32_t)wave_min_u64((uint64_t)W);
@@ -1168,7 +1143,7 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                        n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_cell);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
     hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_split, s.ss_l0);
+                       s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_l0);
     hipLaunchKernelGGL(k_ss_windows, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                        s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
                        (size_t)s.nmax);
