@@ -1,0 +1,98 @@
+"""Seeded random mixtures through every sorter tier and the whole pipeline: blocks glued from pieces of different
+kinds (i.i.d. bytes, text, log lines, runs, repeats, periodic data, small alphabets), random block sizes, random
+batch shapes.  BWT bytes + index against the oracle for every block; compress -> decompress back to the input;
+streams identical to the oracle's for a sample."""
+import numpy as np
+import pytest
+
+import datagen
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _piece(rng, n):
+    kind = int(rng.integers(0, 10))
+    seed = int(rng.integers(1, 1 << 30))
+    if kind == 0:
+        return datagen.zipf_bytes(n, seed=seed, s=float(rng.uniform(0.5, 2.0)))
+    if kind == 1:
+        return datagen.text_bytes(n, seed=seed)
+    if kind == 2:
+        return datagen.log_bytes(n, seed=seed)
+    if kind == 3:
+        return datagen.float_bytes(n, seed=seed)
+    if kind == 4:
+        return np.full(n, int(rng.integers(0, 256)), dtype=np.uint8)
+    if kind == 5:
+        per = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)
+        return np.tile(per, n // per.size + 1)[:n]
+    if kind == 6:
+        return rng.integers(0, int(rng.integers(2, 6)), n, dtype=np.uint8) + np.uint8(rng.integers(0, 250))
+    if kind == 7:
+        chunk = rng.integers(0, 256, max(1, n // int(rng.integers(2, 9))), dtype=np.uint8)
+        return np.tile(chunk, n // chunk.size + 1)[:n]
+    if kind == 8:
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    base = datagen.text_bytes(n, seed=seed)
+    base[rng.integers(0, n, max(1, n // 50))] = rng.integers(0, 256, max(1, n // 50), dtype=np.uint8)   # text with typos
+    return base
+
+
+def _block(rng, n):
+    parts, left = [], n
+    while left > 0:
+        m = left if rng.random() < 0.35 else int(rng.integers(1, left + 1))
+        parts.append(_piece(rng, m))
+        left -= m
+    return np.concatenate(parts)[:n]
+
+
+@pytest.fixture(scope="module")
+def ctx(glc, cuda):
+    c = glc.Cudpp()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_bwt_batches(glc, ctx, cuda, seed):
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 3, 64, 2048, 4097, 50000, 262144, 1 << 20, int(rng.integers(2, 1 << 20))]))
+    rows = int(rng.integers(1, 6))
+    x = np.concatenate([_block(rng, n) for _ in range(rows)])
+    with glc.Plan(ctx, glc.CUDPP_BWT, n, rows=rows) as plan:
+        for mode in (0, 4):
+            plan.set_sorter(mode)
+            d_in = torch.from_numpy(x).cuda()
+            d_out = torch.zeros(x.size, dtype=torch.uint8, device=d_in.device)
+            d_idx = torch.zeros(rows, dtype=torch.int32, device=d_in.device)
+            assert glc.lib().glcBwtBatch(plan.handle, d_in.data_ptr(), d_out.data_ptr(), d_idx.data_ptr(), n, rows) == 0
+            torch.cuda.synchronize()
+            got, gidx = d_out.cpu().numpy(), d_idx.cpu().numpy()
+            for i in range(rows):
+                want, widx = O.bwt(x[i * n:(i + 1) * n])
+                ok = int(gidx[i]) == widx and np.array_equal(got[i * n:(i + 1) * n], want)
+                assert ok, "seed %d n %d block %d mode %d tiers %r" % (seed, n, i, mode, plan.last_sort_stats())
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_fuzz_compress_round_trip(glc, ctx, cuda, seed):
+    import torch
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.choice([4096, 70000, 1 << 19, 1 << 20]))
+    rows = int(rng.integers(1, 5))
+    x = np.concatenate([_block(rng, n) for _ in range(rows)])
+    d_in = torch.from_numpy(x).cuda()
+    with glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
+        for rep in range(2):                                   # the second call sees the plan's memory of the first
+            comp = glc.compress_batch(plan, d_in, n, rows)
+            plan.synchronize()
+            back = glc.decompress_batch(plan, comp, n, rows)
+            torch.cuda.synchronize()
+            assert np.array_equal(back.cpu().numpy(), x), "seed %d n %d call %d" % (seed, n, rep)
+        want = O.compress(x[:n])
+        size = int(comp["size"][0].item())
+        assert size == want["size"] and int(comp["bwt_index"][0].item()) == want["bwt_index"]
+        assert np.array_equal(comp["words"][:size].cpu().numpy().view(np.uint32), want["words"])
