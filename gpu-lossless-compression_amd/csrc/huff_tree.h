@@ -43,12 +43,26 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t k)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// wave-wide minimum of a 32-bit value, broadcast to every lane (inclusive min-scan on DPP, lane 63 holds the result)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
+{
+#define GLC_MIN32_STEP(ctrl, rowmask)                                                                            \
+    { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k, ctrl, rowmask, 0xf, false); k = o < k ? o : k; }
+    GLC_MIN32_STEP(0x111, 0xf) GLC_MIN32_STEP(0x112, 0xf) GLC_MIN32_STEP(0x114, 0xf) GLC_MIN32_STEP(0x118, 0xf)
+    GLC_MIN32_STEP(0x142, 0xa) GLC_MIN32_STEP(0x143, 0xc)
+#undef GLC_MIN32_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
+}
+
 // Called by ONE full wave (l = lane).  hist257[256] must already hold the EOF count 1.
-// The candidate keys live in REGISTERS: slot s (< 320) is register s >> 6 of lane s & 63, so the two arg-mins of a
-// merge are five compares + one DPP reduction each with no LDS round trip between them (with the keys in LDS the
-// 512 reductions of a block each waited for five LDS reads and a barrier: 0.24 -> 0.1x ms per 256 blocks).
+// The candidates live in REGISTERS: slot s (< 320) is register s >> 6 of lane s & 63 and holds count << 5 | level
+// (count <= 2^20 + 1, level < 32; ~0 = no candidate).  The slot itself need not be stored -- it is where the value
+// sits -- so FindMinimumCount's order (count, level, slot) is two 32-bit wave minima: the smallest value, then the
+// smallest slot among the lanes that hold it.  (64-bit keys in LDS: five reads and a barrier per arg-min, 512 arg-mins
+// per block back to back; 64-bit keys in registers: 12 DPP steps of compare-and-select on register pairs.)
 __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *hist257, unsigned l)
 {
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
     // leaves: present symbols in ascending order -> slots 0..nl-1 (compress_kernel.cuh:2310-2321)
     uint32_t nl = 0;
     for (int r = 0; r < 5; r++) {
@@ -59,44 +73,47 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
             const uint32_t slot = nl + mbcnt(bal);
             T.count[slot] = c; T.level[slot] = 0; T.value[slot] = (int16_t)sym;
             T.left[slot] = -1; T.right[slot] = -1; T.parent[slot] = -1;
-            T.key[slot] = ((uint64_t)c << 32) | slot;
+            T.key[slot] = (uint64_t)(c << 5);
         }
         nl += (uint32_t)__popcll(bal);
     }
-    for (uint32_t s = nl + l; s < 320; s += 64) T.key[s] = HUFF_KEY_NONE;
+    for (uint32_t s = nl + l; s < 320; s += 64) T.key[s] = NONE;
     __builtin_amdgcn_wave_barrier();
-    uint64_t key[5];
+    uint32_t P[5];
 #pragma unroll
-    for (int r = 0; r < 5; r++) key[r] = T.key[r * 64 + l];
+    for (int r = 0; r < 5; r++) P[r] = (uint32_t)T.key[r * 64 + l];
     __builtin_amdgcn_wave_barrier();
 
+    // (value, slot) of the smallest candidate; value NONE if there is none
+    auto arg_min = [&](uint32_t &val) -> uint32_t {
+        uint32_t best = P[0], br = 0;
+#pragma unroll
+        for (int r = 1; r < 5; r++) { const bool lt = P[r] < best; best = lt ? P[r] : best; br = lt ? (uint32_t)r : br; }
+        val = wave_min_u32(best);
+        return wave_min_u32(best == val ? br * 64 + l : NONE);
+    };
     int head = -1;
     for (uint32_t k = 0;; k++) {
-        uint64_t best = key[0];
-#pragma unroll
-        for (int r = 1; r < 5; r++) best = key[r] < best ? key[r] : best;
-        best = wave_min_u64(best);
-        if (best == HUFF_KEY_NONE) break;
-        const int min1 = (int)(best & 0xFFFF);
+        uint32_t v1, v2;
+        const uint32_t m1 = arg_min(v1);
+        if (v1 == NONE) break;
+        const int min1 = (int)m1;
         head = min1;
 #pragma unroll
-        for (int r = 0; r < 5; r++) if ((unsigned)min1 == r * 64 + l) key[r] = HUFF_KEY_NONE;
-        uint64_t best2 = key[0];
-#pragma unroll
-        for (int r = 1; r < 5; r++) best2 = key[r] < best2 ? key[r] : best2;
-        best2 = wave_min_u64(best2);
-        if (best2 == HUFF_KEY_NONE) break;
-        const int min2 = (int)(best2 & 0xFFFF);
+        for (int r = 0; r < 5; r++) if (m1 == r * 64 + l) P[r] = NONE;
+        const uint32_t m2 = arg_min(v2);
+        if (v2 == NONE) break;
+        const int min2 = (int)m2;
         // min1 moves to the next free slot >= nl and becomes the LEFT child; min2 stays and
         // is the RIGHT child; the composite takes min1's slot (compress_kernel.cuh:2344-2385)
-        const uint32_t c1 = (uint32_t)(best >> 32), c2 = (uint32_t)(best2 >> 32);
-        const int l1 = (int)((best >> 16) & 0xFFFF), l2 = (int)((best2 >> 16) & 0xFFFF);
+        const uint32_t c1 = v1 >> 5, c2 = v2 >> 5;
+        const int l1 = (int)(v1 & 31u), l2 = (int)(v2 & 31u);
         const int lv = (l1 > l2 ? l1 : l2) + 1;
-        const uint64_t nk = ((uint64_t)(c1 + c2) << 32) | ((uint64_t)lv << 16) | (uint32_t)min1;
+        const uint32_t nk = ((c1 + c2) << 5) | (uint32_t)lv;
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            if ((unsigned)min1 == r * 64 + l) key[r] = nk;
-            if ((unsigned)min2 == r * 64 + l) key[r] = HUFF_KEY_NONE;
+            if (m1 == r * 64 + l) P[r] = nk;
+            if (m2 == r * 64 + l) P[r] = NONE;
         }
         if (l == 0) {
             const int i = (int)(nl + k);

@@ -30,8 +30,11 @@
 
 namespace glc {
 
-// one 256-thread workgroup per 1 MiB block
-__global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__ sub_hist, uint32_t max_sub,
+// one 1024-thread workgroup per 1 MiB block: the two passes over the 256 partial histograms use all 16 waves (they
+// are loads and nothing else; a workgroup per CU is all this kernel has), the tree is built by one wave
+constexpr int HB_NT = 1024;
+
+__global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict__ sub_hist, uint32_t max_sub,
                                                     uint32_t n, uint32_t *__restrict__ d_hist,
                                                     uint32_t *__restrict__ codes_out,
                                                     uint32_t *__restrict__ lens_out,
@@ -41,10 +44,11 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ redo_flag)
 {
     __shared__ uint32_t s_hist[257];
+    __shared__ uint32_t s_part[4][256];
     __shared__ HuffTreeLds T;
     __shared__ uint32_t s_code[257], s_len[257];
     __shared__ uint32_t s_words[256];
-    __shared__ uint32_t s_tmp[8];
+    __shared__ uint32_t s_tmp[HB_NT / 64 + 1];
 
     const uint32_t b = blockIdx.x, tid = threadIdx.x, l = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,17 +58,21 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
     // ---- total histogram (huffman_build_tree_kernel merges partial histograms,
     //      compress_kernel.cuh:2284-2299; EOF gets count 1, :2250) ----
     {
-        // 16 loads in flight per thread: one workgroup per CU is all this kernel has, and a load-wait-add loop over
-        // the 256 partial histograms was ~150 us of latency
-        uint32_t c = 0, s = 0;
-        for (; s + 16 <= nsub; s += 16) {
+        // thread = (symbol, quarter of the sub-blocks), 16 loads in flight
+        const uint32_t sym = tid & 255, qt = tid >> 8;
+        uint32_t c = 0;
+        for (uint32_t s = qt * 16; s < nsub; s += 64) {
             uint32_t v[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = SH[(size_t)(s + k) * 256 + tid];
+            for (int k = 0; k < 16; k++) v[k] = s + k < nsub ? SH[(size_t)(s + k) * 256 + sym] : 0u;
 #pragma unroll
             for (int k = 0; k < 16; k++) c += v[k];
         }
-        for (; s < nsub; s++) c += SH[(size_t)s * 256 + tid];
+        s_part[qt][sym] = c;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const uint32_t c = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
         s_hist[tid] = c;
         d_hist[(size_t)b * 256 + tid] = c;
         s_code[tid] = 0; s_len[tid] = 0;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
     //      (left = 0, right = 1: compress_kernel.cuh:2416-2496) ----
     {
         const int nl = T.nl, used = 2 * nl - 1;
-        for (int s = (int)tid; s < used; s += 256) {
+        for (int s = (int)tid; s < used; s += HB_NT) {
             if (T.left[s] < 0) {
                 uint32_t code = 0, len = 0;
                 int node = s, p = T.parent[s];
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < 257; i += 256) {
+    for (uint32_t i = tid; i < 257; i += HB_NT) {
         codes_out[(size_t)b * 257 + i] = s_code[i];
         lens_out[(size_t)b * 257 + i] = s_len[i];
     }
@@ -104,17 +112,17 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
         uint32_t ln[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) ln[r] = s_len[r * 64 + l];
-        for (uint32_t s0 = w; s0 < 256; s0 += 16) {            // four sub-blocks of this wave at a time: 16 loads in flight
+        for (uint32_t s0 = w; s0 < 256; s0 += 64) {            // four sub-blocks of this wave at a time: 16 loads in flight
             uint32_t h[4][4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t sb = s0 + 4 * k;
+                const uint32_t sb = s0 + 16 * k;
 #pragma unroll
                 for (int r = 0; r < 4; r++) h[k][r] = sb < nsub ? SH[(size_t)sb * 256 + r * 64 + l] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t sb = s0 + 4 * k;
+                const uint32_t sb = s0 + 16 * k;
                 uint32_t bits = h[k][0] * ln[0] + h[k][1] * ln[1] + h[k][2] * ln[2] + h[k][3] * ln[3];
                 bits = wave_sum(bits);
                 if (l == 0) s_words[sb] = (sb < nsub) ? (bits + 31) / 32 : 0u;
@@ -123,10 +131,10 @@ __global__ __launch_bounds__(256) void k_huff_build(const uint32_t *__restrict__
     }
     __syncthreads();
     {
-        const uint32_t wd = s_words[tid];
+        const uint32_t wd = tid < 256 ? s_words[tid] : 0u;
         const uint32_t item = (tid < nsub) ? 1 + wd : 0;
         uint32_t total = 0;
-        const uint32_t off = block_excl_add<256>(item, s_tmp, &total);
+        const uint32_t off = block_excl_add<HB_NT>(item, s_tmp, &total);
         if (tid < nsub) {
             d_offsets[(size_t)b * offset_stride + tid] = off;
             if (wd > HUFF_MAX_WORDS && !(redo_flag && redo_flag[b])) atomicOr(d_status, ST_BLOCK_OVERFLOW);
@@ -329,7 +337,7 @@ hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s,
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const int pi = s.prof ? s.prof->begin(PROF_HUFF_BUILD, st) : -1;
-    hipLaunchKernelGGL(k_huff_build, dim3(nblk), dim3(256), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
+    hipLaunchKernelGGL(k_huff_build, dim3(nblk), dim3(HB_NT), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
                        s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status, redo_flag);
     if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
