@@ -345,7 +345,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gib", type=float, default=4.0, help="input per GPU (GiB)")
-    ap.add_argument("--rows", type=int, default=256, help="blocks per batched call (plan rows)")
+    ap.add_argument("--rows", type=int, default=1024, help="blocks per batched call (plan rows); 47 MiB of plan scratch per row")
     ap.add_argument("--plans", type=int, default=3, help="plans (each with its own stream) per GPU")
     ap.add_argument("--enc-threads", type=int, default=1, help="host threads (= plans) used by the timed encode leg")
     ap.add_argument("--dec-threads", type=int, default=3, help="host threads (= plans) used by the decode leg")
@@ -677,6 +677,13 @@ def main():
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
                 tsrc = "profiles/pmc_traffic.json (offline rocprofv3 --pmc passes, %s)" % tj.get("collected", "see file")
+                if traffic is not None:
+                    # the counters were collected on launches of `blocks_per_launch` blocks; these kernels move a
+                    # fixed number of bytes per block, so a launch over more blocks scales with the block count
+                    per = float(tj.get("blocks_per_launch", 256))
+                    mine = kernels[dom]["units"] / max(1, kernels[dom]["launches"]) / float(n)
+                    traffic = int(round(traffic * mine / per))
+                    tsrc += "; counted per launch of %d blocks, scaled to this run's %d" % (int(per), int(round(mine)))
             except Exception:
                 traffic = None
         res = {

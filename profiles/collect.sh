@@ -19,7 +19,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o ${TAG} -- \
     python $REPO/bench.py --gib $GIB --steps 1 --warmup 1 --no-cpu-baseline --main-only --no-overlap-pass > $OUT/${TAG}_prof.log 2>&1
 for CTR in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $CTR --kernel-trace -d $OUT/${TAG}_pmc_$CTR -o pmc -- \
-      python $REPO/bench.py --gib 0.25 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --main-only --no-overlap-pass > $OUT/${TAG}_pmc_$CTR.log 2>&1
+      python $REPO/bench.py --gib 0.25 --rows 256 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --main-only --no-overlap-pass > $OUT/${TAG}_pmc_$CTR.log 2>&1
 done
 cd $REPO
 find $OUT -name "*.db" -size +62M -delete

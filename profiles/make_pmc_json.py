@@ -81,6 +81,7 @@ def main():
         },
         "fetch_correction": FETCH_CORR, "write_correction": WRITE_CORR,
         "collected": tag,
+        "blocks_per_launch": 256,
         "hbm_bytes_per_launch": per_launch,
         "encode_hbm_bytes_per_input_byte": round(enc_bytes / float(256 << 20), 2) if enc_bytes else None,
         "encode_hbm_bytes_note": "sum over the encode kernels of one 256-block launch each / 256 MiB "
