@@ -171,3 +171,46 @@ def test_compress_text_round_trip(glc, ctx, cuda):
             assert size == want["size"] and int(comp["bwt_index"][i].item()) == want["bwt_index"]
             words = comp["words"][i * comp["stride"]:i * comp["stride"] + size].cpu().numpy().view(np.uint32)
             assert np.array_equal(words, want["words"]), "block %d" % i
+
+
+def test_pipelined_calls_across_tiers(glc, ctx, cuda):
+    """glcPlanSetPipelining with batches that change character from call to call (all text, all Zipf, text with a block
+    for the general sorter, ...): the plan's memory of the previous call decides whether the stages behind the sort are
+    queued speculatively, and every combination must give the streams of plain calls"""
+    import torch
+    n, nb = 1 << 17, 3
+    kinds = ["text", "text", "zipf", "deep", "text", "zipf", "zipf", "text"]
+
+    def batch(c, kind):
+        if kind == "zipf":
+            return np.concatenate([datagen.zipf_bytes(n, seed=3000 + 10 * c + b) for b in range(nb)])
+        x = [datagen.text_bytes(n, seed=4000 + 10 * c + b) for b in range(nb)]
+        if kind == "deep":
+            x[1] = np.tile(np.frombuffer(b"ab", dtype=np.uint8), n // 2)
+        return np.concatenate(x)
+    batches = [batch(c, k) for c, k in enumerate(kinds)]
+    d_in = [torch.from_numpy(x).cuda() for x in batches]
+
+    def run(pipelined):
+        outs = []
+        with glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=nb) as plan:
+            plan.set_pipelining(pipelined)
+            res = [glc.compress_batch(plan, d_in[c], n, nb) for c in range(len(kinds))]   # no sync in between
+            plan.synchronize()
+            for r in res:
+                sizes = r["size"].cpu().numpy()
+                outs.append((r["bwt_index"].cpu().numpy().copy(), sizes.copy(), r["hist"].cpu().numpy().copy(),
+                             [r["words"][b * r["stride"]: b * r["stride"] + int(sizes[b])].cpu().numpy().copy()
+                              for b in range(nb)]))
+        return outs
+
+    plain, piped = run(False), run(True)
+    for c in range(len(kinds)):
+        assert np.array_equal(plain[c][0], piped[c][0]) and np.array_equal(plain[c][1], piped[c][1]), "call %d" % c
+        assert np.array_equal(plain[c][2], piped[c][2]), "call %d" % c
+        for b in range(nb):
+            assert np.array_equal(plain[c][3][b], piped[c][3][b]), "call %d block %d" % (c, b)
+    for c in (1, 3, 5):                                        # and against the oracle
+        for b in range(nb):
+            want = O.compress(batches[c][b * n:(b + 1) * n])
+            assert np.array_equal(plain[c][3][b].view(np.uint32), want["words"]), "call %d block %d vs oracle" % (c, b)
