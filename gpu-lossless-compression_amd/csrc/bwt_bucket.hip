@@ -203,7 +203,17 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     // (38 KB instead of 44 KB of LDS: 4 workgroups per CU instead of 3)
     uint2 *s_tab = reinterpret_cast<uint2 *>(s_w);
     uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_w) + 256 * sizeof(uint2);   // s_txt[k] = T[base - 1 + k]; 16-byte aligned
-    const uint32_t b = SPLIT ? list[blockIdx.y] : blockIdx.y, tid = threadIdx.x, base = blockIdx.x * FSP_TILE;
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs, so physical workgroup p runs on XCD p & 7.  The
+    // tiles of a block are made consecutive on ONE XCD (logical index = first of the XCD's share + p / 8): their appends to a bucket's
+    // slot are neighbours in that XCD's L2 and leave it as whole lines, and the block's fill counters stay in one L2.
+    uint32_t bx, by;
+    {
+        const uint32_t tiles = gridDim.x, total = tiles * gridDim.y, p = blockIdx.y * tiles + blockIdx.x;
+        const uint32_t q = total >> 3, r = total & 7u, x = p & 7u;             // XCD x takes q + (x < r) tiles, in order
+        const uint32_t lg = x * q + min(x, r) + (p >> 3);
+        by = lg / tiles; bx = lg % tiles;
+    }
+    const uint32_t b = SPLIT ? list[by] : by, tid = threadIdx.x, base = bx * FSP_TILE;
     if (base >= n) return;
     if (SPLIT) {                                               // given up while sampling: no splitters to search
         if (tid == 0) s_tmp[0] = flag[b];                      // (one read: other tiles of this launch may flag the block meanwhile)
