@@ -678,6 +678,16 @@ __device__ __forceinline__ uint64_t ss_sym_key(uint64_t raw)
     return k;
 }
 
+// XCD-aware order of a (x, y) grid: physical workgroup p runs on XCD p & 7; the logical workgroups are dealt out so that
+// every XCD takes one contiguous run of them (all the buckets of a block on one XCD: the block's text stays in one L2)
+__device__ __forceinline__ void xcd_order(uint32_t &bx, uint32_t &by)
+{
+    const uint32_t nx = gridDim.x, total = nx * gridDim.y, p = blockIdx.y * nx + blockIdx.x;
+    const uint32_t q = total >> 3, r = total & 7u, x = p & 7u;
+    const uint32_t lg = x * q + min(x, r) + (p >> 3);
+    by = lg / nx; bx = lg % nx;
+}
+
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
 constexpr uint32_t SS_NPL = 4, SS_NPIV0 = 64 * SS_NPL;         // first cut: 256 pivots
@@ -752,7 +762,9 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     __shared__ uint64_t s_piv0[SS_NPIV0];                      // pivots of the first cut, sorted
     __shared__ uint64_t s_pl[SS_NPL][64];                      // ... as the four sorted lists they are merged from
     __shared__ uint32_t s_deep, s_l0, s_next, s_nlong, s_bound[SS_NBIN + 1];
-    const uint32_t b = list[blockIdx.y], bk = blockIdx.x, tid = threadIdx.x, nb = 1u << nbl;
+    uint32_t gx, gy;
+    xcd_order(gx, gy);
+    const uint32_t b = list[gy], bk = gx, tid = threadIdx.x, nb = 1u << nbl;
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
@@ -961,7 +973,9 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
     __shared__ uint32_t s_vw[SS_WIN];                          // index << 8 | BWT byte
     __shared__ uint32_t s_sw[SS_WIN];                          // run descriptors (bucket positions)
     __shared__ uint32_t s_bound[SS_SHARES + 1];
-    const uint32_t b = list[blockIdx.y], bk = blockIdx.x / SSW_PER_BUCKET, w0 = blockIdx.x % SSW_PER_BUCKET;
+    uint32_t gx, gy;
+    xcd_order(gx, gy);
+    const uint32_t b = list[gy], bk = gx / SSW_PER_BUCKET, w0 = gx % SSW_PER_BUCKET;
     const uint32_t lane = threadIdx.x;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
