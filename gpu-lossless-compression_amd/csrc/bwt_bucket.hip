@@ -534,8 +534,25 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
         const uint32_t gs = me.w, idx = me.x >> 8;
         uint32_t rank = 0;
         bool deep = false;
-        for (uint32_t f = me.z; f < me.z + gs && !deep; f++)
-            if (f != e) rank += fs_suffix_less(T, n, WL[f].x >> 8, idx, &deep) ? 1u : 0u;
+        // four members at a time: their list entries, then their first 8 text bytes, are loaded together (a member of a
+        // run of 100 equal codes would otherwise wait for 200 memory round trips one after the other); only a pair
+        // that agrees in those 8 bytes, or sits at the end of the block, takes the byte-exact loop
+        const bool fast_me = idx + 12 <= n;
+        const uint64_t mine = fast_me ? fs_load_be64(T + idx) : 0ull;
+        for (uint32_t f0 = me.z; f0 < me.z + gs && !deep; f0 += 4) {
+            uint32_t oi[4];
+            uint64_t ov[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) oi[k] = f0 + k < me.z + gs ? WL[f0 + k].x >> 8 : idx;
+#pragma unroll
+            for (int k = 0; k < 4; k++) ov[k] = (oi[k] != idx && fast_me && oi[k] + 12 <= n) ? fs_load_be64(T + oi[k]) : mine;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (oi[k] == idx) continue;                    // myself, or past the end of the run
+                if (fast_me && oi[k] + 12 <= n && ov[k] != mine) rank += ov[k] < mine ? 1u : 0u;
+                else rank += fs_suffix_less(T, n, oi[k], idx, &deep) ? 1u : 0u;
+            }
+        }
         if (deep) { atomicOr(&flag[b], 2u); continue; }
         const uint32_t row = me.y + rank;
         if (bwt_out) bwt_out[(size_t)b * bwt_stride + row] = (uint8_t)me.x;
@@ -1148,7 +1165,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, n, nbl, s.keyA, s.fs_kstride, s.fs_fill, s.fs_base,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt);
     if (pi >= 0) s.prof->end(pi, units, st);
-    hipLaunchKernelGGL(k_fs_ties, dim3(8, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
+    hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
                        s.fs_redo[s.parity & 1], s.ss_list);
