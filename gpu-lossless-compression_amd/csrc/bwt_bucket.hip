@@ -354,7 +354,9 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
     __shared__ uint32_t s_deep, s_wl;
     uint16_t *s16 = reinterpret_cast<uint16_t *>(s_cp);
     uint8_t *s_cb = reinterpret_cast<uint8_t *>(s_cp);
-    const uint32_t b = blockIdx.y, bk = blockIdx.x, tid = threadIdx.x;
+    uint32_t gx, gy;
+    xcd_order(gx, gy);
+    const uint32_t b = gy, bk = gx, tid = threadIdx.x;
     if (tid == 0) { s_deep = flag[b]; s_wl = 0; }              // (one read: another bucket may flag the block meanwhile)
     for (uint32_t i = tid; i < FS_BINS / 2; i += FSS_NT) s_cp[i] = 0;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
@@ -693,16 +695,6 @@ __device__ __forceinline__ uint64_t ss_sym_key(uint64_t raw)
 #pragma unroll
     for (int j = 0; j < (int)SS_STEP; j++) k = (k << 9) | (((raw >> (55 - 8 * j)) & 0xFFu) + 1u);
     return k;
-}
-
-// XCD-aware order of a (x, y) grid: physical workgroup p runs on XCD p & 7; the logical workgroups are dealt out so that
-// every XCD takes one contiguous run of them (all the buckets of a block on one XCD: the block's text stays in one L2)
-__device__ __forceinline__ void xcd_order(uint32_t &bx, uint32_t &by)
-{
-    const uint32_t nx = gridDim.x, total = nx * gridDim.y, p = blockIdx.y * nx + blockIdx.x;
-    const uint32_t q = total >> 3, r = total & 7u, x = p & 7u;
-    const uint32_t lg = x * q + min(x, r) + (p >> 3);
-    by = lg / nx; bx = lg % nx;
 }
 
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;

@@ -111,4 +111,15 @@ __device__ __forceinline__ uint32_t block_excl_max(uint32_t x, uint32_t *s_tmp)
     return base > prev ? base : prev;
 }
 
+// XCD-aware order of a (x, y) grid: physical workgroup p runs on XCD p & 7; the logical workgroups are dealt out so that
+// every XCD takes one contiguous run of them (everything of a block on one XCD: what its workgroups share stays in one L2)
+__device__ __forceinline__ void xcd_order(uint32_t &bx, uint32_t &by)
+{
+    const uint32_t nx = gridDim.x, total = nx * gridDim.y, p = blockIdx.y * nx + blockIdx.x;
+    const uint32_t q = total >> 3, r = total & 7u, x = p & 7u;
+    const uint32_t lg = x * q + min(x, r) + (p >> 3);
+    by = lg / nx; bx = lg % nx;
+}
+
+
 } // namespace glc
