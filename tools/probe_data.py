@@ -11,7 +11,7 @@ glc = bench._load("glc_binding", os.path.join(ROOT, "gpu-lossless-compression_am
 sorter = int(os.environ.get("GLC_SORTER", "0"))
 classes = sys.argv[1:] or ["zipf", "float", "text", "log"]
 dev = torch.device("cuda:0")
-n, rows, distinct = 1 << 20, 256, 8
+n, rows, distinct = 1 << 20, int(os.environ.get("GLC_ROWS", "256")), 8
 gen = {"zipf": datagen.zipf_bytes, "float": datagen.float_bytes, "text": datagen.text_bytes, "log": datagen.log_bytes}
 with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
     plan.set_sorter(sorter)
@@ -27,6 +27,6 @@ with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan
             glc.compress_batch_into(plan, d_in, n, rows, out)
             plan.synchronize(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
         ms = min(ts[1:])
-        print("%-6s %8.3f ms per 256 MiB = %6.1f GB/s   blocks on the general sorter: %d" % (name, ms, n * rows / ms / 1e6, plan.last_flagged_blocks()) + "  sample tier gave up on: %d" % plan.last_sort_stats()[1])
+        print("%-6s %8.3f ms per batch = %6.1f GB/s   blocks on the general sorter: %d" % (name, ms, n * rows / ms / 1e6, plan.last_flagged_blocks()) + "  sample tier gave up on: %d" % plan.last_sort_stats()[1])
         prof = plan.kernel_profiles()
         print("       " + ", ".join("%s %.2f" % (k.replace("glc::", ""), v["ms"] / 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:24]))
