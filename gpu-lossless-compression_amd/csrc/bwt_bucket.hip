@@ -526,12 +526,14 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
                                                  uint8_t *__restrict__ bwt_out, size_t bwt_stride,
                                                  int *__restrict__ d_index, uint32_t *__restrict__ sa_out, size_t sa_stride)
 {
-    const uint32_t b = blockIdx.y;
+    uint32_t gx, gy;
+    xcd_order(gx, gy);                                         // a block's text in one L2 for the comparisons
+    const uint32_t b = gy;
     const uint32_t total = wl_count[b];
     if (total == 0 || total > wl_cap || flag[b]) return;       // (flags of this pass are all set before it starts)
     const uint4 *WL = wl + (size_t)b * wl_cap;
     const uint8_t *T = text + (size_t)b * stride;
-    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    for (uint32_t e = gx * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const uint4 me = WL[e];
         const uint32_t gs = me.w, idx = me.x >> 8;
         uint32_t rank = 0;
