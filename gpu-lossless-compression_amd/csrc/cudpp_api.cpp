@@ -285,32 +285,32 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     p->sa.parity = k;
     e = sa_build_begin(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
     tm.mark(1);
-    auto after_sort = [&](const uint32_t *redo_flag) {
+    auto after_sort = [&](const uint32_t *redo_flag, const uint32_t *only) {
         if (p->pipelined) {
             (void)hipEventRecord(p->ev_sorted[k], st);
             (void)hipStreamWaitEvent(s2, p->ev_sorted[k], 0);
             if (p->timing) (void)hipEventRecord(p->ev_s2, s2);
         }
-        if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist);
+        if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist, only);
         if (p->timing) (void)hipEventRecord(p->ev[2], s2);
         if (e == hipSuccess) e = huff_build(s2, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
-                                            compressedStrideWords, p->d_status, redo_flag);
+                                            compressedStrideWords, p->d_status, redo_flag, only);
         if (e == hipSuccess) e = huff_pack(s2, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
-                                           d_compressed, compressedStrideWords);
+                                           d_compressed, compressedStrideWords, only);
         if (p->timing) (void)hipEventRecord(p->ev[3], s2);
     };
     // ... unless most blocks of the plan's previous call were flagged (text-like input tends to stay text-like): then
     // the speculative pass would be thrown away, and the stages are queued once, after the sort is final.
     const bool tiers = p->sa.sorter == 0 || p->sa.sorter == 3 || p->sa.sorter == 4;
     const bool speculate = !tiers || (!p->sa.expect_flagged && p->sa.sorter != 4);
-    if (speculate) after_sort(tiers ? p->sa.fs_redo[k] : nullptr);   // blocks flagged by the bucket sorter are encoded again below
+    if (speculate) after_sort(tiers ? p->sa.fs_redo[k] : nullptr, nullptr);   // blocks flagged by the bucket sorter are encoded again below
     uint32_t nflag = 0;
     if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
     if (e == hipSuccess && (nflag || !speculate)) {
         // sa_build_finish has queued the other sorters for the flagged blocks on st.  Under pipelining the
         // speculative MTF on s2 may still be reading `bwt` while it is rewritten: harmless, everything that pass
         // wrote is written again by the pass below, which is ordered after the last sort (ev_sorted).
-        after_sort(nullptr);
+        after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr);   // after a speculative pass: only the flagged blocks
     }
     tm.done();
     if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], s2); p->released_valid[k] = true; p->side_busy = true; }

@@ -174,7 +174,9 @@ void       mtf_scratch_free(MtfScratch &s);
 // out = MTF(in) per block; if sub_hist != nullptr also writes the histogram of
 // each 4096-symbol chunk of the output: sub_hist[b][chunk][256].
 hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint32_t n, uint32_t nblk,
-                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist);
+                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist, const uint32_t *only = nullptr);
+// (`only`, here and in the Huffman stages: if given, blocks whose entry is 0 are skipped -- the second pass over the
+//  blocks a later sorter tier rewrote)
 
 // ---------------------------------------------------------------------------
 // Huffman
@@ -197,11 +199,12 @@ hipError_t huff_histogram(hipStream_t st, const uint8_t *sym, size_t stride, uin
 // flagged): their status bits are not raised.
 hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
                       uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size,
-                      size_t capacity_words, uint32_t *d_status, const uint32_t *redo_flag = nullptr);
+                      size_t capacity_words, uint32_t *d_status, const uint32_t *redo_flag = nullptr,
+                      const uint32_t *only = nullptr);
 // pack (reads mtf bytes, writes the stream)
 hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
                      HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride,
-                     uint32_t *d_compressed, size_t comp_stride_words);
+                     uint32_t *d_compressed, size_t comp_stride_words, const uint32_t *only = nullptr);
 
 hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride, const uint32_t *d_sizes,
                            uint32_t nblk, uint32_t *d_out, unsigned long long *d_off);

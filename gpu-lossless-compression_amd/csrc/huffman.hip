@@ -41,7 +41,8 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
                                                     uint32_t *__restrict__ d_offsets, size_t offset_stride,
                                                     uint32_t *__restrict__ d_size, uint64_t capacity_words,
                                                     uint32_t *__restrict__ d_status,
-                                                    const uint32_t *__restrict__ redo_flag)
+                                                    const uint32_t *__restrict__ redo_flag,
+                                                    const uint32_t *__restrict__ only)
 {
     __shared__ uint32_t s_hist[257];
     __shared__ uint32_t s_part[4][256];
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
     __shared__ uint32_t s_tmp[HB_NT / 64 + 1];
 
     const uint32_t b = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+    if (only && !only[b]) return;                              // (second pass over the blocks a later sorter tier rewrote)
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const uint32_t *SH = sub_hist + (size_t)b * max_sub * 256;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
                                                    const uint32_t *__restrict__ lens,
                                                    const uint32_t *__restrict__ d_offsets, size_t offset_stride,
                                                    uint32_t *__restrict__ d_comp, size_t comp_stride,
-                                                   uint64_t capacity_words)
+                                                   uint64_t capacity_words, const uint32_t *__restrict__ only)
 {
     constexpr int SPT = HUFF_BLOCK / 256;                     // 16 symbols per thread
     constexpr int MAXW = HUFF_BLOCK * 28 / 32 + 16;            // code length <= 28 for <= 2^20+1 total count
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
     __shared__ uint32_t s_words[MAXW];
     __shared__ uint32_t s_tmp[8];
     const uint32_t b = blockIdx.y, sub = blockIdx.x, tid = threadIdx.x;
+    if (only && !only[b]) return;
     const uint32_t lo = sub * HUFF_BLOCK;
     if (lo >= n) return;
     const uint32_t cntb = min((uint32_t)HUFF_BLOCK, n - lo);
@@ -333,24 +336,24 @@ hipError_t huff_histogram(hipStream_t st, const uint8_t *sym, size_t stride, uin
 
 hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s, uint32_t *d_hist,
                       uint32_t *d_offsets, size_t offset_stride, uint32_t *d_size, size_t capacity_words,
-                      uint32_t *d_status, const uint32_t *redo_flag)
+                      uint32_t *d_status, const uint32_t *redo_flag, const uint32_t *only)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const int pi = s.prof ? s.prof->begin(PROF_HUFF_BUILD, st) : -1;
     hipLaunchKernelGGL(k_huff_build, dim3(nblk), dim3(HB_NT), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
-                       s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status, redo_flag);
+                       s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status, redo_flag, only);
     if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
 }
 
 hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
                      HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride, uint32_t *d_compressed,
-                     size_t comp_stride_words)
+                     size_t comp_stride_words, const uint32_t *only)
 {
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const int pi = s.prof ? s.prof->begin(PROF_HUFF_PACK, st) : -1;
     hipLaunchKernelGGL(k_huff_pack, dim3(nsub, nblk), dim3(256), 0, st, mtf, mtf_stride, n, s.codes, s.lens,
-                       d_offsets, offset_stride, d_compressed, comp_stride_words, (uint64_t)comp_stride_words);
+                       d_offsets, offset_stride, d_compressed, comp_stride_words, (uint64_t)comp_stride_words, only);
     if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
 }

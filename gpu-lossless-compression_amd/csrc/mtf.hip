@@ -36,12 +36,13 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_chunk_lists(const uint8_
                                                                    size_t in_stride, uint32_t n,
                                                                    uint8_t *__restrict__ lists,
                                                                    uint16_t *__restrict__ lens,
-                                                                   uint32_t max_chunks)
+                                                                   uint32_t max_chunks, const uint32_t *__restrict__ only)
 {
     __shared__ uint32_t s_first[MTF_WAVES][256];
     __shared__ unsigned long long s_bm[MTF_WAVES][64];
     __shared__ uint32_t s_cum[MTF_WAVES][64];
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63;
+    if (only && !only[b]) return;                              // (second pass over the blocks a later sorter tier rewrote)
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const uint32_t chunk = blockIdx.x * MTF_WAVES + w;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
@@ -133,7 +134,7 @@ __device__ __forceinline__ uint32_t mtf_fold(const uint8_t *cur, uint8_t *next, 
 
 __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__restrict__ lists,
                                                                   const uint16_t *__restrict__ lens, uint32_t n,
-                                                                  uint32_t max_chunks)
+                                                                  uint32_t max_chunks, const uint32_t *__restrict__ only)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_state[MSC_WAVES][2][256];
     __shared__ __attribute__((aligned(16))) uint8_t s_inp[MSC_WAVES][256];
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__re
     __shared__ __attribute__((aligned(16))) uint8_t s_start[MSC_WAVES][256];     // state at the start of every group
     __shared__ __attribute__((aligned(16))) uint8_t s_carry[256];                // state at the start of the round
     const uint32_t b = blockIdx.x, l = threadIdx.x & 63;
+    if (only && !only[b]) return;
     const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
     uint8_t *LB = lists + (size_t)b * max_chunks * 256;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
                                                               const uint8_t *__restrict__ lists,
                                                               uint32_t max_chunks,
                                                               uint8_t *__restrict__ out, size_t out_stride,
-                                                              uint32_t *__restrict__ sub_hist)
+                                                              uint32_t *__restrict__ sub_hist, const uint32_t *__restrict__ only)
 {
     // slot strides are padded so that the four rows of a wave, which run in lockstep and favour the same symbols, ranks and
     // bitmap words, do not meet in the same LDS banks
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
     // ten bytes apart they were an unaligned 8-byte store, which alone cost a quarter of the kernel)
     __shared__ __attribute__((aligned(16))) uint16_t s_cum[MTF_WAVES * MTF_ROWS][16 * 8 + 16];
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63, lr = l & 15, row = l >> 4;
+    if (only && !only[b]) return;
     const uint32_t w = threadIdx.x >> 6, slot = w * MTF_ROWS + row;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
     const uint32_t chunk0 = (blockIdx.x * MTF_WAVES + w) * MTF_ROWS;       // first chunk of this wave
@@ -362,7 +365,7 @@ void mtf_scratch_free(MtfScratch &s)
 }
 
 hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint32_t n, uint32_t nblk,
-                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist)
+                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist, const uint32_t *only)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
@@ -370,16 +373,16 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
     dim3 ge((nchunks + MTF_WAVES * MTF_ROWS - 1) / (MTF_WAVES * MTF_ROWS), nblk);      // encode: 4 chunks per wave
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_MTF_LISTS, st) : -1;
-    hipLaunchKernelGGL(k_mtf_chunk_lists, g, t, 0, st, in, in_stride, n, s.lists, s.lens, s.max_chunks);
-    hipLaunchKernelGGL(k_mtf_scan_lists, dim3(nblk), dim3(MSC_WAVES * 64), 0, st, s.lists, s.lens, n, s.max_chunks);
+    hipLaunchKernelGGL(k_mtf_chunk_lists, g, t, 0, st, in, in_stride, n, s.lists, s.lens, s.max_chunks, only);
+    hipLaunchKernelGGL(k_mtf_scan_lists, dim3(nblk), dim3(MSC_WAVES * 64), 0, st, s.lists, s.lens, n, s.max_chunks, only);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_MTF_ENCODE, st) : -1;
     if (sub_hist)
         hipLaunchKernelGGL(k_mtf_encode<true>, ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
-                           out_stride, sub_hist);
+                           out_stride, sub_hist, only);
     else
         hipLaunchKernelGGL(k_mtf_encode<false>, ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
-                           out_stride, sub_hist);
+                           out_stride, sub_hist, only);
     if (pi >= 0) s.prof->end(pi, units, st);
     return hipGetLastError();
 }
