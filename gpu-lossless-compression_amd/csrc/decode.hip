@@ -201,6 +201,103 @@ __global__ __launch_bounds__(DH_WAVES * 64) void k_dec_huff(const uint32_t *__re
 }
 
 // ---------------------------------------------------------------------------
+// 2b. Huffman decode for large batches: one LANE per 4096-symbol block, the way the CPU gold walks a stream, 256 of
+//     them per workgroup (= a 1 MiB block).  With >= 128 blocks in a call there are enough 4096-symbol blocks to fill
+//     the machine with such lanes (1024 blocks: 4 waves per SIMD), and a lane decodes every symbol ONCE -- the
+//     wave-per-block kernel above decodes every span three to four times to find where its codes start.
+//     Each lane's words come through a 32-word ring in LDS, refilled 16 words (64 contiguous bytes) at a time, so a
+//     cache line is fetched twice, not once per word; symbols leave as 16-byte stores.
+// ---------------------------------------------------------------------------
+constexpr uint32_t DL_NT = 256, DL_RING = 32, DL_PITCH = DL_RING + 1;
+constexpr uint64_t DL_MIN_SUBS = 32768;                      // 4096-symbol blocks in a call from which the lane kernel is used
+
+__global__ __launch_bounds__(DL_NT) void k_dec_huff_lanes(const uint32_t *__restrict__ comp, size_t comp_stride,
+                                                          const uint32_t *__restrict__ offsets, size_t offset_stride,
+                                                          const uint32_t *__restrict__ lut,
+                                                          const uint32_t *__restrict__ nodes, uint32_t n,
+                                                          uint8_t *__restrict__ mtf, size_t mtf_stride,
+                                                          uint32_t *__restrict__ d_status)
+{
+    __shared__ uint16_t s_lut[1 << DEC_LUT_BITS];
+    __shared__ uint32_t s_nodes[HUFF_NODES];
+    __shared__ uint32_t s_ring[DL_NT * DL_PITCH];
+    const uint32_t b = blockIdx.y, tid = threadIdx.x;
+    for (uint32_t i = tid; i < (1u << DEC_LUT_BITS); i += DL_NT) {
+        const uint32_t e = lut[((size_t)b << DEC_LUT_BITS) + i];
+        s_lut[i] = (e & DEC_FLAG) ? (uint16_t)(0x8000u | (e & 0x3FFu)) : (uint16_t)((e & 0x3FFu) | ((e >> 16) << 10));
+    }
+    for (uint32_t i = tid; i < HUFF_NODES; i += DL_NT) s_nodes[i] = nodes[(size_t)b * HUFF_NODES + i];
+    __syncthreads();
+    const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
+    const uint32_t sub = blockIdx.x * DL_NT + tid;
+    if (sub >= nsub) return;
+    const uint32_t lo = sub * HUFF_BLOCK, cnt = min((uint32_t)HUFF_BLOCK, n - lo);
+    // offsets and lengths come from the stream: stay inside the block's slot whatever they say
+    uint32_t off = offsets[(size_t)b * offset_stride + sub];
+    if ((size_t)off + 1 > comp_stride) { off = 0; if (d_status) atomicOr(d_status, ST_CORRUPT); }
+    const uint32_t *w = comp + (size_t)b * comp_stride + off;
+    uint32_t nwords = w[0];
+    if (nwords > HUFF_MAX_WORDS || (size_t)off + 1 + nwords > comp_stride) {
+        nwords = (uint32_t)min((size_t)min(nwords, (uint32_t)HUFF_MAX_WORDS), comp_stride - off - 1);
+        if (d_status) atomicOr(d_status, ST_CORRUPT);
+    }
+    w++;
+    uint32_t *ring = s_ring + tid * DL_PITCH;
+    uint32_t wi = 0, rd = 0, have = 0;                          // next word to fetch / ring read position / words in the ring
+    auto refill = [&]() {                                       // 16 more words behind the ones in the ring
+        const uint32_t at = (rd + have) & (DL_RING - 1);        // (0 or 16: refills come in halves of the ring)
+        if (wi + 16 <= nwords) {
+            uint4 q[4];                                         // four 16-byte loads at a 4-byte-aligned address
+#pragma unroll
+            for (int k = 0; k < 4; k++) __builtin_memcpy(&q[k], w + wi + 4 * k, 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ring[(at + 4 * k + 0) & (DL_RING - 1)] = q[k].x; ring[(at + 4 * k + 1) & (DL_RING - 1)] = q[k].y;
+                ring[(at + 4 * k + 2) & (DL_RING - 1)] = q[k].z; ring[(at + 4 * k + 3) & (DL_RING - 1)] = q[k].w;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) ring[(at + k) & (DL_RING - 1)] = wi + k < nwords ? w[wi + k] : 0u;
+        }
+        wi += 16; have += 16;
+    };
+    refill();
+    refill();
+    auto next_word = [&]() -> uint32_t { const uint32_t x = ring[rd]; rd = (rd + 1) & (DL_RING - 1); have--; return x; };
+    uint64_t buf = (uint64_t)next_word() << 32;
+    buf |= next_word();
+    uint32_t nb = 64;
+    uint8_t *dst = mtf + (size_t)b * mtf_stride + lo;
+    const bool vec = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 16) {
+        if (have <= 16) refill();                               // 16 symbols take at most 14 words (codes <= 28 bits)
+        uint32_t o4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            if (nb <= 32) { buf |= (uint64_t)next_word() << (32 - nb); nb += 32; }
+            const uint32_t e = s_lut[(uint32_t)(buf >> (64 - DEC_LUT_BITS))];
+            uint32_t len, sym;
+            if (!(e & 0x8000u)) { sym = e & 0x3FFu; len = e >> 10; }
+            else {
+                uint32_t ne = s_nodes[e & 0x3FFu];
+                len = DEC_LUT_BITS;
+                while (!(ne & DEC_FLAG) && len < 33) {
+                    const uint32_t bit = (uint32_t)(buf >> (63 - len)) & 1u;
+                    ne = s_nodes[bit ? (ne >> 16) : (ne & 0xFFFF)];
+                    len++;
+                }
+                sym = ne & 0xFFFF;
+            }
+            len = len ? len : 1u;
+            o4[j >> 2] |= (sym & 0xFFu) << (8 * (j & 3));
+            buf <<= len; nb -= len;
+        }
+        if (vec && i0 + 16 <= cnt) *reinterpret_cast<uint4 *>(dst + i0) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+        else for (uint32_t j = 0; j < 16 && i0 + j < cnt; j++) dst[i0 + j] = (uint8_t)(o4[j >> 2] >> (8 * (j & 3)));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 3. inverse MTF
 // ---------------------------------------------------------------------------
 
@@ -675,8 +772,12 @@ hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
     hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes);
-    hipLaunchKernelGGL(k_dec_huff, dim3((nsub + DH_WAVES - 1) / DH_WAVES, nblk), dim3(DH_WAVES * 64), 0, st, d_comp, comp_stride_words,
-                       d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
+    if ((uint64_t)nsub * nblk >= DL_MIN_SUBS)
+        hipLaunchKernelGGL(k_dec_huff_lanes, dim3((nsub + DL_NT - 1) / DL_NT, nblk), dim3(DL_NT), 0, st, d_comp, comp_stride_words,
+                           d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
+    else
+        hipLaunchKernelGGL(k_dec_huff, dim3((nsub + DH_WAVES - 1) / DH_WAVES, nblk), dim3(DH_WAVES * 64), 0, st, d_comp, comp_stride_words,
+                           d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
     hipLaunchKernelGGL(k_imtf_pos, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
                        s.max_chunks, bwt, (size_t)s.nmax);
     hipLaunchKernelGGL(k_imtf_scan, dim3(nblk), dim3(64), 0, st, s.ilists, n, s.max_chunks);
