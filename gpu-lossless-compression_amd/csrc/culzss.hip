@@ -23,9 +23,69 @@
 namespace glc {
 
 // ---------------------------------------------------------------------------
+// The 127 steps of one position's window scan, written out by hand.
+//   st = window index where the current run of equal bytes started, R = A0 - st with A0 = LDS address of la[0]:
+//   step k reads la[k - st] at R + k (k is the instruction's immediate offset), and only a MISMATCH changes R
+//   (st = k + 1), which v_cmpx + one subtraction under the narrowed EXEC do: no select, no address arithmetic.
+//   After step k the run length is j = k + 1 - st, so (R << 16) + ((k + 1) << 16 | 0xFFFF - k) orders records by
+//   (A0 + j, earlier k first); the records of two steps go into one v_max3.  3.5 VALU operations + one LDS byte
+//   read per step.  (Left to the compiler the loop became ~10 VALU per step: the 127 compare masks were computed
+//   up front and parked in VGPR lanes with v_writelane / v_readlane.)
+// ---------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void lz_scan(const uint32_t (&W)[32], uint32_t A0, uint32_t &R, uint32_t &best, uint32_t &c1,
+                                        uint32_t &c2, uint64_t ex)
+{
+    if constexpr (K < 127) {
+        uint32_t lb, C;
+        if constexpr (K == 0) {
+            asm volatile("ds_read_u8 %[lb], %[R]\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "v_cmpx_ne_u16_sdwa vcc, %[lb], %[w] src0_sel:DWORD src1_sel:BYTE_0\n"
+                         "v_subrev_u32_e32 %[R], 1, %[A0]\n"
+                         "s_mov_b64 exec, %[ex]\n"
+                         : [R] "+v"(R), [lb] "=&v"(lb) : [w] "v"(W[0]), [A0] "v"(A0), [ex] "s"(ex) : "vcc");
+        } else if constexpr ((K & 1) == 1) {                  // record of step K - 1 (even) -> c1
+            asm volatile("ds_read_u8 %[lb], %[R] offset:%[k]\n"
+                         "s_mov_b32 %[C], %[ck]\n"
+                         "v_lshl_add_u32 %[c1], %[R], 16, %[C]\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "v_cmpx_ne_u16_sdwa vcc, %[lb], %[w] src0_sel:DWORD src1_sel:BYTE_%[b]\n"
+                         "v_subrev_u32_e32 %[R], %[k1], %[A0]\n"
+                         "s_mov_b64 exec, %[ex]\n"
+                         : [R] "+v"(R), [c1] "=&v"(c1), [lb] "=&v"(lb), [C] "=&s"(C)
+                         : [w] "v"(W[K >> 2]), [A0] "v"(A0), [ex] "s"(ex), [k] "n"(K), [k1] "n"(K + 1), [b] "n"(K & 3),
+                           [ck] "n"((K << 16) | (0xFFFF - (K - 1)))
+                         : "vcc");
+        } else {                                               // record of step K - 1 (odd) -> c2, both into best
+            asm volatile("ds_read_u8 %[lb], %[R] offset:%[k]\n"
+                         "s_mov_b32 %[C], %[ck]\n"
+                         "v_lshl_add_u32 %[c2], %[R], 16, %[C]\n"
+                         "v_max3_u32 %[best], %[best], %[c1], %[c2]\n"
+                         "s_waitcnt lgkmcnt(0)\n"
+                         "v_cmpx_ne_u16_sdwa vcc, %[lb], %[w] src0_sel:DWORD src1_sel:BYTE_%[b]\n"
+                         "v_subrev_u32_e32 %[R], %[k1], %[A0]\n"
+                         "s_mov_b64 exec, %[ex]\n"
+                         : [R] "+v"(R), [best] "+v"(best), [c2] "=&v"(c2), [lb] "=&v"(lb), [C] "=&s"(C)
+                         : [w] "v"(W[K >> 2]), [A0] "v"(A0), [ex] "s"(ex), [c1] "v"(c1), [k] "n"(K), [k1] "n"(K + 1),
+                           [b] "n"(K & 3), [ck] "n"((K << 16) | (0xFFFF - (K - 1)))
+                         : "vcc");
+        }
+        lz_scan<K + 1>(W, A0, R, best, c1, c2, ex);
+    } else {                                                   // record of step 126 (even)
+        uint32_t C;
+        asm volatile("s_mov_b32 %[C], %[ck]\n"
+                     "v_lshl_add_u32 %[c1], %[R], 16, %[C]\n"
+                     "v_max_u32_e32 %[best], %[best], %[c1]\n"
+                     : [best] "+v"(best), [c1] "=&v"(c1), [C] "=&s"(C)
+                     : [R] "v"(R), [ck] "n"((127 << 16) | (0xFFFF - 126)));
+    }
+}
+
+// ---------------------------------------------------------------------------
 // match search: one workgroup (256 threads) per packet, 16 positions / thread
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 6) void k_lzss_match(const uint8_t *__restrict__ in, uint8_t *__restrict__ cand)
+__global__ __launch_bounds__(256, 8) void k_lzss_match(const uint8_t *__restrict__ in, uint8_t *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[LZ_WIN + LZ_PCKT];
     const uint32_t pk = blockIdx.x, tid = threadIdx.x;
@@ -51,7 +111,7 @@ __global__ __launch_bounds__(256, 6) void k_lzss_match(const uint8_t *__restrict
             // mismatch.  Recording (j, st) at every step through max((j << 16) | ~st) is the same thing:
             // a run's last record dominates its earlier ones, longer beats shorter, earlier start beats
             // later on ties.  The 127 window bytes text[p-128 .. p-2] sit in 32 register dwords (aligned
-            // LDS dword reads funnelled by p & 3), so a step is one LDS byte read + ~6 VALU.
+            // LDS dword reads funnelled by p & 3).
             uint32_t W[32];
             {
                 const uint32_t *wa = reinterpret_cast<const uint32_t *>(s_buf + (p & ~3));
@@ -64,17 +124,12 @@ __global__ __launch_bounds__(256, 6) void k_lzss_match(const uint8_t *__restrict
                     prev = nxt;
                 }
             }
-            // state = (j << 16) | (0xFFFF - st): +0x10000 on a match, a per-step constant on a mismatch
-            uint32_t state = 0xFFFFu, best = 0, addr = (uint32_t)p;
-#pragma unroll
-            for (int k = 0; k < 127; k++) {
-                const uint32_t wb = (W[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                const bool eq = wb == (uint32_t)s_buf[LZ_WIN + addr];
-                addr = eq ? addr + 1 : (uint32_t)p;
-                state = eq ? state + 0x10000u : (0xFFFFu - (uint32_t)(k + 1));
-                best = best > state ? best : state;
-            }
-            if ((best >> 16) >= 2) { length = (int)(best >> 16); offset = (p + (int)(0xFFFFu - (best & 0xFFFFu))) & 255; }
+            // The scan itself, one window byte per step (lz_scan above).
+            const uint32_t A0 = (uint32_t)(uintptr_t)(s_buf + LZ_WIN + p);      // low half of the flat address = LDS offset
+            uint32_t R = A0, best = 0, c1 = 0, c2 = 0;
+            lz_scan<0>(W, A0, R, best, c1, c2, __builtin_amdgcn_ballot_w64(true));
+            const int j = (int)(best >> 16) - (int)A0;
+            if (j >= 2) { length = j; offset = (p + (int)(0xFFFFu - (best & 0xFFFFu)) + 1 - j) & 255; }
         } else {
             // last 128-byte chunk: shortened scan, look-ahead wrapping into the stale ring half
             const int iters = max(1, 127 - tx);

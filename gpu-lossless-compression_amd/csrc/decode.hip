@@ -36,9 +36,15 @@ constexpr int      DEC_LUT_BITS = 12;
 constexpr uint32_t DEC_FLAG     = 0x80000000u;
 constexpr int      LF_TILE      = 2048;
 constexpr uint32_t LF_MASK      = (1u << 21) - 1;
-constexpr uint32_t SPLIT        = 128;                   // LF-cycle rows between splitters
+#ifndef GLC_SPLIT
+#define GLC_SPLIT 128
+#endif
+constexpr uint32_t SPLIT        = GLC_SPLIT;                   // LF-cycle rows between splitters
 constexpr uint32_t MAX_SPLITS   = (1u << 20) / SPLIT + 8;
-constexpr uint32_t SLOT         = 256;                   // bytes a walk emits before it continues in a new segment
+#ifndef GLC_SLOT
+#define GLC_SLOT 256
+#endif
+constexpr uint32_t SLOT         = GLC_SLOT;                   // bytes a walk emits before it continues in a new segment
 constexpr uint32_t EMIT_SEGS    = 4;                     // segments per wave in k_ibwt_emit
 
 // ---------------------------------------------------------------------------
@@ -642,20 +648,22 @@ __global__ void k_ibwt_seg_init(uint32_t *__restrict__ seg_count, uint32_t n, ui
 constexpr uint32_t MAX_SEG  = MAX_SPLITS + ((1u << 20) + 1) / SLOT + 8;
 constexpr uint32_t RANK_NT  = 1024;
 constexpr uint32_t RANK_E   = (MAX_SEG + RANK_NT - 1) / RANK_NT;
-constexpr uint32_t SEG_NIL  = 0xFFFFFFFFu;
+constexpr uint32_t SEG_NIL  = 0xFFFFu;
+static_assert(MAX_SEG < SEG_NIL, "segment ids are kept as 16 bits in k_ibwt_rank");
 
 __global__ __launch_bounds__(RANK_NT) void k_ibwt_rank(const uint32_t *__restrict__ seg_info, uint32_t max_seg,
                                                        const uint32_t *__restrict__ seg_count,
                                                        int *__restrict__ seg_pos)
 {
-    __shared__ uint32_t s_d[MAX_SEG], s_nx[MAX_SEG];
+    __shared__ uint32_t s_d[MAX_SEG];
+    __shared__ uint16_t s_nx[MAX_SEG];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t nseg = min(seg_count[b], min(max_seg, MAX_SEG));
     const uint32_t *SI = seg_info + (size_t)b * max_seg;
     for (uint32_t i = tid; i < nseg; i += RANK_NT) {
         const uint32_t v = SI[i], nx = v >> 9;
         s_d[i] = v & 511u;
-        s_nx[i] = (nx == 0 || nx >= nseg) ? SEG_NIL : nx;
+        s_nx[i] = (uint16_t)((nx == 0 || nx >= nseg) ? SEG_NIL : nx);
     }
     __syncthreads();
     uint32_t nd[RANK_E], nn[RANK_E];
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(RANK_NT) void k_ibwt_rank(const uint32_t *__restric
 #pragma unroll
         for (uint32_t e = 0; e < RANK_E; e++) {
             const uint32_t i = tid + e * RANK_NT;
-            if (i < nseg) { s_d[i] = nd[e]; s_nx[i] = nn[e]; }
+            if (i < nseg) { s_d[i] = nd[e]; s_nx[i] = (uint16_t)nn[e]; }
         }
         __syncthreads();
     }
