@@ -177,11 +177,11 @@ __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ c
     __syncthreads();
     // The greedy walk p -> p + len(p) from 0 (gpu_compress.cu:498-515) without a serial chain:
     // positions reachable in fewer than 2^r steps are marked round by round while the jump table is
-    // squared (J <- J o J), 12 rounds for 4096 positions; the marked positions, compacted in order,
+    // squared (J <- J o J), at most 12 rounds for 4096 positions; the marked positions, compacted in order,
     // are the tokens.  (One lane walking ~1500 dependent LDS reads held the other 255 idle.)
     {
         __shared__ uint16_t s_j1[LZ_PCKT];
-        __shared__ uint32_t mark[LZ_PCKT / 32];
+        __shared__ __attribute__((aligned(16))) uint8_t mark[LZ_PCKT];   // one byte per position: plain stores, no atomics
         uint16_t *J0 = s_tok, *J1 = s_j1;                     // s_tok is free until the tokens are compacted
 #pragma unroll
         for (int r = 0; r < LZ_PCKT / 256; r++) {
@@ -190,25 +190,34 @@ __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ c
             const uint32_t nx = p + ((c0 <= 1) ? 1u : c0);
             J0[p] = (uint16_t)(nx < LZ_PCKT ? nx : LZ_PCKT);
         }
-        if (tid < LZ_PCKT / 32) mark[tid] = (tid == 0) ? 1u : 0u;
+        reinterpret_cast<uint4 *>(mark)[tid] = make_uint4(tid == 0 ? 1u : 0u, 0u, 0u, 0u);
         __syncthreads();
         uint16_t *J = J0, *Jn = J1;
-        for (int round = 0; round < 12; round++) {
+#ifndef GLC_EXP_ROUNDS
+#define GLC_EXP_ROUNDS 12
+#endif
+        for (int round = 0; round < GLC_EXP_ROUNDS; round++) {
             uint32_t jn[LZ_PCKT / 256];
 #pragma unroll
             for (int r = 0; r < LZ_PCKT / 256; r++) {
                 const uint32_t p = r * 256 + tid;
                 const uint32_t a = J[p];
-                if (((mark[p >> 5] >> (p & 31)) & 1u) && a < LZ_PCKT) atomicOr(&mark[a >> 5], 1u << (a & 31));
+                if (mark[p] && a < LZ_PCKT) mark[a] = 1;
                 jn[r] = a < LZ_PCKT ? (uint32_t)J[a] : (uint32_t)LZ_PCKT;
             }
 #pragma unroll
             for (int r = 0; r < LZ_PCKT / 256; r++) Jn[r * 256 + tid] = (uint16_t)jn[r];
             __syncthreads();
             uint16_t *x = J; J = Jn; Jn = x;
+            if (J[0] >= LZ_PCKT) break;                       // the walk from 0 ends within 2^(round+1) steps: all marked
         }
         // compact: thread t owns positions [16t, 16t+16)
-        const uint32_t mw = (mark[tid >> 1] >> (16 * (tid & 1))) & 0xFFFFu;
+        uint32_t mw;
+        {
+            const uint4 m4 = reinterpret_cast<const uint4 *>(mark)[tid];                    // 16 flag bytes -> 16 bits
+            mw = ((m4.x * 0x01020408u) >> 24) | (((m4.y * 0x01020408u) >> 24) << 4) |
+                 (((m4.z * 0x01020408u) >> 24) << 8) | (((m4.w * 0x01020408u) >> 24) << 12);
+        }
         uint32_t tot = 0;
         const uint32_t pre = block_excl_add<256>((uint32_t)__popc(mw), s_tmp, &tot);
         __syncthreads();                                      // everyone has read J / marks: s_tok is reused
