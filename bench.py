@@ -291,7 +291,7 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
             "hbm_frac": {"encode": round((1 + rho) * total / ms_enc / 1e6 / HBM_PEAK_GBPS, 5),
                          "decode": round((1 + rho) * total / ms_dec / 1e6 / HBM_PEAK_GBPS, 5),
                          "algorithmic_bytes": "1 R + rho W (encode), rho R + 1 W (decode) per input byte",
-                         "bound": "VALU: k_lzss_match does 127 window compares per input byte (6 VALU each); see DESIGN.md"},
+                         "bound": "VALU: k_lzss_match does 127 window compares per input byte (3.5 VALU each, hand-written); see DESIGN.md"},
             "roundtrip": "decode(encode(x)) == x on all %d buffers" % nbuf,
             "parity": "%d/%d sampled buffers byte-exact vs oracle" % (ok, len(pick)),
             "cpu_port": {"value": round(MiB / cpu_s / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ c
                                                    uint2 *__restrict__ meta)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_c[2 * LZ_PCKT];
-    __shared__ uint16_t s_tok[LZ_PCKT];
+    __shared__ __attribute__((aligned(16))) uint16_t s_tok[LZ_PCKT];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_STAGE];
     __shared__ uint32_t s_tmp[8];
     __shared__ uint32_t s_ntok;
@@ -178,9 +178,12 @@ __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ c
     // The greedy walk p -> p + len(p) from 0 (gpu_compress.cu:498-515) without a serial chain:
     // positions reachable in fewer than 2^r steps are marked round by round while the jump table is
     // squared (J <- J o J), at most 12 rounds for 4096 positions; the marked positions, compacted in order,
-    // are the tokens.  (One lane walking ~1500 dependent LDS reads held the other 255 idle.)
+    // are the tokens.  (One lane walking ~1500 dependent LDS reads held the other 255 idle.  Also measured: one WAVE
+    // per packet walking on the scalar unit -- candidates in 64 VGPRs, a step = v_readlane + 5 SALU + the token's
+    // store -- with no barrier anywhere: ~115 cycles per token, 7.8 ms per GiB against 6.1 ms for the rounds below,
+    // because 129 VGPRs and 12.6 KB of LDS per packet leave only 12 such chains per CU.)
     {
-        __shared__ uint16_t s_j1[LZ_PCKT];
+        __shared__ __attribute__((aligned(16))) uint16_t s_j1[LZ_PCKT];
         __shared__ __attribute__((aligned(16))) uint8_t mark[LZ_PCKT];   // one byte per position: plain stores, no atomics
         uint16_t *J0 = s_tok, *J1 = s_j1;                     // s_tok is free until the tokens are compacted
 #pragma unroll
@@ -193,20 +196,26 @@ __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ c
         reinterpret_cast<uint4 *>(mark)[tid] = make_uint4(tid == 0 ? 1u : 0u, 0u, 0u, 0u);
         __syncthreads();
         uint16_t *J = J0, *Jn = J1;
-#ifndef GLC_EXP_ROUNDS
-#define GLC_EXP_ROUNDS 12
-#endif
-        for (int round = 0; round < GLC_EXP_ROUNDS; round++) {
-            uint32_t jn[LZ_PCKT / 256];
+        for (int round = 0; round < 12; round++) {
+            // four consecutive positions per thread and trip: their table entries and flags are one 8-byte and one
+            // 4-byte LDS read, the squared entries one 8-byte write; only the J[a] gathers are per position
+            uint2 jn[LZ_PCKT / 1024];
 #pragma unroll
-            for (int r = 0; r < LZ_PCKT / 256; r++) {
-                const uint32_t p = r * 256 + tid;
-                const uint32_t a = J[p];
-                if (mark[p] && a < LZ_PCKT) mark[a] = 1;
-                jn[r] = a < LZ_PCKT ? (uint32_t)J[a] : (uint32_t)LZ_PCKT;
+            for (int r = 0; r < LZ_PCKT / 1024; r++) {
+                const uint32_t p = r * 1024 + tid * 4;
+                const uint2 a2 = *reinterpret_cast<const uint2 *>(J + p);
+                const uint32_t m4 = *reinterpret_cast<const uint32_t *>(mark + p);
+                const uint32_t a[4] = {a2.x & 0xFFFFu, a2.x >> 16, a2.y & 0xFFFFu, a2.y >> 16};
+                uint32_t g[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (((m4 >> (8 * i)) & 1u) && a[i] < LZ_PCKT) mark[a[i]] = 1;
+                    g[i] = a[i] < LZ_PCKT ? (uint32_t)J[a[i]] : (uint32_t)LZ_PCKT;
+                }
+                jn[r] = make_uint2(g[0] | (g[1] << 16), g[2] | (g[3] << 16));
             }
 #pragma unroll
-            for (int r = 0; r < LZ_PCKT / 256; r++) Jn[r * 256 + tid] = (uint16_t)jn[r];
+            for (int r = 0; r < LZ_PCKT / 1024; r++) *reinterpret_cast<uint2 *>(Jn + r * 1024 + tid * 4) = jn[r];
             __syncthreads();
             uint16_t *x = J; J = Jn; Jn = x;
             if (J[0] >= LZ_PCKT) break;                       // the walk from 0 ends within 2^(round+1) steps: all marked

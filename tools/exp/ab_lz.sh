@@ -6,5 +6,5 @@ for V in "$@"; do
   rm -rf /tmp/pr
   timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pr -o x -- python $R/tools/bench_culzss.py --gib 1 > /tmp/log 2>&1
   echo "== $V: $(grep -o '"encode_GBps": [0-9.]*' /tmp/log | head -1) $(grep -o '"parity": "[^"]*"' /tmp/log) $(grep -o '"roundtrip": "[^"]*"' /tmp/log)"
-  python $R/profiles/summarize_rocpd.py /tmp/pr/x_results.db | grep -E "lzss_(match|pack)" | awk -F'|' '{printf "   %-40s calls %s avg %s max %s\n", substr($2,1,40), $3, $5, $7}'
+  python $R/profiles/summarize_rocpd.py /tmp/pr/x_results.db | grep -E "lzss_(match|pack|gather|layout)" | awk -F'|' '{printf "   %-40s calls %s avg %s max %s\n", substr($2,1,40), $3, $5, $7}'
 done
