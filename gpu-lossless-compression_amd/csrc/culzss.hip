@@ -32,8 +32,8 @@ namespace glc {
 //   read per step.  (Left to the compiler the loop became ~10 VALU per step: the 127 compare masks were computed
 //   up front and parked in VGPR lanes with v_writelane / v_readlane.)
 // ---------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void lz_scan(const uint32_t (&W)[32], uint32_t A0, uint32_t &R, uint32_t &best, uint32_t &c1,
+template <int K, int SH>
+__device__ __forceinline__ void lz_scan(const uint32_t (&W)[33], uint32_t A0, uint32_t &R, uint32_t &best, uint32_t &c1,
                                         uint32_t &c2, uint64_t ex)
 {
     if constexpr (K < 127) {
@@ -41,10 +41,10 @@ __device__ __forceinline__ void lz_scan(const uint32_t (&W)[32], uint32_t A0, ui
         if constexpr (K == 0) {
             asm volatile("ds_read_u8 %[lb], %[R]\n"
                          "s_waitcnt lgkmcnt(0)\n"
-                         "v_cmpx_ne_u16_sdwa vcc, %[lb], %[w] src0_sel:DWORD src1_sel:BYTE_0\n"
+                         "v_cmpx_ne_u16_sdwa vcc, %[lb], %[w] src0_sel:DWORD src1_sel:BYTE_%[b]\n"
                          "v_subrev_u32_e32 %[R], 1, %[A0]\n"
                          "s_mov_b64 exec, %[ex]\n"
-                         : [R] "+v"(R), [lb] "=&v"(lb) : [w] "v"(W[0]), [A0] "v"(A0), [ex] "s"(ex) : "vcc");
+                         : [R] "+v"(R), [lb] "=&v"(lb) : [w] "v"(W[SH >> 2]), [A0] "v"(A0), [ex] "s"(ex), [b] "n"(SH & 3) : "vcc");
         } else if constexpr ((K & 1) == 1) {                  // record of step K - 1 (even) -> c1
             asm volatile("ds_read_u8 %[lb], %[R] offset:%[k]\n"
                          "s_mov_b32 %[C], %[ck]\n"
@@ -54,7 +54,7 @@ __device__ __forceinline__ void lz_scan(const uint32_t (&W)[32], uint32_t A0, ui
                          "v_subrev_u32_e32 %[R], %[k1], %[A0]\n"
                          "s_mov_b64 exec, %[ex]\n"
                          : [R] "+v"(R), [c1] "=&v"(c1), [lb] "=&v"(lb), [C] "=&s"(C)
-                         : [w] "v"(W[K >> 2]), [A0] "v"(A0), [ex] "s"(ex), [k] "n"(K), [k1] "n"(K + 1), [b] "n"(K & 3),
+                         : [w] "v"(W[(K + SH) >> 2]), [A0] "v"(A0), [ex] "s"(ex), [k] "n"(K), [k1] "n"(K + 1), [b] "n"((K + SH) & 3),
                            [ck] "n"((K << 16) | (0xFFFF - (K - 1)))
                          : "vcc");
         } else {                                               // record of step K - 1 (odd) -> c2, both into best
@@ -67,11 +67,11 @@ __device__ __forceinline__ void lz_scan(const uint32_t (&W)[32], uint32_t A0, ui
                          "v_subrev_u32_e32 %[R], %[k1], %[A0]\n"
                          "s_mov_b64 exec, %[ex]\n"
                          : [R] "+v"(R), [best] "+v"(best), [c2] "=&v"(c2), [lb] "=&v"(lb), [C] "=&s"(C)
-                         : [w] "v"(W[K >> 2]), [A0] "v"(A0), [ex] "s"(ex), [c1] "v"(c1), [k] "n"(K), [k1] "n"(K + 1),
-                           [b] "n"(K & 3), [ck] "n"((K << 16) | (0xFFFF - (K - 1)))
+                         : [w] "v"(W[(K + SH) >> 2]), [A0] "v"(A0), [ex] "s"(ex), [c1] "v"(c1), [k] "n"(K), [k1] "n"(K + 1),
+                           [b] "n"((K + SH) & 3), [ck] "n"((K << 16) | (0xFFFF - (K - 1)))
                          : "vcc");
         }
-        lz_scan<K + 1>(W, A0, R, best, c1, c2, ex);
+        lz_scan<K + 1, SH>(W, A0, R, best, c1, c2, ex);
     } else {                                                   // record of step 126 (even)
         uint32_t C;
         asm volatile("s_mov_b32 %[C], %[ck]\n"
@@ -85,6 +85,58 @@ __device__ __forceinline__ void lz_scan(const uint32_t (&W)[32], uint32_t A0, ui
 // ---------------------------------------------------------------------------
 // match search: one workgroup (256 threads) per packet, 16 positions / thread
 // ---------------------------------------------------------------------------
+// One position p = p4 + SH (p4 a multiple of 4) outside the last 128-byte chunk: returns its candidate
+// (c0 | c1 << 8).  W = the 33 aligned dwords text[p4-128 .. p4+3], shared by the four positions of a lane: window
+// byte k of position p is byte k + SH of W, a byte select of the compare, so the window costs no funnel shift and a
+// quarter of the LDS reads.
+// FindMatch (gpu_compress.cu:104-168) restated without its flag and its branch: a run of equal bytes starting at
+// window byte `st` has length j; the reference records a run when it ends, keeps the first longest (strict >) and
+// restarts at la[0] on the byte AFTER the mismatch.  Recording (j, st) at every step through a maximum is the same
+// thing: a run's last record dominates its earlier ones, longer beats shorter, earlier start beats later on ties.
+__device__ __forceinline__ uint32_t lz_candidate(int length, int offset, uint32_t la0)
+{
+    if (length >= LZ_MAXC) length = LZ_MAXC - 1;
+    return length <= 2 ? (1u | (la0 << 8)) : ((uint32_t)length | ((uint32_t)offset << 8));
+}
+
+template <int SH>
+__device__ __forceinline__ uint32_t lz_position(const uint32_t (&W)[33], const uint8_t *s_buf, int p4)
+{
+    const int p = p4 + SH;
+    const uint8_t *la = s_buf + LZ_WIN + p;                   // text[p + j]
+    const uint32_t A0 = (uint32_t)(uintptr_t)la;              // low half of the flat address = LDS offset
+    uint32_t R = A0, best = 0, c1 = 0, c2 = 0;
+    lz_scan<0, SH>(W, A0, R, best, c1, c2, __builtin_amdgcn_ballot_w64(true));
+    const int j = (int)(best >> 16) - (int)A0;
+    int length = 1, offset = 1;
+    if (j >= 2) { length = j; offset = (p + (int)(0xFFFFu - (best & 0xFFFFu)) + 1 - j) & 255; }
+    return lz_candidate(length, offset, la[0]);
+}
+
+// A position of the last 128-byte chunk: the reference's scan is shortened to max(1, 127 - tx) window bytes and its
+// look-ahead wraps into the stale ring half past the end of the packet (gpu_compress.cu:120,149,303,313-317).
+__device__ __forceinline__ uint32_t lz_position_last(const uint8_t *s_buf, int p)
+{
+    const int tx = p & 127;
+    const uint8_t *la = s_buf + LZ_WIN + p;
+    const int iters = max(1, 127 - tx);
+    const int la_wrap = 128 - tx;                             // look-ahead index where the stale half begins
+    int j = 0, length = 1, offset = 1;
+    bool matching = false;
+    const uint8_t *win = s_buf + p;                           // text[p-128 + k]
+    for (int k = 0; k < iters; k++) {
+        const uint8_t lb = (j < la_wrap) ? la[j] : la[j - 256];
+        if (win[k] == lb) { j++; matching = true; }
+        else {
+            if (matching && j > length) { length = j; offset = (p + k - j) & 255; }
+            j = 0; matching = false;
+        }
+    }
+    if (j > length && matching) { length = j; offset = (p + iters - j) & 255; }
+    if (length > 128 - tx) length = 128 - tx;
+    return lz_candidate(length, offset, la[0]);
+}
+
 __global__ __launch_bounds__(256, 8) void k_lzss_match(const uint8_t *__restrict__ in, uint8_t *__restrict__ cand)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_buf[LZ_WIN + LZ_PCKT];
@@ -97,62 +149,21 @@ __global__ __launch_bounds__(256, 8) void k_lzss_match(const uint8_t *__restrict
     }
     __syncthreads();
     uint8_t *dst = cand + (size_t)pk * 2 * LZ_PCKT;
+    constexpr int QUADS = (LZ_PCKT - 128) / 4;                // groups of four adjacent positions before the last chunk
 #pragma unroll 1
-    for (int it = 0; it < LZ_PCKT / 256; it++) {
-        const int p = it * 256 + tid;
-        const int tx = p & 127;
-        const bool last = (p >> 7) == (LZ_PCKT / 128 - 1);     // wave-uniform: waves 2,3 of the last trip
-        int length = 1, offset = 1;
-        const uint8_t *la = s_buf + LZ_WIN + p;               // text[p + j]
-        if (!last) {
-            // FindMatch (gpu_compress.cu:104-168) restated without its flag and its branch: a run of
-            // equal bytes starting at window byte `st` has length j; the reference records a run when it
-            // ends, keeps the first longest (strict >) and restarts at la[0] on the byte AFTER the
-            // mismatch.  Recording (j, st) at every step through max((j << 16) | ~st) is the same thing:
-            // a run's last record dominates its earlier ones, longer beats shorter, earlier start beats
-            // later on ties.  The 127 window bytes text[p-128 .. p-2] sit in 32 register dwords (aligned
-            // LDS dword reads funnelled by p & 3).
-            uint32_t W[32];
-            {
-                const uint32_t *wa = reinterpret_cast<const uint32_t *>(s_buf + (p & ~3));
-                const uint32_t sh = (uint32_t)(p & 3);
-                uint32_t prev = wa[0];
+    for (int g = (int)tid; g < QUADS; g += 256) {
+        const int p4 = g * 4;
+        uint32_t W[33];
+        const uint32_t *wa = reinterpret_cast<const uint32_t *>(s_buf + p4);
 #pragma unroll
-                for (int q = 0; q < 32; q++) {
-                    const uint32_t nxt = wa[q + 1];
-                    W[q] = __builtin_amdgcn_alignbyte(nxt, prev, sh);
-                    prev = nxt;
-                }
-            }
-            // The scan itself, one window byte per step (lz_scan above).
-            const uint32_t A0 = (uint32_t)(uintptr_t)(s_buf + LZ_WIN + p);      // low half of the flat address = LDS offset
-            uint32_t R = A0, best = 0, c1 = 0, c2 = 0;
-            lz_scan<0>(W, A0, R, best, c1, c2, __builtin_amdgcn_ballot_w64(true));
-            const int j = (int)(best >> 16) - (int)A0;
-            if (j >= 2) { length = j; offset = (p + (int)(0xFFFFu - (best & 0xFFFFu)) + 1 - j) & 255; }
-        } else {
-            // last 128-byte chunk: shortened scan, look-ahead wrapping into the stale ring half
-            const int iters = max(1, 127 - tx);
-            const int la_wrap = 128 - tx;                     // look-ahead index where the stale half begins
-            int j = 0;
-            bool matching = false;
-            const uint8_t *win = s_buf + p;                   // text[p-128 + k]
-            for (int k = 0; k < iters; k++) {
-                const uint8_t lb = (j < la_wrap) ? la[j] : la[j - 256];
-                if (win[k] == lb) { j++; matching = true; }
-                else {
-                    if (matching && j > length) { length = j; offset = (p + k - j) & 255; }
-                    j = 0; matching = false;
-                }
-            }
-            if (j > length && matching) { length = j; offset = (p + iters - j) & 255; }
-        }
-        if (last && length > 128 - tx) length = 128 - tx;
-        if (length >= LZ_MAXC) length = LZ_MAXC - 1;
-        uint8_t c0, c1;
-        if (length <= 2) { c0 = 1; c1 = la[0]; }
-        else { c0 = (uint8_t)length; c1 = (uint8_t)offset; }
-        reinterpret_cast<uint16_t *>(dst)[p] = (uint16_t)c0 | ((uint16_t)c1 << 8);
+        for (int q = 0; q < 33; q++) W[q] = wa[q];
+        const uint32_t r0 = lz_position<0>(W, s_buf, p4), r1 = lz_position<1>(W, s_buf, p4);
+        const uint32_t r2 = lz_position<2>(W, s_buf, p4), r3 = lz_position<3>(W, s_buf, p4);
+        *reinterpret_cast<uint2 *>(dst + 2 * p4) = make_uint2(r0 | (r1 << 16), r2 | (r3 << 16));
+    }
+    if (tid < 128) {                                           // the last chunk, one position per lane of waves 0 and 1
+        const int p = LZ_PCKT - 128 + (int)tid;
+        reinterpret_cast<uint16_t *>(dst)[p] = (uint16_t)lz_position_last(s_buf, p);
     }
 }
 
