@@ -21,6 +21,9 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $CTR --kernel-trace -d $OUT/${TAG}_pmc_$CTR -o pmc -- \
       python $REPO/bench.py --gib 0.25 --rows 256 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --main-only --no-overlap-pass > $OUT/${TAG}_pmc_$CTR.log 2>&1
 done
+rm -rf $OUT/${TAG}_culzss_prof
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_culzss_prof -o ${TAG} -- \
+    python $REPO/tools/bench_culzss.py --gib 1 > $OUT/${TAG}_culzss_bench.json 2> $OUT/${TAG}_culzss_prof.log
 cd $REPO
 find $OUT -name "*.db" -size +62M -delete
 ls -la $OUT | tail -20

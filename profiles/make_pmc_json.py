@@ -32,6 +32,16 @@ def main():
                             "--no-cpu-baseline --main-only --no-overlap-pass  (MI355X, %s)\n\n" % tag)
         subprocess.run([sys.executable, os.path.join(HERE, "summarize_rocpd.py"), prof, md], check=True,
                        capture_output=True)
+    cprof = db_in(os.path.join(out, tag + "_culzss_prof"))
+    if cprof:
+        md = os.path.join(HERE, tag + "_culzss_kernel_stats.md")
+        open(md, "w").write("# rocprofv3 --kernel-trace --stats -- python tools/bench_culzss.py --gib 1  (MI355X, %s; the run "
+                            "also times smaller batches, see min/max)\n\n" % tag)
+        subprocess.run([sys.executable, os.path.join(HERE, "summarize_rocpd.py"), cprof, md], check=True,
+                       capture_output=True)
+        cj = os.path.join(out, tag + "_culzss_bench.json")
+        if os.path.exists(cj) and os.path.getsize(cj):
+            shutil.copy(cj, os.path.join(HERE, tag + "_culzss_bench.json"))
     bj = os.path.join(out, tag + "_bench.json")
     if os.path.exists(bj) and os.path.getsize(bj):
         shutil.copy(bj, os.path.join(HERE, tag + "_bench.json"))
