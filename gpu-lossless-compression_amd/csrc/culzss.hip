@@ -170,10 +170,13 @@ __global__ __launch_bounds__(256, 8) void k_lzss_match(const uint8_t *__restrict
 // ---------------------------------------------------------------------------
 // token selection + packing: one workgroup per packet (aftercomp's inner loop)
 //   stage[pk][0..size) = flag/token bytes of the packet, meta[pk] = (size, last group bytes)
+//   Second choice since k_lzss_pack_wave (below): it takes the packets that kernel gives up on -- candidate streams
+//   whose walks from different starts never fall into step -- at a cost that does not depend on the data.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ cand, uint8_t *__restrict__ stage,
-                                                   uint2 *__restrict__ meta)
+                                                   uint2 *__restrict__ meta, const uint32_t *__restrict__ need)
 {
+    if (need[blockIdx.x] == 0) return;                         // k_lzss_pack_wave has done this packet
     __shared__ __attribute__((aligned(16))) uint8_t s_c[2 * LZ_PCKT];
     __shared__ __attribute__((aligned(16))) uint16_t s_tok[LZ_PCKT];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[LZ_STAGE];
@@ -294,6 +297,134 @@ __global__ __launch_bounds__(256) void k_lzss_pack(const uint8_t *__restrict__ c
     uint8_t *dst = stage + (size_t)pk * LZ_STAGE;
     for (uint32_t i = tid; i < (size + 3) / 4; i += 256)
         reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(s_out)[i];
+}
+
+// ---------------------------------------------------------------------------
+// token selection + packing, one WAVE per packet (four packets per workgroup, no barrier).
+//   The greedy walk p -> p + len(p) from 0 (gpu_compress.cu:498-515) is a chain of ~1800 dependent steps, but two
+//   walks that start at different positions fall into step within a few tokens.  So every lane first walks its own
+//   64 positions from their START (speculative marks, 64 bits in registers); then it walks again from the position
+//   where the real chain enters its segment -- first guess: where its left neighbour's speculative walk left -- only
+//   until it lands on a speculative mark: from there on the speculative marks ARE the chain.  A lane whose real walk
+//   leaves without meeting its marks hands its neighbour a new entry and that one walks again, until nothing
+//   changes (lane 0's entry is exact, so at most 64 trips; one or two in practice, and after LP_MAX_TRIPS the packet
+//   is left to k_lzss_pack above).  Tokens are then compacted in place (rank <= position) and the flag groups are
+//   sized and written 64 at a time.
+//   Candidates sit in LDS with one pad dword per 64 positions: the lanes' private walks are 132 bytes apart and
+//   spread over the banks.
+// ---------------------------------------------------------------------------
+constexpr int LP_WAVES = 4;
+constexpr int LP_MAX_TRIPS = 6;                                    // real walks per lane before the packet is handed over
+constexpr int LP_CAND_BYTES = 2 * LZ_PCKT + 4 * (LZ_PCKT / 64);     // 8448
+
+__device__ __forceinline__ uint32_t lp_off(uint32_t p) { return 2u * p + 4u * (p >> 6); }     // byte offset of position p
+
+__global__ __launch_bounds__(LP_WAVES * 64) void k_lzss_pack_wave(const uint8_t *__restrict__ cand, uint8_t *__restrict__ stage,
+                                                                  uint2 *__restrict__ meta, uint32_t total_pk,
+                                                                  uint32_t *__restrict__ need)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_cand[LP_WAVES][LP_CAND_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[LP_WAVES][LZ_STAGE];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t pk = blockIdx.x * LP_WAVES + wave;
+    if (pk >= total_pk) return;                                // wave-uniform; nothing below synchronises waves
+    uint8_t *CD = s_cand[wave];
+    uint8_t *OUT = s_out[wave];
+    {
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(cand + (size_t)pk * 2 * LZ_PCKT);
+#pragma unroll
+        for (int i = 0; i < 2 * LZ_PCKT / 16 / 64; i++) {
+            const uint32_t q = i * 64 + lane;                  // 8 positions, inside one segment
+            const uint4 v = c4[q];
+            uint32_t *d = reinterpret_cast<uint32_t *>(CD + lp_off(q * 8));
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    auto next = [&](uint32_t p) { const uint32_t c0 = CD[lp_off(p)]; return p + (c0 <= 1u ? 1u : c0); };
+    const uint32_t lo = lane * 64, hi = lo + 64;
+    // 1. speculative walk from the segment's start
+    uint64_t spec = 0;
+    uint32_t spec_exit = lo;
+    while (spec_exit < hi) { spec |= 1ull << (spec_exit - lo); spec_exit = next(spec_exit); }
+    // 2. the real walk, from where the chain enters the segment, until it meets the speculative marks
+    uint64_t mine = 0;
+    uint32_t out = 0, cur = 0xFFFFFFFFu;
+    uint32_t want = wave_prev(spec_exit);                      // lane 0: 0
+    for (int trips = 0;; trips++) {
+        const bool redo = want != cur;
+        if (__builtin_amdgcn_ballot_w64(redo) == 0) break;
+        if (trips == LP_MAX_TRIPS) {                           // walks that do not meet: leave the packet to k_lzss_pack
+            if (lane == 0) need[pk] = 1;
+            return;
+        }
+        if (redo) {
+            cur = want;
+            uint32_t p = cur;
+            uint64_t m = 0;
+            while (p < hi) {
+                const uint64_t bit = 1ull << (p - lo);
+                if (spec & bit) { m |= spec & (0ull - bit); p = spec_exit; break; }
+                m |= bit;
+                p = next(p);
+            }
+            mine = m; out = p;
+        }
+        want = wave_prev(out);
+    }
+    if (lane == 0) need[pk] = 0;
+    // 3. compaction in place: token r of the packet <- candidate word of the r-th marked position
+    uint16_t *TK = reinterpret_cast<uint16_t *>(CD);
+    uint32_t T = 0;
+    const uint32_t mlo = (uint32_t)mine, mhi = (uint32_t)(mine >> 32);
+    for (int c = 0; c < LZ_PCKT / 64; c++) {
+        const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)mlo, c), b = (uint32_t)__builtin_amdgcn_readlane((int)mhi, c);
+        if ((a | b) == 0) continue;
+        const uint32_t v = *reinterpret_cast<const uint16_t *>(CD + lp_off(c * 64 + lane));
+        const uint32_t r = T + __builtin_amdgcn_mbcnt_hi(b, __builtin_amdgcn_mbcnt_lo(a, 0));
+        if ((lane < 32 ? a >> lane : b >> (lane - 32)) & 1u) TK[r] = (uint16_t)v;
+        T += (uint32_t)__popc(a) + (uint32_t)__popc(b);
+    }
+    const uint32_t ngroups = (T + 7) / 8;
+    // 4. groups g = g0 + lane: eight token words = one 16-byte LDS read
+    uint32_t base = 0, last_group_bytes = 0;
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += 64) {
+        const uint32_t g = g0 + lane;
+        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t nt = 0;
+        if (g < ngroups) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(TK + g * 8);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            nt = min(8u, T - g * 8);
+        }
+        uint32_t flags = 0, sz = nt ? 1u : 0u;                // the flag byte
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t t = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const bool lit = (t & 0xFFu) == 1u;
+            if ((uint32_t)j < nt) { flags |= (lit ? 1u : 0u) << j; sz += lit ? 1u : 2u; }
+        }
+        const uint32_t inc = wave_incl_add(sz);
+        if (nt) {
+            uint32_t o = base + inc - sz;
+            const uint32_t gstart = o;
+            OUT[o++] = (uint8_t)flags;                         // flags, LSB first (gpu_compress.cu:505,529-531)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t t = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                if ((uint32_t)j < nt) {
+                    if ((flags >> j) & 1u) OUT[o++] = (uint8_t)(t >> 8);
+                    else { OUT[o++] = (uint8_t)t; OUT[o++] = (uint8_t)(t >> 8); }
+                }
+            }
+            if (g == ngroups - 1) last_group_bytes = o - gstart;
+        }
+        base += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    const uint32_t size = base;
+    if (last_group_bytes) meta[pk] = make_uint2(size, last_group_bytes);
+    uint8_t *dst = stage + (size_t)pk * LZ_STAGE;
+    for (uint32_t i = lane; i < (size + 3) / 4; i += 64)
+        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(OUT)[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -567,7 +698,10 @@ hipError_t lzss_pack(hipStream_t st, const uint8_t *d_cand, int buf_length, int 
     carve(d_work, buf_length, nbuf, &stage, &meta, &pk_off, &cand);
     const uint32_t npk = buf_length / LZ_PCKT;
     const size_t stride = lzss_pack_stride(buf_length);
-    hipLaunchKernelGGL(k_lzss_pack, dim3(npk * nbuf), dim3(256), 0, st, d_cand, stage, meta);
+    // pk_off doubles as the "left to k_lzss_pack" flags until k_lzss_layout writes the offsets
+    hipLaunchKernelGGL(k_lzss_pack_wave, dim3((npk * nbuf + LP_WAVES - 1) / LP_WAVES), dim3(LP_WAVES * 64), 0, st, d_cand, stage,
+                       meta, npk * nbuf, pk_off);
+    hipLaunchKernelGGL(k_lzss_pack, dim3(npk * nbuf), dim3(256), 0, st, d_cand, stage, meta, pk_off);
     hipLaunchKernelGGL(k_lzss_layout, dim3(nbuf), dim3(256), 0, st, meta, npk, buf_length, pk_off, d_packed, stride,
                        d_sizes);
     hipLaunchKernelGGL(k_lzss_gather, dim3(npk, nbuf), dim3(256), 0, st, stage, meta, pk_off, npk, d_packed, stride,

@@ -149,6 +149,67 @@ def test_reference_wrapper_abi(glc, cuda):
     L.deleteGPUStreams()
 
 
+def _synthetic_candidates():
+    """candidate streams (c0 = 1 literal | match length, c1) chosen for the token walk, not produced by a match search:
+    walks from different starts that never fall into step (one length everywhere), jumps of exactly / just under /
+    just over the 64 positions a lane owns, the longest jumps, and random mixtures"""
+    rng = np.random.default_rng(77)
+    n = 16 * 4096
+    out = {}
+
+    def stream(lengths):
+        # as EncodeKernel leaves them: no match crosses the end of its packet (gpu_compress.cu:313-317), and a length
+        # below 3 is a literal
+        room = 4096 - (np.arange(n) % 4096)
+        lengths = np.minimum(lengths.astype(np.int64), room)
+        lengths[lengths <= 2] = 1
+        c = np.empty(2 * n, dtype=np.uint8)
+        c[0::2] = lengths.astype(np.uint8)
+        c[1::2] = rng.integers(0, 256, n, dtype=np.uint8)
+        return c
+
+    for k in (3, 4, 5, 7, 63, 64, 65, 127):
+        out["all_%d" % k] = stream(np.full(n, k, dtype=np.uint8))
+    out["alternate_3_4"] = stream(np.where(np.arange(n) % 2 == 0, 3, 4).astype(np.uint8))
+    out["by_residue"] = stream((3 + (np.arange(n) % 5)).astype(np.uint8))               # a different chain per start
+    mix = rng.integers(3, 128, n).astype(np.uint8)
+    mix[rng.random(n) < 0.3] = 1
+    out["random_mix"] = stream(mix)
+    short = rng.integers(3, 6, n).astype(np.uint8)
+    short[rng.random(n) < 0.1] = 1
+    out["short_mix"] = stream(short)
+    seg = np.full(n, 3, dtype=np.uint8)
+    seg[(np.arange(n) % 64) == 61] = 127                                                 # jumps over whole segments
+    out["jump_over_segments"] = stream(seg)
+    return n, out
+
+
+def test_token_walk_on_synthetic_candidates(glc, cuda):
+    """aftercompression_wrapper on candidates that did not come from a tracked call packs them on the GPU
+    (gpu_compress.cu:462-566 semantics): packed bytes identical to the oracle's serial walk"""
+    L = glc.lib()
+    n, cases = _synthetic_candidates()
+    L.initGPU()
+    buf = L.initCPUmem(n)
+    cand = L.initCPUmem(2 * n)
+    bad = []
+    for name, c in cases.items():
+        want = O.lzss_pack(c, n)
+        C.memmove(cand, c.ctypes.data, 2 * n)
+        m = C.c_int(-1)
+        rc = L.aftercompression_wrapper(buf, n, cand, C.byref(m))
+        if want is None or want.size >= n:
+            assert rc == 0, name + ": oracle says store-raw"
+            continue
+        assert rc == 1, name
+        got = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(n,))[:m.value].copy()
+        if not np.array_equal(got, want):
+            bad.append(name + " " + _first_diff(got, want))
+    L.deleteCPUmem(buf); L.deleteCPUmem(cand)
+    L.deleteGPUStreams()
+    assert not bad, "; ".join(bad)
+
+
 def test_culzss_compress_decompress_roundtrip(glc, cuda):
     L = glc.lib()
     x = datagen.text_bytes(MiB, seed=77)
