@@ -79,13 +79,23 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
     }
     for (uint32_t s = nl + l; s < 320; s += 64) T.key[s] = NONE;
     __builtin_amdgcn_wave_barrier();
-    uint32_t P[5];
+    // Q = value << 9 | slot for values below 2^23 (count < 2^18), else ~0: while the smallest candidate is that small
+    // -- all but the last few merges of a 1 MiB block, whose counts add up to 2^20 + 1 -- ONE wave minimum finds it
+    uint32_t P[5], Q[5];
+    auto packed = [&](uint32_t v, int r) -> uint32_t { return v < (1u << 23) ? (v << 9) | (uint32_t)(r * 64 + (int)l) : NONE; };
 #pragma unroll
-    for (int r = 0; r < 5; r++) P[r] = (uint32_t)T.key[r * 64 + l];
+    for (int r = 0; r < 5; r++) { P[r] = (uint32_t)T.key[r * 64 + l]; Q[r] = packed(P[r], r); }
     __builtin_amdgcn_wave_barrier();
 
     // (value, slot) of the smallest candidate; value NONE if there is none
     auto arg_min = [&](uint32_t &val) -> uint32_t {
+        {
+            uint32_t qb = Q[0];
+#pragma unroll
+            for (int r = 1; r < 5; r++) qb = Q[r] < qb ? Q[r] : qb;
+            const uint32_t q = wave_min_u32(qb);
+            if (q != NONE) { val = q >> 9; return q & 511u; }
+        }
         uint32_t best = P[0], br = 0;
 #pragma unroll
         for (int r = 1; r < 5; r++) { const bool lt = P[r] < best; best = lt ? P[r] : best; br = lt ? (uint32_t)r : br; }
@@ -100,7 +110,7 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
         const int min1 = (int)m1;
         head = min1;
 #pragma unroll
-        for (int r = 0; r < 5; r++) if (m1 == r * 64 + l) P[r] = NONE;
+        for (int r = 0; r < 5; r++) if (m1 == r * 64 + l) { P[r] = NONE; Q[r] = NONE; }
         const uint32_t m2 = arg_min(v2);
         if (v2 == NONE) break;
         const int min2 = (int)m2;
@@ -112,8 +122,8 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
         const uint32_t nk = ((c1 + c2) << 5) | (uint32_t)lv;
 #pragma unroll
         for (int r = 0; r < 5; r++) {
-            if (m1 == r * 64 + l) P[r] = nk;
-            if (m2 == r * 64 + l) P[r] = NONE;
+            if (m1 == r * 64 + l) { P[r] = nk; Q[r] = packed(nk, r); }
+            if (m2 == r * 64 + l) { P[r] = NONE; Q[r] = NONE; }
         }
         if (l == 0) {
             const int i = (int)(nl + k);
