@@ -82,6 +82,38 @@ __device__ __forceinline__ void lz_scan(const uint32_t (&W)[33], uint32_t A0, ui
     }
 }
 
+// The same scan for a position of the LAST 128-byte chunk, where the reference stops after max(1, 127 - tx) window
+// bytes (gpu_compress.cu:120,149): step K runs under EXEC = lanes with K < iters, everything else as above (one record
+// per step, so the result is complete whenever the wave stops).
+template <int K>
+__device__ __forceinline__ void lz_scan_tail(const uint32_t (&W)[33], uint32_t A0, uint32_t iters, uint32_t &R, uint32_t &best,
+                                             uint64_t ex)
+{
+    if constexpr (K < 127) {
+        if constexpr (K % 16 == 0 && K > 0)
+            if (__builtin_amdgcn_ballot_w64(iters > (uint32_t)K) == 0) return;               // wave-uniform
+        uint32_t lb, C, c;
+        uint64_t M;
+        asm volatile("v_cmp_lt_u32_e32 vcc, %[k], %[it]\n"
+                     "s_and_b64 exec, %[ex], vcc\n"
+                     "ds_read_u8 %[lb], %[R] offset:%[k]\n"
+                     "s_mov_b64 %[M], exec\n"
+                     "s_mov_b32 %[C], %[ck]\n"
+                     "s_waitcnt lgkmcnt(0)\n"
+                     "v_cmpx_ne_u16_sdwa vcc, %[lb], %[w] src0_sel:DWORD src1_sel:BYTE_%[b]\n"
+                     "v_subrev_u32_e32 %[R], %[k1], %[A0]\n"
+                     "s_mov_b64 exec, %[M]\n"
+                     "v_lshl_add_u32 %[c], %[R], 16, %[C]\n"
+                     "v_max_u32_e32 %[best], %[best], %[c]\n"
+                     "s_mov_b64 exec, %[ex]\n"
+                     : [R] "+v"(R), [best] "+v"(best), [lb] "=&v"(lb), [c] "=&v"(c), [C] "=&s"(C), [M] "=&s"(M)
+                     : [w] "v"(W[K >> 2]), [A0] "v"(A0), [it] "v"(iters), [ex] "s"(ex), [k] "n"(K), [k1] "n"(K + 1),
+                       [b] "n"(K & 3), [ck] "n"(((K + 1) << 16) | (0xFFFF - K))
+                     : "vcc");
+        lz_scan_tail<K + 1>(W, A0, iters, R, best, ex);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // match search: one workgroup (256 threads) per packet, 16 positions / thread
 // ---------------------------------------------------------------------------
@@ -113,26 +145,33 @@ __device__ __forceinline__ uint32_t lz_position(const uint32_t (&W)[33], const u
     return lz_candidate(length, offset, la[0]);
 }
 
-// A position of the last 128-byte chunk: the reference's scan is shortened to max(1, 127 - tx) window bytes and its
-// look-ahead wraps into the stale ring half past the end of the packet (gpu_compress.cu:120,149,303,313-317).
+// A position of the last 128-byte chunk: the reference's scan is shortened to max(1, 127 - tx) window bytes
+// (gpu_compress.cu:120,149,303).  (Its look-ahead would wrap into the stale ring half past the end of the packet,
+// :313-317, but a run that starts at window byte st has compared j <= iters - 1 - st < 128 - tx bytes when the scan
+// stops, so the wrapped bytes are never read.)
 __device__ __forceinline__ uint32_t lz_position_last(const uint8_t *s_buf, int p)
 {
     const int tx = p & 127;
     const uint8_t *la = s_buf + LZ_WIN + p;
-    const int iters = max(1, 127 - tx);
-    const int la_wrap = 128 - tx;                             // look-ahead index where the stale half begins
-    int j = 0, length = 1, offset = 1;
-    bool matching = false;
-    const uint8_t *win = s_buf + p;                           // text[p-128 + k]
-    for (int k = 0; k < iters; k++) {
-        const uint8_t lb = (j < la_wrap) ? la[j] : la[j - 256];
-        if (win[k] == lb) { j++; matching = true; }
-        else {
-            if (matching && j > length) { length = j; offset = (p + k - j) & 255; }
-            j = 0; matching = false;
+    uint32_t W[33];
+    {
+        const uint32_t *wa = reinterpret_cast<const uint32_t *>(s_buf + (p & ~3));
+        const uint32_t sh = (uint32_t)(p & 3);
+        uint32_t prev = wa[0];
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const uint32_t nxt = wa[q + 1];
+            W[q] = __builtin_amdgcn_alignbyte(nxt, prev, sh);
+            prev = nxt;
         }
+        W[32] = 0;
     }
-    if (j > length && matching) { length = j; offset = (p + iters - j) & 255; }
+    const uint32_t A0 = (uint32_t)(uintptr_t)la;
+    uint32_t R = A0, best = 0;
+    lz_scan_tail<0>(W, A0, (uint32_t)max(1, 127 - tx), R, best, __builtin_amdgcn_ballot_w64(true));
+    const int j = (int)(best >> 16) - (int)A0;
+    int length = 1, offset = 1;
+    if (j >= 2) { length = j; offset = (p + (int)(0xFFFFu - (best & 0xFFFFu)) + 1 - j) & 255; }
     if (length > 128 - tx) length = 128 - tx;
     return lz_candidate(length, offset, la[0]);
 }
@@ -161,9 +200,12 @@ __global__ __launch_bounds__(256, 8) void k_lzss_match(const uint8_t *__restrict
         const uint32_t r2 = lz_position<2>(W, s_buf, p4), r3 = lz_position<3>(W, s_buf, p4);
         *reinterpret_cast<uint2 *>(dst + 2 * p4) = make_uint2(r0 | (r1 << 16), r2 | (r3 << 16));
     }
-    if (tid < 128) {                                           // the last chunk, one position per lane of waves 0 and 1
-        const int p = LZ_PCKT - 128 + (int)tid;
-        reinterpret_cast<uint16_t *>(dst)[p] = (uint16_t)lz_position_last(s_buf, p);
+    if (tid >= 192) {                                          // the last chunk: wave 3, which had half a trip less above
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const int p = LZ_PCKT - 128 + 64 * half + (int)tid - 192;
+            reinterpret_cast<uint16_t *>(dst)[p] = (uint16_t)lz_position_last(s_buf, p);
+        }
     }
 }
 
