@@ -421,6 +421,13 @@ def main():
     compact_off = torch.empty(nblocks + 1, dtype=torch.int64, device=dev)
     ctx = glc.Cudpp()
     nplans = max(1, args.plans)
+    # a plan's scratch is ~47 MiB per row for the encoder and ~9.5 MiB for the decoder (allocated on first decode): batches
+    # shrink if the device does not have that much free (e.g. several ranks sharing one device in a dry run)
+    free_b, _tot = torch.cuda.mem_get_info(dev)
+    if one_device:
+        free_b //= world
+    while rows > 64 and nplans * rows * 60 * MiB > 0.85 * free_b:
+        rows //= 2
     plans, streams = [], []
     for _ in range(nplans):
         pl = glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows)
