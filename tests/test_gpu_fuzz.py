@@ -2,6 +2,8 @@
 kinds (i.i.d. bytes, text, log lines, runs, repeats, periodic data, small alphabets), random block sizes, random
 batch shapes.  BWT bytes + index against the oracle for every block; compress -> decompress back to the input;
 streams identical to the oracle's for a sample."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ import datagen
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
+_OFFSET = 100000 * int(os.environ.get("GLC_FUZZ_OFFSET", "0"))      # other seed ranges for one-off sweeps
 
 
 def _piece(rng, n):
@@ -58,7 +61,7 @@ def ctx(glc, cuda):
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_fuzz_bwt_batches(glc, ctx, cuda, seed):
     import torch
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + _OFFSET)
     n = int(rng.choice([1, 3, 64, 2048, 4097, 50000, 262144, 1 << 20, int(rng.integers(2, 1 << 20))]))
     rows = int(rng.integers(1, 6))
     x = np.concatenate([_block(rng, n) for _ in range(rows)])
@@ -80,12 +83,25 @@ def test_fuzz_bwt_batches(glc, ctx, cuda, seed):
 @pytest.mark.parametrize("seed", list(range(6)))
 def test_fuzz_compress_round_trip(glc, ctx, cuda, seed):
     import torch
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + seed + _OFFSET)
     n = int(rng.choice([4096, 70000, 1 << 19, 1 << 20]))
     rows = int(rng.integers(1, 5))
     x = np.concatenate([_block(rng, n) for _ in range(rows)])
     d_in = torch.from_numpy(x).cuda()
+    # a 4096-symbol block whose codes need more than the 1536 words the format gives it (cudpp_globals.h:66; glued
+    # pieces can do that: rare symbols of one piece under the tree of the whole block): the oracle says so and the
+    # library must report it (include/cudpp.h: CUDPP_ERROR_UNKNOWN from glcPlanSynchronize), not produce a stream
+    overflow = any(O.compress(x[i * n:(i + 1) * n])["rc"] != 0 for i in range(rows))
     with glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
+        if overflow:
+            glc.compress_batch(plan, d_in, n, rows)
+            with pytest.raises(glc.CudppError):
+                plan.synchronize()
+            ok = torch.from_numpy(datagen.zipf_bytes(n * rows, seed=7)).cuda()     # the plan is usable afterwards
+            comp = glc.compress_batch(plan, ok, n, rows)
+            plan.synchronize()
+            assert torch.equal(glc.decompress_batch(plan, comp, n, rows), ok)
+            return
         for rep in range(2):                                   # the second call sees the plan's memory of the first
             comp = glc.compress_batch(plan, d_in, n, rows)
             plan.synchronize()
@@ -96,3 +112,23 @@ def test_fuzz_compress_round_trip(glc, ctx, cuda, seed):
         size = int(comp["size"][0].item())
         assert size == want["size"] and int(comp["bwt_index"][0].item()) == want["bwt_index"]
         assert np.array_equal(comp["words"][:size].cpu().numpy().view(np.uint32), want["words"])
+
+
+def test_compress_reports_a_block_that_does_not_fit(glc, ctx, cuda):
+    """one of the one-off sweeps' inputs (GLC_FUZZ_OFFSET=4, seed 5): glued pieces whose third 512 KiB block has a
+    4096-symbol piece that needs 1544 words under the block's tree -- more than the format's 1536 (cudpp_globals.h:66).
+    The oracle reports it, the library must too, and the plan must go on working."""
+    import torch
+    rng = np.random.default_rng(2000 + 5 + 400000)
+    n = int(rng.choice([4096, 70000, 1 << 19, 1 << 20]))
+    rows = int(rng.integers(1, 5))
+    x = np.concatenate([_block(rng, n) for _ in range(rows)])
+    assert [O.compress(x[i * n:(i + 1) * n])["rc"] for i in range(rows)] == [0, 0, 1, 0]
+    with glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
+        glc.compress_batch(plan, torch.from_numpy(x).cuda(), n, rows)
+        with pytest.raises(glc.CudppError):
+            plan.synchronize()
+        ok = torch.from_numpy(datagen.zipf_bytes(n * rows, seed=7)).cuda()
+        comp = glc.compress_batch(plan, ok, n, rows)
+        plan.synchronize()
+        assert torch.equal(glc.decompress_batch(plan, comp, n, rows), ok)
