@@ -39,6 +39,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MiB = 1 << 20
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# wave64 VALU instructions per 64 input bytes of the instruction-bound kernels (PMC SQ_INSTS_VALU, round 2, r02l kernels)
+VALU_PER_64 = {"k_fs_sort": 109.5, "k_mtf_encode": 107.4, "k_fs_part": 55.0}
 # algorithmic HBM bytes per input byte of the profiled kernels
 ALG_BYTES = {"k_fs_part": 9.0, "k_fs_sort": 9.0, "k_fs_hist": 1.0, "k_mtf_encode": 2.0,
              "k_mtf_chunk_lists+k_mtf_scan_lists": 1.0, "k_huff_pack": None, "k_huff_build": 1.0 / 16,
@@ -676,12 +678,13 @@ def main():
             ktab[name] = {"avg_launch_ms": round(avg, 4), "launches": k["launches"], "alg_bytes_per_input_byte": ab,
                           "achieved_GBps": round(ach, 1) if ach else None,
                           "hbm_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
-            if name == "k_mtf_encode" and avg > 0:
-                # this kernel is bound by VALU issue, not by HBM: its loop body is 162 VALU instructions per 64 symbols
-                # (ISA of k_mtf_encode<true>); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 op
-                issued = per_launch_units / 64.0 * 162.0 / (avg * 1e-3)
+            if name in VALU_PER_64 and avg > 0:
+                # these kernels are bound by instruction issue rather than by HBM: wave64 VALU instructions per 64 input
+                # bytes from the PMC passes (SQ_INSTS_VALU; tools/exp/pmc_fs.sh, pmc_mtf.sh); peak = 1024 SIMDs x 2.4 GHz / 4
+                # cycles per wave64 instruction
+                issued = per_launch_units / 64.0 * VALU_PER_64[name] / (avg * 1e-3)
                 ktab[name]["valu_issue_frac"] = round(issued / (1024 * 2.4e9 / 4), 3)
-                ktab[name]["bound"] = "VALU issue + LDS latency at 4-5 waves per SIMD (162 wave64 VALU instructions per 64 symbols)"
+                ktab[name]["valu_instructions_per_64_bytes"] = VALU_PER_64[name]
         dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
         d = ktab.get(dom, {})
         traffic, tsrc = None, None
@@ -737,7 +740,9 @@ def main():
                                                                 * d["alg_bytes_per_input_byte"], 1)
                                                           if dom and d.get("alg_bytes_per_input_byte") else None),
                          "timing": "hipEvent pairs on the launch stream around every launch inside the timed region",
-                         "note": "dominant = largest summed launch time of the encode pipeline; the per-kernel table is under `kernels`"},
+                         "valu_issue_frac": d.get("valu_issue_frac"),
+                         "note": "dominant = largest summed launch time of the encode pipeline; the per-kernel table is under `kernels`; "
+                                 "`valu_issue_frac` = fraction of the VALU issue rate (the bound that actually holds this kernel)"},
             "kernels": ktab,
             "parity": verify,
         }
