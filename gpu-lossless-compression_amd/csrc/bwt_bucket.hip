@@ -702,8 +702,21 @@ __device__ __forceinline__ uint64_t ss_sym_key(uint64_t raw)
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
 constexpr uint32_t SS_NPL = 4, SS_NPIV0 = 64 * SS_NPL;         // first cut: 256 pivots
-constexpr uint32_t SS_SHARES = 64;                             // shares of a bucket's positions handed out to the waves
+// shares of a bucket's positions handed out to the waves (two per wave).  A share is what a wave cuts into windows, so it
+// should hold at least one full window: with 64 shares of ~32 positions each window filled an eighth of the wave's 256
+// slots and k_ss_windows took 8.0 ms per 256 text blocks; 32 / 16 / 8 / 4 shares: 6.6 / 5.8 / 5.4 / 5.3 ms.
+constexpr uint32_t SS_SHARES = 8;
 constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
+// k_ss_windows' form of a round's key: the SS_STEP = 7 text bytes themselves in the top 56 bits (0 past the end of
+// the text) and the window slot in the low 8, so that no two keys of a window are equal: a position's new place is
+// ONE count (keys below it) and the start of its new run a second one (keys below the key with slot 0).  Bytes cannot
+// tell a suffix that ENDS from one that goes on with zero bytes, so a round with a member whose 7 bytes reach the end of
+// the text (i + 8 > n: the last suffixes of a block) is done with the 9-bit digits above instead.
+__device__ __forceinline__ uint64_t ss_raw7(const uint8_t *T, uint32_t n, uint32_t i)
+{
+    (void)n;
+    return fs_load_be64(T + i) & ~0xFFull;                     // (callers: i + 8 <= n)
+}
 constexpr uint32_t SS_MAXSTEP = FS_LCP_CAP / SS_STEP + 1;      // rounds of a run before the block is given up as deep
 
 // run descriptor of a position: start : 12 | end : 12 | rounds done : 8   (a decided position: end = start + 1)
@@ -983,6 +996,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
     __shared__ uint64_t s_kw[SS_WIN];                          // keys of the window
     __shared__ uint32_t s_vw[SS_WIN];                          // index << 8 | BWT byte
     __shared__ uint32_t s_sw[SS_WIN];                          // run descriptors (bucket positions)
+    __shared__ uint32_t s_cw[SS_WIN];                          // members of the run that starts at a window slot
     __shared__ uint32_t s_bound[SS_SHARES + 1];
     uint32_t gx, gy;
     xcd_order(gx, gy);
@@ -1038,57 +1052,112 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
             // ---- window [pos, W): rounds in registers until every position is decided ----
             while (__ballot(und) != 0) {
                 uint64_t key[4];
-                uint32_t v4[4];
-                bool dp = false;
+                uint32_t v4[4], at[4];
+                bool dp = false, tail = false;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t p = pos + lane + 64 * j;
-                    key[j] = 0; v4[j] = 0;
+                    key[j] = 0; v4[j] = 0; at[j] = 0;
                     if (p < W) {
                         const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
                         if (se - ss > 1) {
                             v4[j] = VW[p - pos];
-                            key[j] = ss_sym_load(T, n, (v4[j] >> 8) + l0 + SS_STEP * st);
+                            at[j] = (v4[j] >> 8) + l0 + SS_STEP * st;
                             dp |= st > SS_MAXSTEP;
+                            tail |= at[j] + 8 > n;                 // its 7 bytes (or the 8-byte load) reach the end of the text
                         }
                     }
                 }
                 if (__ballot(dp) != 0) { deep = true; break; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t p = pos + lane + 64 * j;
-                    if (p < W && ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) { key[j] = ss_sym_key(key[j]); KW[p - pos] = key[j]; }
-                }
-                __builtin_amdgcn_wave_barrier();
                 uint32_t np[4];
+                if (__ballot(tail) == 0) {
+                    // the usual round: keys that cannot be equal (ss_raw7), two counts per member
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t p = pos + lane + 64 * j;
-                    np[j] = 0xFFFFFFFFu;
-                    if (p < W) {
-                        const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
-                        if (se - ss > 1) {
-                            uint32_t less = 0, eqt = 0, eqb = 0;
-#pragma unroll 4
-                            for (uint32_t q = ss; q < se; q++) {
-                                const uint64_t kq = KW[q - pos];
-                                less += kq < key[j]; eqt += kq == key[j]; eqb += (kq == key[j]) & (q < p);
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t p = pos + lane + 64 * j;
+                        if (p < W) {
+                            s_cw[p - pos] = 0;
+                            if (((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) {
+                                key[j] = ss_raw7(T, n, at[j]) | (uint64_t)(p - pos);
+                                KW[p - pos] = key[j];
                             }
-                            np[j] = ss + less + eqb;
-                            g4[j] = ss_run(ss + less, ss + less + eqt, st + 1);
                         }
                     }
-                }
-                __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (np[j] != 0xFFFFFFFFu) { VW[np[j] - pos] = v4[j]; SW[np[j] - pos] = g4[j]; }
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t p = pos + lane + 64 * j;
+                        np[j] = 0xFFFFFFFFu;
+                        if (p < W) {
+                            const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
+                            if (se - ss > 1) {
+                                const uint64_t klow = key[j] & ~0xFFull;
+                                uint32_t below = 0, below_run = 0;
+#pragma unroll 4
+                                for (uint32_t q = ss; q < se; q++) {
+                                    const uint64_t kq = KW[q - pos];
+                                    below += kq < key[j]; below_run += kq < klow;
+                                }
+                                np[j] = ss + below;
+                                g4[j] = (ss + below_run) | (st + 1) << 24;      // new run start + step; the end follows from the count
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (np[j] != 0xFFFFFFFFu) {
+                            VW[np[j] - pos] = v4[j]; SW[np[j] - pos] = g4[j];
+                            atomicAdd(&s_cw[(g4[j] & 0xFFFu) - pos], 1u);
+                        }
+                } else {
+                    // a member's bytes reach the end of the text (the last suffixes of a block): the 9-bit digits that tell
+                    // "ended" from a zero byte, equal keys counted apart
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t p = pos + lane + 64 * j;
+                        if (p < W && ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) {
+                            key[j] = ss_sym_key(ss_sym_load(T, n, at[j]));
+                            KW[p - pos] = key[j];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t p = pos + lane + 64 * j;
+                        np[j] = 0xFFFFFFFFu;
+                        if (p < W) {
+                            const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
+                            if (se - ss > 1) {
+                                uint32_t less = 0, eqt = 0, eqb = 0;
+                                for (uint32_t q = ss; q < se; q++) {
+                                    const uint64_t kq = KW[q - pos];
+                                    less += kq < key[j]; eqt += kq == key[j]; eqb += (kq == key[j]) & (q < p);
+                                }
+                                np[j] = ss + less + eqb;
+                                g4[j] = ss_run(ss + less, ss + less + eqt, st + 1);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (np[j] != 0xFFFFFFFFu) { VW[np[j] - pos] = v4[j]; SW[np[j] - pos] = g4[j]; }
+                }
                 __builtin_amdgcn_wave_barrier();
                 und = false;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t p = pos + lane + 64 * j;
-                    if (p < W) { g4[j] = SW[p - pos]; und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1; }
+                    if (p < W) {
+                        g4[j] = SW[p - pos];
+                        if (((g4[j] >> 12) & 0xFFFu) == 0) {          // written by the usual round: (start, step) -> (start, end, step)
+                            const uint32_t ss = g4[j] & 0xFFFu;
+                            g4[j] = ss_run(ss, ss + s_cw[ss - pos], g4[j] >> 24);
+                            SW[p - pos] = g4[j];
+                        }
+                        und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1;
+                    }
                 }
             }
             // rows R0 + pos .. R0 + W
