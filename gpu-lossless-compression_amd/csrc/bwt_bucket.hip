@@ -621,7 +621,8 @@ __device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8
 __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                       uint32_t nbl, const uint2 *__restrict__ tab,
                                                       const uint32_t *__restrict__ list, uint64_t *__restrict__ split,
-                                                      uint16_t *__restrict__ cell, uint32_t *__restrict__ flag)
+                                                      uint16_t *__restrict__ cell, uint32_t *__restrict__ flag,
+                                                      uint32_t *__restrict__ l0_out)
 {
     __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
     __shared__ uint2 s_tab[256];
@@ -665,6 +666,25 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
     for (uint32_t k = tid; k < nb; k += SSA_NT)
         split[(size_t)b * FS_MAXNB + k] = k ? s_s[(uint32_t)(((uint64_t)k * S) / nb)] : 0ull;
+    // every suffix of a bucket lies between its two splitters and shares their common prefix: l0 of bucket k, here
+    // for all buckets at once (in k_ss_cut it was three dependent memory round trips of ONE thread, with the other
+    // 1023 of the workgroup waiting at the first barrier)
+    for (uint32_t k = tid; k < nb; k += SSA_NT) {
+        uint32_t l0 = 0;
+        if (k >= 1 && k + 1 < nb) {
+            const uint32_t ia = (uint32_t)(s_s[(uint32_t)(((uint64_t)k * S) / nb)] >> 8) & 0xFFFFFu;
+            const uint32_t ib = (uint32_t)(s_s[(uint32_t)(((uint64_t)(k + 1) * S) / nb)] >> 8) & 0xFFFFFu;
+            if (ia != ib) {
+                const uint32_t m = max(ia, ib);
+                while (l0 < SS_L0_CAP && m + l0 + 12 <= n) {
+                    const uint64_t x = fs_load_be64(T + ia + l0) ^ fs_load_be64(T + ib + l0);
+                    if (x) { l0 += (uint32_t)__builtin_clzll(x) >> 3; break; }
+                    l0 += 8;
+                }
+            }
+        }
+        l0_out[(size_t)b * FS_MAXNB + k] = l0;
+    }
     // cell[x] = first splitter (counted from 1) whose leading 12 code bits are >= x; nb if there is none
     for (uint32_t x = tid; x < SS_CELLS + 2; x += SSA_NT) {
         uint32_t lo = 1, hi = nb;
@@ -777,7 +797,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
                                                     uint32_t nbl, uint64_t *__restrict__ keys, size_t kstride,
                                                     const uint32_t *__restrict__ fill,
                                                     uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
-                                                    const uint64_t *__restrict__ split, uint32_t *__restrict__ l0_out)
+                                                    const uint32_t *__restrict__ l0_in)
 {
     __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position; scratch of a cut
     __shared__ uint32_t s_v[FS_FILLMAX];                       // index << 8 | BWT byte of the suffix at a position
@@ -792,24 +812,10 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
-    const uint64_t *SP = split + (size_t)b * FS_MAXNB;
     if (tid == 0) {
         s_deep = flag[b];
         s_next = 0; s_nlong = 0;
-        // every suffix of the bucket lies between its two splitters and shares their common prefix
-        uint32_t l0 = 0;
-        if (bk >= 1 && bk + 1 < nb && c > 1) {
-            const uint32_t ia = (uint32_t)(SP[bk] >> 8) & 0xFFFFFu, ib = (uint32_t)(SP[bk + 1] >> 8) & 0xFFFFFu;
-            if (ia != ib) {
-                const uint32_t m = max(ia, ib);
-                while (l0 < SS_L0_CAP && m + l0 + 12 <= n) {
-                    const uint64_t x = fs_load_be64(T + ia + l0) ^ fs_load_be64(T + ib + l0);
-                    if (x) { l0 += (uint32_t)__builtin_clzll(x) >> 3; break; }
-                    l0 += 8;
-                }
-            }
-        }
-        s_l0 = l0;
+        s_l0 = c > 1 ? l0_in[(size_t)b * FS_MAXNB + bk] : 0u;   // common prefix of the bucket's two splitters (k_ss_sample)
     }
     uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
     // ---- first cut, by the whole workgroup (thread = the positions r NT + tid) ----
@@ -980,7 +986,6 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
     // the bucket goes back to its slot in run order: [run : 32 | index : 20 | bwt : 8 ...] (bits 28..31 unused)
     for (uint32_t p = tid; p < c; p += SSS_NT) K[p] = (uint64_t)s_v[p] | ((uint64_t)s_seg[p] << 32);
-    if (tid == 0) l0_out[(size_t)b * FS_MAXNB + bk] = l0;
 }
 
 constexpr int SSW_PER_BUCKET = 4;                              // one-wave workgroups per bucket; wave w takes shares w, w + 4, ...
@@ -1242,12 +1247,12 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
     hipLaunchKernelGGL(k_ss_sample, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, s.ss_list,
-                       s.ss_split, s.ss_cell, s.ss_flag);
+                       s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0);
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
                        n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_cell);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
     hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_l0);
+                       s.fs_fill, s.ss_flag, s.ss_list, s.ss_l0);
     hipLaunchKernelGGL(k_ss_windows, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                        s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
                        (size_t)s.nmax);
