@@ -139,9 +139,8 @@ __device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
 }
 
 // suffix a < suffix b ?  (a != b; the shorter of two suffixes that agree to the end of one is the smaller)
-__device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep)
+__device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep, uint32_t k = 0)
 {
-    uint32_t k = 0;
     for (;;) {
         const uint32_t m = max(a, b) + k;
         if (m + 12 <= n) {
@@ -164,8 +163,11 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
 // ---------------------------------------------------------------------------
 // SPLIT = the sample tier's form: blocks come from a list, and the bucket of a word is found among the block's
 // splitter suffixes (code first, text on equal codes) instead of in the top bits of the code.
-__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint16_t *cell, uint64_t w, const uint8_t *T,
-                                              uint32_t n, bool *deep)
+// sp8[k] / w8: the first 8 text bytes of splitter k / of the word's suffix (big-endian, 0 past the end of the text): on
+// equal codes they decide most comparisons without going to the text (text-like blocks are exactly those with thousands
+// of suffixes under one code)
+__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t *sp8, const uint16_t *cell, uint64_t w,
+                                              uint64_t w8, const uint8_t *T, uint32_t n, bool *deep)
 {
     const uint64_t cw = w >> 28;
     const uint32_t iw = (uint32_t)(w >> 8) & 0xFFFFFu;
@@ -180,7 +182,9 @@ __device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint16_t
         if (cs != cw) le = cs < cw;
         else {
             const uint32_t is = (uint32_t)(sw >> 8) & 0xFFFFFu;
-            le = is == iw || !fs_suffix_less(T, n, iw, is, deep);
+            const uint64_t s8 = sp8[mid];
+            if (s8 != w8) le = s8 < w8;
+            else le = is == iw || !fs_suffix_less(T, n, iw, is, deep, 8);
         }
         if (le) lo = mid; else hi = mid;
     }
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
                                                     uint64_t *__restrict__ keys, size_t kstride,
                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
                                                     const uint32_t *__restrict__ list, const uint64_t *__restrict__ split,
-                                                    const uint16_t *__restrict__ cell)
+                                                    const uint16_t *__restrict__ cell, const uint64_t *__restrict__ split8)
 {
     __shared__ uint32_t s_cnt[FS_MAXNB], s_start[FS_MAXNB], s_gbase[FS_MAXNB];
     __shared__ uint64_t s_w[FSP_TILE];
@@ -223,8 +227,12 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     const uint8_t *T = text + (size_t)b * stride;
     uint64_t *s_split = s_w + 1024;                            // (SPLIT) behind the table and the staged text, dead with them
     uint16_t *s_cell = reinterpret_cast<uint16_t *>(s_w + 1024 + FS_MAXNB);
+    uint64_t *s_split8 = s_w + 1024 + FS_MAXNB + (SS_CELLS + 2 + 3) / 4 + 1;    // behind the cell table (8196 bytes)
     if (SPLIT) {
-        for (uint32_t i = tid; i < (1u << nbl); i += FSP_NT) s_split[i] = split[(size_t)b * FS_MAXNB + i];
+        for (uint32_t i = tid; i < (1u << nbl); i += FSP_NT) {
+            s_split[i] = split[(size_t)b * FS_MAXNB + i];
+            s_split8[i] = split8[(size_t)b * FS_MAXNB + i];
+        }
         for (uint32_t i = tid; i < SS_CELLS + 2; i += FSP_NT) s_cell[i] = cell[(size_t)b * (SS_CELLS + 2) + i];
     }
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
@@ -277,7 +285,12 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
         uint32_t bk;
         if (SPLIT) {
             bool deep = false;
-            bk = gi < n ? ss_bucket(s_split, s_cell, w[j], T, n, &deep) : 0u;
+            // bytes j + 1 .. j + 8 of the 16 staged ones = the suffix's first 8 text bytes
+            const uint32_t o0 = j + 1, o1 = j + 5;
+            const uint32_t d0 = (o0 & 3) ? __builtin_amdgcn_alignbyte(by4[(o0 >> 2) + 1], by4[o0 >> 2], o0 & 3) : by4[o0 >> 2];
+            const uint32_t d1 = (o1 & 3) ? __builtin_amdgcn_alignbyte(by4[min((o1 >> 2) + 1, 3u)], by4[o1 >> 2], o1 & 3) : by4[o1 >> 2];
+            const uint64_t w8 = ((uint64_t)__builtin_bswap32(d0) << 32) | __builtin_bswap32(d1);
+            bk = gi < n ? ss_bucket(s_split, s_split8, s_cell, w[j], w8, T, n, &deep) : 0u;
             if (deep) atomicOr(&flag[b], 2u);
         } else bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
         br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
@@ -622,7 +635,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                                                       uint32_t nbl, const uint2 *__restrict__ tab,
                                                       const uint32_t *__restrict__ list, uint64_t *__restrict__ split,
                                                       uint16_t *__restrict__ cell, uint32_t *__restrict__ flag,
-                                                      uint32_t *__restrict__ l0_out)
+                                                      uint32_t *__restrict__ l0_out, uint64_t *__restrict__ split8)
 {
     __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
     __shared__ uint2 s_tab[256];
@@ -664,8 +677,15 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         if (s_deep) break;
     }
     if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-    for (uint32_t k = tid; k < nb; k += SSA_NT)
-        split[(size_t)b * FS_MAXNB + k] = k ? s_s[(uint32_t)(((uint64_t)k * S) / nb)] : 0ull;
+    for (uint32_t k = tid; k < nb; k += SSA_NT) {
+        const uint64_t sw = k ? s_s[(uint32_t)(((uint64_t)k * S) / nb)] : 0ull;
+        split[(size_t)b * FS_MAXNB + k] = sw;
+        const uint32_t is = (uint32_t)(sw >> 8) & 0xFFFFFu;  // its first 8 text bytes, 0 past the end (k_fs_part<true>)
+        uint64_t f8 = 0;
+        if (is + 8 <= n) f8 = fs_load_be64(T + is);
+        else for (uint32_t t = 0; t < 8; t++) f8 = (f8 << 8) | (is + t < n ? (uint64_t)T[is + t] : 0ull);
+        split8[(size_t)b * FS_MAXNB + k] = f8;
+    }
     // every suffix of a bucket lies between its two splitters and shares their common prefix: l0 of bucket k, here
     // for all buckets at once (in k_ss_cut it was three dependent memory round trips of ONE thread, with the other
     // 1023 of the workgroup waiting at the first barrier)
@@ -1226,7 +1246,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
     hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
                        nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag, (const uint32_t *)nullptr,
-                       (const uint64_t *)nullptr, (const uint16_t *)nullptr);
+                       (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr);
     if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag, (const uint32_t *)nullptr);
     pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
@@ -1247,9 +1267,10 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
     hipLaunchKernelGGL(k_ss_sample, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, s.ss_list,
-                       s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0);
+                       s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB);
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
-                       n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_cell);
+                       n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_cell,
+                       s.ss_split + (size_t)s.rows * FS_MAXNB);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
     hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
                        s.fs_fill, s.ss_flag, s.ss_list, s.ss_l0);
