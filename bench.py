@@ -39,7 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MiB = 1 << 20
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# wave64 VALU instructions per 64 input bytes of the instruction-bound kernels (PMC SQ_INSTS_VALU, round 2, r02n kernels)
+# wave64 VALU instructions per 64 input bytes of the instruction-bound kernels (PMC SQ_INSTS_VALU, round 2, r02o kernels)
 VALU_PER_64 = {"k_fs_sort": 109.5, "k_mtf_encode": 107.4, "k_fs_part": 55.0}
 # algorithmic HBM bytes per input byte of the profiled kernels
 ALG_BYTES = {"k_fs_part": 9.0, "k_fs_sort": 9.0, "k_fs_hist": 1.0, "k_mtf_encode": 2.0,
