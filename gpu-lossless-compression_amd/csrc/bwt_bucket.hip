@@ -148,8 +148,7 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
             if (va != vb) return va < vb;
             k += 8;
         } else {
-            if (a + k >= n) return true;
-            if (b + k >= n) return false;
+            if (a + k >= n || b + k >= n) return a > b;        // one (or both: called with k > 0) ended: the shorter suffix is the smaller
             const uint32_t ca = T[a + k], cb = T[b + k];
             if (ca != cb) return ca < cb;
             k++;

@@ -20,15 +20,29 @@
  *     oracle/_ref/libsagold.so, plus the computeBwtGold/computeMtfGold
  *     semantics of test_compress.cpp:79-125) on the reference's own test
  *     inputs (glibc srand(95835)); see tests/golden/make_golden.py.
- *   - Huffman tree: the node-merge order restates huffman_build_tree_cpu
- *     (test_compress.cpp:127-186), which is itself the CPU twin of the device
- *     kernel (compress_kernel.cuh:2306-2392); the reference test only checks
- *     decode round trip, so the packed bitstream is pinned by round trip
- *     through the gold *decoder* semantics (test_compress.cpp:240-311), not
- *     by a reference-produced byte vector: "bitstream parity unpinned".
- *   - CULZSS: the reference has no test; restated from gpu_compress.cu /
- *     gpu_decompress.cu and pinned only by encode->decode round trip:
- *     "parity unpinned".
+ *   - Huffman tree / codes / packed stream / offsets: pinned against the
+ *     reference's own FindMinimumCountTest + huffman_build_tree_cpu and the
+ *     Huffman + inverse-MTF half of computeCompressGold
+ *     (test_compress.cpp:55-78,127-190,192-311), compiled from the
+ *     reference's lines by oracle/mk_ref_compress_gold.sh: code lengths on 14
+ *     tie-heavy histograms, streams the reference's gold decoder reads back,
+ *     4 end-to-end 1 MiB chains (tests/golden/make_huff_gold.py,
+ *     ref_huff_gold.npz).
+ *   - CULZSS token selection + packing + trailer (aftercomp,
+ *     aftercompression_wrapper: gpu_compress.cu:462-672): pinned against the
+ *     reference's own host code, compiled from the reference's lines by
+ *     oracle/mk_ref_aftercomp.sh, on 31 candidate streams -- return code,
+ *     size, CRC, head / tail bytes, full bytes for the small buffers
+ *     (tests/golden/make_lzss_gold.py, ref_lzss_gold.npz).  The decoder
+ *     restatement reads those reference-packed bytes back to the input.
+ *   - CULZSS match search (EncodeKernel / FindMatch, gpu_compress.cu:104-350)
+ *     and DecodeKernel (gpu_decompress.cu:120-244) are CUDA only: no CPU twin
+ *     and no test in the reference.  Restated lock-step from the cited lines;
+ *     "parity unpinned" by reference-produced vectors for those two kernels.
+ *     What they have: the survey's INDEPENDENT restatement KAT on pg1661.txt
+ *     (candidates CRC 799b54ef, 569 823 packed bytes CRC 15c4edd7; SURVEY.md
+ *     App. C; tests/test_cpu_oracle.py::test_survey_kat_on_pg1661), and the
+ *     decoder reading bytes written by the reference's packer.
  */
 #include <stdint.h>
 #include <stdlib.h>

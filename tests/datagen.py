@@ -99,3 +99,65 @@ def glibc_rand_bytes(n, mod, seed=95835):
     libc.srand(seed)
     rand = libc.rand
     return np.fromiter(((rand() % mod) + 1 for _ in range(n)), dtype=np.uint8, count=n)
+
+
+def lzss_synthetic_candidates():
+    """candidate streams (c0 = 1 literal | match length, c1) chosen for the token walk, not produced by a match search:
+    walks from different starts that never fall into step (one length everywhere), jumps of exactly / just under /
+    just over the 64 positions a lane owns, the longest jumps, and random mixtures"""
+    rng = np.random.default_rng(77)
+    n = 16 * 4096
+    out = {}
+
+    def stream(lengths):
+        # as EncodeKernel leaves them: no match crosses the end of its packet (gpu_compress.cu:313-317), and a length
+        # below 3 is a literal
+        room = 4096 - (np.arange(n) % 4096)
+        lengths = np.minimum(lengths.astype(np.int64), room)
+        lengths[lengths <= 2] = 1
+        c = np.empty(2 * n, dtype=np.uint8)
+        c[0::2] = lengths.astype(np.uint8)
+        c[1::2] = rng.integers(0, 256, n, dtype=np.uint8)
+        return c
+
+    for k in (3, 4, 5, 7, 63, 64, 65, 127):
+        out["all_%d" % k] = stream(np.full(n, k, dtype=np.uint8))
+    out["alternate_3_4"] = stream(np.where(np.arange(n) % 2 == 0, 3, 4).astype(np.uint8))
+    out["by_residue"] = stream((3 + (np.arange(n) % 5)).astype(np.uint8))               # a different chain per start
+    mix = rng.integers(3, 128, n).astype(np.uint8)
+    mix[rng.random(n) < 0.3] = 1
+    out["random_mix"] = stream(mix)
+    short = rng.integers(3, 6, n).astype(np.uint8)
+    short[rng.random(n) < 0.1] = 1
+    out["short_mix"] = stream(short)
+    seg = np.full(n, 3, dtype=np.uint8)
+    seg[(np.arange(n) % 64) == 61] = 127                                                 # jumps over whole segments
+    out["jump_over_segments"] = stream(seg)
+    out["all_literal"] = stream(np.full(n, 1, dtype=np.uint8))                           # 9/8 of the buffer: store raw
+    return n, out
+
+
+def lzss_gold_inputs():
+    """inputs of tests/golden/ref_lzss_gold.npz (CULZSS rows a13/a14): name -> bytes of one buffer (a multiple of 4096).
+    Shared by the generator (tests/golden/make_lzss_gold.py) and the tests that read the fixture."""
+    MiB = 1 << 20
+    rng = np.random.default_rng(11)
+    tail = np.random.default_rng(20260928).integers(0, 256, MiB, dtype=np.uint8)
+    c = {
+        "log_1m": log_bytes(MiB),
+        "text_1m": text_bytes(MiB),
+        "zeros_1m": np.zeros(MiB, dtype=np.uint8),
+        "zipf_1m": zipf_bytes(MiB),                                   # store raw
+        "float_256k": float_bytes(262144),                            # store raw
+        "run_118685": np.concatenate([np.full(118685, 65, dtype=np.uint8), tail[: MiB - 118685]]),   # packed > buffer
+        "run_119175": np.concatenate([np.full(119175, 65, dtype=np.uint8), tail[: MiB - 119175]]),   # packed == buffer
+        "zeros_64k": np.zeros(65536, dtype=np.uint8),
+        "spaces_then_text": np.concatenate([np.full(8192, 0x20, dtype=np.uint8), text_bytes(57344, seed=5)]),
+        "period3_8k": np.tile(np.array([1, 2, 3], dtype=np.uint8), 2731)[:8192].copy(),
+        "caret_tail_4k": np.concatenate([log_bytes(3968, seed=9), np.full(128, ord("^"), dtype=np.uint8)]),
+        "repeat_across_last_chunk": np.tile(text_bytes(96, seed=3), 43)[:4096].copy(),
+        "one_packet_random": rng.integers(0, 256, 4096, dtype=np.uint8),
+    }
+    for k in (1, 2, 3, 4):
+        c["log_%dpkt" % k] = log_bytes(4096 * k, seed=40 + k)
+    return c

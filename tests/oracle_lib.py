@@ -366,3 +366,23 @@ def glibc_rand_bytes(n, mod, seed=95835):
     libc.srand(seed)
     rand = libc.rand
     return np.fromiter(((rand() % mod) + 1 for _ in range(n)), dtype=np.uint8, count=n)
+
+
+AFTERCOMP_SO = os.path.join(os.path.dirname(SAGOLD_SO), "libaftercomp.so")
+_aftercomp = None
+
+
+def have_ref_aftercomp():
+    return os.path.exists(AFTERCOMP_SO)
+
+
+def ref_aftercomp_lib():
+    """oracle/_ref/libaftercomp.so: the reference's own aftercomp + aftercompression_wrapper
+    (cuda-lzss-cluster/gpu_compress.cu:462-672), built by oracle/mk_ref_aftercomp.sh from the reference's lines."""
+    global _aftercomp
+    if _aftercomp is None:
+        L = C.CDLL(AFTERCOMP_SO)
+        L.aftercompression_wrapper.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.aftercompression_wrapper.restype = C.c_int
+        _aftercomp = L
+    return _aftercomp

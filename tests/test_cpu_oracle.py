@@ -295,3 +295,102 @@ def test_reference_gold_live_against_oracle():
     r = O.compress(y)
     sym, byt = O.ref_compress_gold_decode(r["hist"], r["offsets"], r["words"], y.size)
     assert np.array_equal(byt, O.bwt(y)[0])                  # gold Huffman decode + inverse MTF reads the oracle's stream
+
+
+# ------------------------------------------------ CULZSS packer vs the reference's own aftercomp (row a13) ----
+LZSS_GOLD = np.load(os.path.join(GOLD, "ref_lzss_gold.npz"))
+_LZSS_INPUTS = None
+
+
+def lzss_gold_candidates(name):
+    """the candidate stream of a fixture case, regenerated from its seed (and checked against the fixture's CRC)"""
+    global _LZSS_INPUTS
+    import zlib
+    n = int(LZSS_GOLD[name + "/n"])
+    if str(LZSS_GOLD[name + "/kind"]) == "input":
+        if _LZSS_INPUTS is None:
+            _LZSS_INPUTS = datagen.lzss_gold_inputs()
+        x = _LZSS_INPUTS[name]
+        cand = O.lzss_candidates(x)
+    else:
+        x = None
+        cand = datagen.lzss_synthetic_candidates()[1][name[4:]]
+    assert (zlib.crc32(cand.tobytes()) & 0xFFFFFFFF) == int(LZSS_GOLD[name + "/cand_crc"]), "candidates of %s drifted" % name
+    return n, x, cand
+
+
+@pytest.mark.parametrize("name", [str(s) for s in LZSS_GOLD["names"]])
+def test_oracle_lzss_pack_vs_reference_aftercomp(name):
+    """orc_lzss_pack == the reference's own aftercompression_wrapper (gpu_compress.cu:462-672, compiled from the
+    reference's lines; tests/golden/make_lzss_gold.py): return code, size, CRC, first / last bytes, and the bytes
+    themselves where the fixture keeps them; the oracle's decoder reads the reference-packed bytes back."""
+    import zlib
+    n, x, cand = lzss_gold_candidates(name)
+    got = O.lzss_pack(cand, n)
+    if int(LZSS_GOLD[name + "/rc"]) == 0:
+        assert got is None
+        return
+    assert got is not None and got.size == int(LZSS_GOLD[name + "/size"])
+    assert (zlib.crc32(got.tobytes()) & 0xFFFFFFFF) == int(LZSS_GOLD[name + "/crc"])
+    assert np.array_equal(got[:64], LZSS_GOLD[name + "/head"]) and np.array_equal(got[-32:], LZSS_GOLD[name + "/tail"])
+    if name + "/packed" in LZSS_GOLD:
+        ref_bytes = LZSS_GOLD[name + "/packed"]
+        assert np.array_equal(got, ref_bytes)
+        if x is not None:
+            assert np.array_equal(O.lzss_decode(ref_bytes), x), "oracle decoder on reference-packed bytes"
+
+
+@pytest.mark.skipif(not O.have_ref_aftercomp(), reason="oracle/_ref/libaftercomp.so not built (needs /root/reference)")
+def test_reference_aftercomp_live_against_fixture_and_oracle():
+    """in the build container: the reference's packer run now == the committed fixture == the oracle, on fresh
+    candidate streams too (random mixtures the fixture does not hold)"""
+    import ctypes
+    import zlib
+    L = O.ref_aftercomp_lib()
+
+    def ref(cand, n):
+        buf = np.zeros(n + 8192, dtype=np.uint8)
+        m = ctypes.c_int(-1)
+        c = cand.copy()
+        rc = L.aftercompression_wrapper(buf.ctypes.data, n, c.ctypes.data, ctypes.byref(m))
+        return buf[: m.value].copy() if rc == 1 else None
+
+    for name in ("log_4pkt", "spaces_then_text", "syn_random_mix", "one_packet_random"):
+        n, _, cand = lzss_gold_candidates(name)
+        r = ref(cand, n)
+        if int(LZSS_GOLD[name + "/rc"]) == 0:
+            assert r is None
+        else:
+            assert (zlib.crc32(r.tobytes()) & 0xFFFFFFFF) == int(LZSS_GOLD[name + "/crc"])
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        x = np.concatenate([datagen.log_bytes(8192, seed=100 + trial), rng.integers(97, 101, 4096, dtype=np.uint8),
+                            datagen.text_bytes(4096, seed=trial)])
+        cand = O.lzss_candidates(x)
+        r, o = ref(cand, x.size), O.lzss_pack(cand, x.size)
+        assert (r is None) == (o is None) and (r is None or np.array_equal(r, o)), trial
+
+
+PG1661 = "/root/reference/cuda-lzss-unknown/pg1661.txt"
+
+
+@pytest.mark.skipif(not os.path.exists(PG1661), reason="in-container only: the text lives under /root/reference")
+def test_survey_kat_on_pg1661():
+    """the survey's INDEPENDENT lock-step restatement of EncodeKernel / aftercomp on pg1661.txt
+    zero-padded to one 1 MiB buffer gave candidates CRC 799b54ef and 569 823 packed bytes, CRC 15c4edd7.  The only
+    pin rows a11 / a14 can have (EncodeKernel and DecodeKernel are CUDA only, no CPU twin, no test in the reference)."""
+    import zlib
+    raw = np.fromfile(PG1661, dtype=np.uint8)
+    x = np.zeros(1 << 20, dtype=np.uint8)
+    x[: raw.size] = raw[: 1 << 20]
+    cand = O.lzss_candidates(x)
+    assert "%08x" % (zlib.crc32(cand.tobytes()) & 0xFFFFFFFF) == "799b54ef"
+    packed = O.lzss_pack(cand, x.size)
+    assert packed.size == 569823 and "%08x" % (zlib.crc32(packed.tobytes()) & 0xFFFFFFFF) == "15c4edd7"
+    assert np.array_equal(O.lzss_decode(packed), x)
+    if O.have_ref_aftercomp():
+        import ctypes
+        buf = np.zeros(x.size + 8192, dtype=np.uint8)
+        m = ctypes.c_int(-1)
+        assert O.ref_aftercomp_lib().aftercompression_wrapper(buf.ctypes.data, x.size, cand.ctypes.data, ctypes.byref(m)) == 1
+        assert m.value == 569823 and np.array_equal(buf[: m.value], packed)

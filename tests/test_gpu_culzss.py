@@ -150,39 +150,7 @@ def test_reference_wrapper_abi(glc, cuda):
     L.deleteGPUStreams()
 
 
-def _synthetic_candidates():
-    """candidate streams (c0 = 1 literal | match length, c1) chosen for the token walk, not produced by a match search:
-    walks from different starts that never fall into step (one length everywhere), jumps of exactly / just under /
-    just over the 64 positions a lane owns, the longest jumps, and random mixtures"""
-    rng = np.random.default_rng(77)
-    n = 16 * 4096
-    out = {}
-
-    def stream(lengths):
-        # as EncodeKernel leaves them: no match crosses the end of its packet (gpu_compress.cu:313-317), and a length
-        # below 3 is a literal
-        room = 4096 - (np.arange(n) % 4096)
-        lengths = np.minimum(lengths.astype(np.int64), room)
-        lengths[lengths <= 2] = 1
-        c = np.empty(2 * n, dtype=np.uint8)
-        c[0::2] = lengths.astype(np.uint8)
-        c[1::2] = rng.integers(0, 256, n, dtype=np.uint8)
-        return c
-
-    for k in (3, 4, 5, 7, 63, 64, 65, 127):
-        out["all_%d" % k] = stream(np.full(n, k, dtype=np.uint8))
-    out["alternate_3_4"] = stream(np.where(np.arange(n) % 2 == 0, 3, 4).astype(np.uint8))
-    out["by_residue"] = stream((3 + (np.arange(n) % 5)).astype(np.uint8))               # a different chain per start
-    mix = rng.integers(3, 128, n).astype(np.uint8)
-    mix[rng.random(n) < 0.3] = 1
-    out["random_mix"] = stream(mix)
-    short = rng.integers(3, 6, n).astype(np.uint8)
-    short[rng.random(n) < 0.1] = 1
-    out["short_mix"] = stream(short)
-    seg = np.full(n, 3, dtype=np.uint8)
-    seg[(np.arange(n) % 64) == 61] = 127                                                 # jumps over whole segments
-    out["jump_over_segments"] = stream(seg)
-    return n, out
+_synthetic_candidates = datagen.lzss_synthetic_candidates
 
 
 def test_token_walk_on_synthetic_candidates(glc, cuda):

@@ -214,3 +214,29 @@ def test_pipelined_calls_across_tiers(glc, ctx, cuda):
         for b in range(nb):
             want = O.compress(batches[c][b * n:(b + 1) * n])
             assert np.array_equal(plain[c][3][b].view(np.uint32), want["words"]), "call %d block %d vs oracle" % (c, b)
+
+
+def test_sample_sorter_first_on_short_blocks_ending_in_zero_bytes(glc, ctx, cuda):
+    """ADVICE.md (round 2): with the sample tier forced (sorter 4) on blocks shorter than 128 bytes a suffix inside
+    the trailing zero bytes can be a splitter; a word and a splitter whose zero-padded first 8 bytes agree and which
+    both end inside them must compare by LENGTH (fs_suffix_less called with k = 8, both past the end)."""
+    import torch
+    rng = np.random.default_rng(4)
+    cases = []
+    for n in (16, 23, 40, 64, 65, 100, 127):
+        for z in (2, 3, 6, 8):
+            x = rng.integers(0, 4, n, dtype=np.uint8)
+            x[n - z:] = 0
+            cases.append(x)
+        cases.append(np.zeros(n, dtype=np.uint8))
+        y = rng.integers(1, 256, n, dtype=np.uint8)
+        y[n - 5:] = 0
+        cases.append(y)
+    for x in cases:
+        n = x.size
+        want, widx = O.bwt(x)
+        with glc.Plan(ctx, glc.CUDPP_BWT, n, rows=1) as plan:
+            for mode in (4, 0, 3):
+                plan.set_sorter(mode)
+                got, gidx = _bwt(glc, plan, torch, x)
+                assert int(gidx[0]) == widx and np.array_equal(got, want), "n %d mode %d: %r" % (n, mode, x.tolist())
