@@ -39,8 +39,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MiB = 1 << 20
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# wave64 VALU instructions per 64 input bytes of the instruction-bound kernels (PMC SQ_INSTS_VALU, round 2, r02o kernels)
-VALU_PER_64 = {"k_fs_sort": 109.5, "k_mtf_encode": 107.4, "k_fs_part": 55.0}
+
+
+def load_pmc_insts():
+    """profiles/pmc_insts.json (profiles/make_pmc_insts.py from tools/exp/pmc_insts.sh): wave64 instructions per 64 input
+    bytes of every kernel (rocprofv3 --pmc SQ_INSTS_VALU / SALU / LDS passes) and the issue rates measured by
+    tools/probes/valu_rate_probe.hip.  Returns (per-kernel table, issue-rate dict, source label)."""
+    path = os.path.join(ROOT, "profiles", "pmc_insts.json")
+    try:
+        j = json.load(open(path))
+        return j["per_64_bytes"], j["issue_rate"], "profiles/pmc_insts.json (offline rocprofv3 --pmc passes, %s)" % j.get("collected", "?")
+    except Exception:
+        return {}, {"slow_class_cycles_per_inst": 4.0, "fast_class_cycles_per_inst": 2.1, "clock_GHz": 2.4}, None
+
 # algorithmic HBM bytes per input byte of the profiled kernels (DESIGN.md section 4)
 ALG_BYTES = {"k_fs_part": 9.0, "k_fs_sort": 9.0, "k_fs_hist": 1.0, "k_mtf_encode": 2.0,
              "k_mtf_chunk_lists+k_mtf_scan_lists": 1.0, "k_huff_pack": None, "k_huff_build": 1.0 / 16,
@@ -668,6 +679,7 @@ def main():
     if rank == 0:
         rho = 1.0 / ratio
         ktab = {}
+        pmc_per64, issue, valu_src = load_pmc_insts()
         for name, k in kernels.items():
             avg = k["ms"] / max(1, k["launches"])
             per_launch_units = k["units"] / max(1, k["launches"])
@@ -678,13 +690,19 @@ def main():
             ktab[name] = {"avg_launch_ms": round(avg, 4), "launches": k["launches"], "alg_bytes_per_input_byte": ab,
                           "achieved_GBps": round(ach, 1) if ach else None,
                           "hbm_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
-            if name in VALU_PER_64 and avg > 0:
-                # these kernels are bound by instruction issue rather than by HBM: wave64 VALU instructions per 64 input
-                # bytes from the PMC passes (SQ_INSTS_VALU; tools/exp/pmc_fs.sh, pmc_mtf.sh); peak = 1024 SIMDs x 2.4 GHz / 4
-                # cycles per wave64 instruction
-                issued = per_launch_units / 64.0 * VALU_PER_64[name] / (avg * 1e-3)
-                ktab[name]["valu_issue_frac"] = round(issued / (1024 * 2.4e9 / 4), 3)
-                ktab[name]["valu_instructions_per_64_bytes"] = VALU_PER_64[name]
+            pk = pmc_per64.get(name)
+            if pk and avg > 0 and pk.get("SQ_INSTS_VALU"):
+                # instruction issue, not HBM, bounds the big kernels: wave64 instructions per 64 input bytes from the
+                # committed PMC passes; issue rates from tools/probes/valu_rate_probe.hip (profiles/*_valu_rate.md): a SIMD
+                # takes 4 cycles per instruction of the "slow" class (DPP, compares, carries, shifts left, min/max,
+                # multiplies, bit-field ops: most of what these kernels execute), ~2.1 for plain add/sub/logic/mov; the
+                # scalar unit issues one instruction per cycle per CU
+                simd_cycles = 1024 * issue["clock_GHz"] * 1e9 * (avg * 1e-3)
+                n64 = per_launch_units / 64.0
+                ktab[name]["valu_issue_frac"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["slow_class_cycles_per_inst"] / simd_cycles, 3)
+                ktab[name]["valu_issue_frac_if_all_fast_class"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["fast_class_cycles_per_inst"] / simd_cycles, 3)
+                ktab[name]["salu_issue_frac"] = round(n64 * pk.get("SQ_INSTS_SALU", 0.0) / (simd_cycles / 4), 3)
+                ktab[name]["instructions_per_64_bytes"] = {"valu": pk["SQ_INSTS_VALU"], "salu": pk.get("SQ_INSTS_SALU"), "lds": pk.get("SQ_INSTS_LDS")}
         dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
         d = ktab.get(dom, {})
         traffic, tsrc = None, None
@@ -740,9 +758,11 @@ def main():
                                                                 * d["alg_bytes_per_input_byte"], 1)
                                                           if dom and d.get("alg_bytes_per_input_byte") else None),
                          "timing": "hipEvent pairs on the launch stream around every launch inside the timed region",
-                         "valu_issue_frac": d.get("valu_issue_frac"),
+                         "valu_issue_frac": d.get("valu_issue_frac"), "salu_issue_frac": d.get("salu_issue_frac"),
+                         "valu_source": valu_src,
                          "note": "dominant = largest summed launch time of the encode pipeline; the per-kernel table is under `kernels`; "
-                                 "`valu_issue_frac` = fraction of the VALU issue rate (the bound that actually holds this kernel)"},
+                                 "`valu_issue_frac` = wave64 VALU instructions (PMC) x 4 cycles / SIMD cycles of the launch: the share of the VALU issue slots "
+                                 "at the 4-cycle rate tools/probes/valu_rate_probe measures for these kernels' instruction mix (the bound that actually holds them)"},
             "kernels": ktab,
             "parity": verify,
         }
