@@ -1,42 +1,65 @@
-"""Builds libglc_amd.so (HIP kernels + the C ABI of include/cudpp.h and
-include/culzss.h) in-tree for gfx950 with hipcc.  No torch dependency: the
-library's boundary is plain pointers and sizes."""
+"""Builds libglc_amd.so (HIP kernels + the C ABI of include/cudpp.h, include/culzss.h and include/glc_hd.h) in-tree for
+gfx950 with hipcc.  No torch dependency: the library's boundary is plain pointers and sizes.
+Sources are compiled to objects in parallel (build/ is git-ignored), an object is reused while it is newer than its
+source and every header; the link step pulls in librccl for the multi-GPU exchange (csrc/exchange.cpp)."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libglc_amd.so")
 SOURCES = ["cudpp_api.cpp", "bwt_sa.hip", "bwt_bucket.hip", "mtf.hip", "huffman.hip", "decode.hip", "culzss.hip",
-           "culzss_api.cpp", "hd_decode.hip", "probe.hip"]
+           "culzss_api.cpp", "hd_decode.hip", "probe.hip", "exchange.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"]
 
 
-def _newest_source_mtime():
+def _header_mtime():
     m = 0.0
-    for f in os.listdir(CSRC):
-        m = max(m, os.path.getmtime(os.path.join(CSRC, f)))
-    inc = os.path.join(os.path.dirname(HERE), "include")
-    for f in os.listdir(inc):
-        m = max(m, os.path.getmtime(os.path.join(inc, f)))
-    return m
+    for d in (CSRC, INC):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return max(m, os.path.getmtime(os.path.abspath(__file__)))
 
 
 def build(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-o", LIB] + srcs
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    os.makedirs(OBJ, exist_ok=True)
+    hm = _header_mtime()
+    jobs = []
+    for s in srcs:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hm, os.path.getmtime(src)):
+            jobs.append((src, obj))
+    if not jobs and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(os.path.join(OBJ, s + ".o")) for s in srcs):
+        return LIB
+
+    def cc(job):
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd))
+        return job[0], subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for src, r in ex.map(cc, jobs):
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError("hipcc failed compiling " + src)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + \
+          [os.path.join(OBJ, s + ".o") for s in srcs] + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libglc_amd.so")
+        raise RuntimeError("hipcc failed linking libglc_amd.so")
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

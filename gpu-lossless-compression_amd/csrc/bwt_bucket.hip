@@ -64,16 +64,28 @@ uint32_t fs_bucket_log2(uint32_t n)
 // and Zipf data puts 10 lanes of 64 on the same symbol
 // ---------------------------------------------------------------------------
 constexpr uint32_t FSH_SLICE = 32768;
+// Text-likeness probe, free of charge inside the histogram pass: two of a thread's eight 16-byte vectors give a
+// 6-gram each (512 samples per 32 KB slice); a sample whose 6-gram another sample of the slice has already put into a
+// 2048-slot LDS table is a REPEAT.  I.i.d. bytes (Zipf(1.0), float data, random) repeat ~0 times per 1 MiB block, text and
+// log lines hundreds to thousands of times: exactly the blocks whose order-0 code is lumpy (a frequent 6-gram = one code
+// shared by thousands of suffixes), which the bucket sorter would flag after a wasted attempt.  k_fs_tables flags a block
+// with FS_DUP_FLAG repeats or more up front: its tiles leave k_fs_part / k_fs_sort / k_fs_ties at once and the sample sorter
+// takes it.  A wrong guess costs time, never correctness (the other way round, the attempt flags the block as before).
+constexpr uint32_t FSH_SLOTS = 2048, FS_DUP_FLAG = 48;
 
 __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
-                                                 uint32_t *__restrict__ hist)
+                                                 uint32_t *__restrict__ hist, uint32_t *__restrict__ dup)
 {
     __shared__ uint32_t s_h[8 * 257];
+    __shared__ uint32_t s_fp[FSH_SLOTS];
+    __shared__ uint32_t s_dup;
     const uint32_t b = blockIdx.y, tid = threadIdx.x;
     const uint32_t lo = blockIdx.x * FSH_SLICE;
     if (lo >= n) return;
     const uint32_t hi = min(n, lo + FSH_SLICE);
     for (uint32_t i = tid; i < 8 * 257; i += 256) s_h[i] = 0;
+    for (uint32_t i = tid; i < FSH_SLOTS; i += 256) s_fp[i] = 0;
+    if (tid == 0) s_dup = 0;
     __syncthreads();
     const uint8_t *T = text + (size_t)b * stride;
     uint32_t *H = s_h + (tid & 7) * 257;
@@ -86,6 +98,15 @@ __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ tex
         for (int r = 0; r < 8; r++) {
             const uint32_t i = r * 256 + tid;
             q[r] = i < nvec ? V[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r += 4) {
+            if (r * 256 + tid < nvec) {
+                // fingerprint of the vector's first six bytes (never 0); equal 6-grams give equal fingerprints and slots
+                const uint32_t fp = (q[r].x * 0x9E3779B1u + (q[r].y & 0xFFFFu) * 0x85EBCA6Bu) | 1u;
+                const uint32_t old = atomicCAS(&s_fp[(fp * 0xC2B2AE35u) >> 21], 0u, fp);
+                if (old == fp) atomicAdd(&s_dup, 1u);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -108,14 +129,17 @@ __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ tex
 #pragma unroll
     for (int k = 0; k < 8; k++) c += s_h[k * 257 + tid];
     if (c) atomicAdd(&hist[(size_t)b * 256 + tid], c);
+    if (tid == 0 && s_dup) atomicAdd(&dup[b], s_dup);
 }
 
 // {C, p} scaled to 2^32.  floor() on both keeps C[s] + p[s] <= C[s+1], which is what makes the code monotone.
 __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ hist, uint32_t n,
-                                                   uint2 *__restrict__ tab)
+                                                   uint2 *__restrict__ tab, const uint32_t *__restrict__ dup,
+                                                   uint32_t *__restrict__ flag)
 {
     __shared__ uint32_t s_tmp[5];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0 && dup[b] >= FS_DUP_FLAG) flag[b] = 1u;       // text-like (see k_fs_hist): straight to the sample sorter
     const uint32_t h = hist[(size_t)b * 256 + tid];
     const uint32_t c = block_excl_add<256>(h, s_tmp);
     const uint64_t C32 = ((uint64_t)c << 32) / n, P32 = ((uint64_t)h << 32) / n;
@@ -202,6 +226,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     __shared__ uint64_t s_w[FSP_TILE];
     __shared__ uint32_t s_tmp[FSP_NT / 64 + 1];
     __shared__ uint16_t s_bk[SPLIT ? FSP_TILE : 1];            // (SPLIT) bucket of the word at a position: not in the word's top bits there
+    __shared__ uint32_t s_flagged;
     // the symbol table and the staged text are dead before the first word is bucketed: they live inside s_w
     // (38 KB instead of 44 KB of LDS: 4 workgroups per CU instead of 3)
     uint2 *s_tab = reinterpret_cast<uint2 *>(s_w);
@@ -218,11 +243,10 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     }
     const uint32_t b = SPLIT ? list[by] : by, tid = threadIdx.x, base = bx * FSP_TILE;
     if (base >= n) return;
-    if (SPLIT) {                                               // given up while sampling: no splitters to search
-        if (tid == 0) s_tmp[0] = flag[b];                      // (one read: other tiles of this launch may flag the block meanwhile)
-        __syncthreads();
-        if (s_tmp[0]) return;
-    }
+    // SPLIT: given up while sampling, no splitters to search; otherwise: flagged up front as text-like (k_fs_tables), or
+    // by a tile of this launch whose bucket overflowed -- the block is another sorter's either way.  One read by one
+    // thread (other tiles of this launch may flag the block meanwhile), looked at behind the staging barrier below.
+    if (tid == 0) s_flagged = flag[b];
     const uint8_t *T = text + (size_t)b * stride;
     uint64_t *s_split = s_w + 1024;                            // (SPLIT) behind the table and the staged text, dead with them
     uint16_t *s_cell = reinterpret_cast<uint16_t *>(s_w + 1024 + FS_MAXNB);
@@ -260,6 +284,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
         }
     }
     __syncthreads();
+    if (s_flagged) return;
     // thread = 8 consecutive suffixes gi0 .. gi0+7; byte j of its 16 staged bytes is T[gi0 - 1 + j]
     const uint32_t k0 = tid * FSP_ITEMS, gi0 = base + k0;
     const uint2 qa = *reinterpret_cast<const uint2 *>(s_txt + k0), qb = *reinterpret_cast<const uint2 *>(s_txt + k0 + 8);
@@ -581,13 +606,15 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
 // (`redo` is a per-call copy of the flags for the stages queued speculatively behind the sort: under stage
 //  pipelining the next call clears `flag` while they may still be reading)
 __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint32_t nblk, uint32_t *__restrict__ lcnt,
-                            uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo, uint32_t *__restrict__ list)
+                            uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo, uint32_t *__restrict__ keep,
+                            uint32_t *__restrict__ list)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nblk) {
         const uint32_t f = flag[b] ? n : 0u;
         lcnt[b] = f;
         redo[b] = f;
+        keep[b] = f ? 0u : 1u;
         if (f) list[atomicAdd(nflag, 1u)] = b;                 // (any order)
     }
 }
@@ -1229,17 +1256,18 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     GLC_TRY(hipMemsetAsync(s.fs_flag, 0, (size_t)nblk * 4, st));
     GLC_TRY(hipMemsetAsync(s.fs_nflag, 0, 8, st));
     GLC_TRY(hipMemsetAsync(s.fs_wlcnt, 0, (size_t)nblk * 4, st));
+    GLC_TRY(hipMemsetAsync(s.fs_dup, 0, (size_t)nblk * 4, st));
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
-                       s.fs_hist);
+                       s.fs_hist, s.fs_dup);
     if (pi >= 0) s.prof->end(pi, units, st);
-    hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab);
+    hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab, s.fs_dup, s.fs_flag);
     if (s.skip_tier1) {
         // most blocks of the plan's previous call were flagged: no attempt, every block goes to the sample sorter
         GLC_TRY(hipMemsetAsync(s.fs_flag, 1, (size_t)nblk * 4, st));
         hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
-                           s.fs_redo[s.parity & 1], s.ss_list);
+                           s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
         return hipGetLastError();
     }
     pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
@@ -1255,7 +1283,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
-                       s.fs_redo[s.parity & 1], s.ss_list);
+                       s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
     return hipGetLastError();
 }
 

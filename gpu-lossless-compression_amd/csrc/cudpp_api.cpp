@@ -299,18 +299,17 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
                                            d_compressed, compressedStrideWords, only);
         if (p->timing) (void)hipEventRecord(p->ev[3], s2);
     };
-    // ... unless most blocks of the plan's previous call were flagged (text-like input tends to stay text-like): then
-    // the speculative pass would be thrown away, and the stages are queued once, after the sort is final.
+    // Blocks the bucket sorter has given up on (flagged up front as text-like, or after its attempt) are skipped by this
+    // speculative pass (`only` = the sorter's keep mask of this call) and encoded below, once their sort is final.
     const bool tiers = p->sa.sorter == 0 || p->sa.sorter == 3 || p->sa.sorter == 4;
-    const bool speculate = !tiers || (!p->sa.expect_flagged && p->sa.sorter != 4);
-    if (speculate) after_sort(tiers ? p->sa.fs_redo[k] : nullptr, nullptr);   // blocks flagged by the bucket sorter are encoded again below
+    const bool speculate = !tiers || p->sa.sorter != 4;
+    if (speculate) after_sort(nullptr, tiers ? p->sa.fs_keep[k] : nullptr);
     uint32_t nflag = 0;
     if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
     if (e == hipSuccess && (nflag || !speculate)) {
-        // sa_build_finish has queued the other sorters for the flagged blocks on st.  Under pipelining the
-        // speculative MTF on s2 may still be reading `bwt` while it is rewritten: harmless, everything that pass
-        // wrote is written again by the pass below, which is ordered after the last sort (ev_sorted).
-        after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr);   // after a speculative pass: only the flagged blocks
+        // sa_build_finish has queued the other sorters for the flagged blocks on st; this pass is ordered after the
+        // last of them (ev_sorted) and touches only those blocks
+        after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr);
     }
     tm.done();
     if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], s2); p->released_valid[k] = true; p->side_busy = true; }

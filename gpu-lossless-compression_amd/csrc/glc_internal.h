@@ -109,6 +109,8 @@ struct SaScratch {
     uint32_t *fs_flag = nullptr;                 // [rows] 1 = a bucket overflowed, 2 = deep (equal codes beyond the depth cap)
     uint32_t *fs_lcnt = nullptr;                 // [rows] n for flagged blocks, 0 otherwise
     uint32_t *fs_redo[2] = {nullptr, nullptr};   // [rows] copies of fs_lcnt, one per call parity (read by the speculative Huffman pass)
+    uint32_t *fs_keep[2] = {nullptr, nullptr};   // [rows] 1 = the bucket sorter finished the block (the speculative stages' `only` mask)
+    uint32_t *fs_dup = nullptr;                  // [rows] repeated 6-grams among the samples k_fs_hist looks at (text-likeness probe)
     uint32_t  parity = 0;                        // set by the caller before sa_build_begin
     uint32_t *fs_nflag = nullptr;                // [1] number of flagged blocks
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
@@ -116,7 +118,6 @@ struct SaScratch {
     uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build the bucket sorter gave up on
     uint32_t  last_general = 0;                  // ... of which the sample sorter gave up on too (general sorter)
-    bool      expect_flagged = false;            // most blocks of the previous call were flagged: no speculative stages behind the sort,
     bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
     // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
     uint32_t *ss_list = nullptr;                 // [rows] their block numbers
