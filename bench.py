@@ -439,6 +439,8 @@ def main():
     free_b, _tot = torch.cuda.mem_get_info(dev)
     if one_device:
         free_b //= world
+    if world > 1:
+        free_b -= 2 * world * nblocks * MiB                   # rank 0 also holds what it gathers (one shot + per batch)
     while rows > 64 and nplans * rows * 60 * MiB > 0.85 * free_b:
         rows //= 2
     plans, streams = [], []
@@ -487,8 +489,60 @@ def main():
             raise RuntimeError("glcCompactStreams -> %d" % rc)
         plan.synchronize()                                    # the compacted streams are complete for any stream
 
+    # the exchange under the C ABI (include/glc_exchange.h: RCCL); over gloo (one-device dry run) the same protocol in torch
+    xch = ex.RcclExchange(glc, torch, dist) if (world > 1 and not one_device) else None
+
     def exchange():
-        return ex.gather_blocks(dist, torch, compact, compact_off, ex.pack_records(torch, out, nblocks, nsub), dst=0)
+        if xch is None:
+            return ex.gather_blocks(dist, torch, compact, compact_off, ex.pack_records(torch, out, nblocks, nsub), dst=0)
+        g = xch.gather(compact, compact_off.data_ptr() + 8 * nblocks, xch.pack_records(out, nblocks, nsub), dst=0)
+        torch.cuda.synchronize(dev)
+        return xch.finish(g)
+
+    def encode_with_batch_gather(root_words, root_records):
+        """the encode with result collection INSIDE: batch k's records + streams leave for rank 0 on a side stream while
+        batch k + 1 encodes ("issued per wave of blocks on a side stream").  Rank 0 receives batch-major:
+        [batch 0: rank 0 | rank 1 | ...][batch 1: ...].  Returns the per-batch gather results (rank 0) for checking."""
+        pl, st_main = plans[0], streams[0]
+        side = torch.cuda.Stream(dev)
+        R = ex.RECORD_FIXED + nsub
+        got, wo, bo, prev, keep = [], 0, 0, None, []       # keep: the record tensors stay allocated until the side stream is done
+
+        def collect(item):
+            nonlocal wo, bo
+            k, b0, nb, ev, rec, offk = item
+            side.wait_event(ev)
+            g = xch.gather(compact[b0 * stride:], offk.data_ptr() + 8 * nb, rec, dst=0, stream=side.cuda_stream,
+                           out_words=root_words[wo:] if root_words is not None else None,
+                           out_records=root_records.view(-1)[bo * R:] if root_records is not None else None)
+            if g is not None:
+                g["first_block"] = b0
+                got.append(g)
+                wo += sum(g["words"]); bo += sum(g["nblk"])
+        for k, b0 in enumerate(batches):
+            nb = min(rows, nblocks - b0)
+            rc = L.glcCompressBatch(pl.handle, d_in.data_ptr() + b0 * n, out["bwt_index"].data_ptr() + 4 * b0,
+                                    out["hist"].data_ptr() + 1024 * b0, out["offsets"].data_ptr() + 4 * nsub * b0, nsub,
+                                    out["size"].data_ptr() + 4 * b0, out["words"].data_ptr() + 4 * stride * b0, stride, n, nb)
+            if rc != 0:
+                raise RuntimeError("glcCompressBatch -> %d" % rc)
+            offk = batch_off[k]
+            rc = L.glcCompactStreams(pl.handle, out["words"].data_ptr() + 4 * stride * b0, stride, out["size"].data_ptr() + 4 * b0,
+                                     nb, compact.data_ptr() + 4 * stride * b0, offk.data_ptr())
+            if rc != 0:
+                raise RuntimeError("glcCompactStreams -> %d" % rc)
+            with torch.cuda.stream(st_main):
+                rec = xch.pack_records(out, nb, nsub, first_block=b0, stream=st_main.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(st_main)
+            if prev is not None:
+                collect(prev)                                      # host waits for batch k - 1's counts; the GPU has batch k queued
+            prev = (k, b0, nb, ev, rec, offk)
+            keep.append(rec)
+        collect(prev)
+        pl.synchronize()
+        side.synchronize()
+        return got
 
     def step():
         # the hot path: every rank encodes its own blocks; nothing crosses GPUs (SURVEY.md 8(e)).
@@ -548,7 +602,8 @@ def main():
         for pl in plans:
             pl.set_pipelining(False)
 
-    # result collection (the one exchange step of the multi-GPU path), timed on its own, then checked on rank 0
+    # result collection (the one exchange step of the multi-GPU path): timed on its own, timed INSIDE the encode
+    # (per batch on a side stream, overlapped with the next batch's encode), then checked on rank 0
     gather_info = None
     if world > 1:
         barrier()
@@ -557,9 +612,53 @@ def main():
         barrier()
         gather_ms = (time.perf_counter() - tg0) * 1e3
         gather_info = {"ms": round(gather_ms, 2),
+                       "backend": "RCCL through the C ABI (glcGatherCounts / glcGatherStreams)" if xch is not None else "gloo, host-staged (one-device dry run)",
                        "what": "all_gather of {blocks, words}, gather of per-block records {size, bwtIndex, hist[256], "
-                               "encodeOffset[256]}, exact-length gather-v of the streams (grouped RCCL send/recv), outside "
-                               "the timed region"}
+                               "encodeOffset[256]}, exact-length gather-v of the streams (grouped RCCL send/recv), one shot "
+                               "after the encode, outside the timed region"}
+        wg_best = None
+        if xch is not None:
+            tot_w = torch.tensor([float(gathered["all_words"].numel() if rank == 0 else 0)], dtype=torch.float64, device=dev)
+            root_words = torch.empty(int(tot_w.item()) + 1024, dtype=torch.int32, device=dev) if rank == 0 else None
+            root_records = torch.empty((nblocks * world, ex.RECORD_FIXED + nsub), dtype=torch.int32, device=dev) if rank == 0 else None
+            batch_off = [torch.empty(rows + 1, dtype=torch.int64, device=dev) for _ in batches]
+            per_batch = None
+            for _ in range(2):
+                barrier()
+                ts = time.perf_counter()
+                per_batch = encode_with_batch_gather(root_words, root_records)
+                barrier()
+                dt = time.perf_counter() - ts
+                wg_best = dt if wg_best is None or dt < wg_best else wg_best
+            if rank == 0 and not args.no_verify:
+                # the batch-major arrays hold the same bytes as the one-shot gather
+                okb = 0
+                for g in per_batch:
+                    g = xch.finish(g)
+                    b0 = g["first_block"]
+                    for r in range(world):
+                        i0 = b0
+                        o = gathered["offsets"][r]
+                        want = gathered["buffers"][r][int(o[i0].item()):int(o[i0 + g["nblk"][r]].item())]
+                        okb += int(torch.equal(g["buffers"][r], want) and torch.equal(g["records"][r], gathered["records"][r][i0:i0 + g["nblk"][r]]))
+                gather_info["per_batch_gather_equals_one_shot"] = "%d/%d (batch, rank) pieces" % (okb, len(per_batch) * world)
+                if okb != len(per_batch) * world:
+                    raise RuntimeError("per-batch gather differs from the one-shot gather")
+            del root_words, root_records
+        else:
+            barrier()
+            ts = time.perf_counter()
+            encode_all()
+            gathered2 = exchange()
+            barrier()
+            wg_best = time.perf_counter() - ts
+            del gathered2
+        twg = torch.tensor([wg_best], dtype=torch.float64, device=dev)
+        dist.all_reduce(twg, op=dist.ReduceOp.MAX)
+        gather_info["value_with_gather_GBps"] = round(float(nblocks) * n * world / float(twg.item()) / 1e9, 4)
+        gather_info["value_with_gather_is"] = ("encode + result collection on rank 0: each batch's records and streams are gathered on a side "
+                                               "stream while the next batch encodes" if xch is not None else
+                                               "encode, then one gather (no overlap: gloo dry run)")
         if rank == 0 and not args.no_verify:
             # (a) gathered == what ONE process produces: rank 0 regenerates sampled blocks of every rank and encodes them
             # (b) rank 0 DECODES gathered blocks of every rank back to the regenerated input
@@ -768,6 +867,8 @@ def main():
         }
         if gather_info is not None:
             res["gather_to_rank0"] = gather_info
+            res["value_with_gather"] = gather_info.get("value_with_gather_GBps")
+            res["gather_ms"] = gather_info["ms"]
 
     # the other configs' single-GPU figures, same run (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.main_only:
@@ -796,6 +897,8 @@ def main():
     if rank == 0:
         print(json.dumps(res))
     pool.shutdown()
+    if xch is not None:
+        xch.close()
     for pl in plans:
         pl.close()
     ctx.close()

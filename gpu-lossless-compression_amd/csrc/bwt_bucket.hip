@@ -602,6 +602,26 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
     }
 }
 
+// everything the pass accumulates into, cleared by ONE launch (six hipMemsetAsync calls were six dispatches of ~2 us with
+// ~8 us between them: 90 us of a 1 MiB call that takes 400)
+__global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__restrict__ hist, uint32_t *__restrict__ fill,
+                                                  uint32_t *__restrict__ flag, uint32_t flag_value, uint32_t *__restrict__ wlcnt,
+                                                  uint32_t *__restrict__ dup, uint32_t *__restrict__ nflag)
+{
+    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + nf + 3u * nblk + 2u;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        if (i < nh) hist[i] = 0;
+        else if (i < nh + nf) fill[i - nh] = 0;
+        else {
+            const uint32_t j = i - nh - nf;
+            if (j < nblk) flag[j] = flag_value;
+            else if (j < 2 * nblk) wlcnt[j - nblk] = 0;
+            else if (j < 3 * nblk) dup[j - 2 * nblk] = 0;
+            else nflag[j - 3 * nblk] = 0;
+        }
+    }
+}
+
 // blocks the fast path gave up on -> live counts for the general sorter
 // (`redo` is a per-call copy of the flags for the stages queued speculatively behind the sort: under stage
 //  pipelining the next call clears `flag` while they may still be reading)
@@ -1251,12 +1271,12 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out)
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
-    GLC_TRY(hipMemsetAsync(s.fs_hist, 0, (size_t)nblk * 256 * 4, st));
-    GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)nblk * FS_MAXNB * 4, st));
-    GLC_TRY(hipMemsetAsync(s.fs_flag, 0, (size_t)nblk * 4, st));
-    GLC_TRY(hipMemsetAsync(s.fs_nflag, 0, 8, st));
-    GLC_TRY(hipMemsetAsync(s.fs_wlcnt, 0, (size_t)nblk * 4, st));
-    GLC_TRY(hipMemsetAsync(s.fs_dup, 0, (size_t)nblk * 4, st));
+    {
+        const uint32_t words = nblk * (256u + FS_MAXNB + 3u) + 2u, g = (words + 1023) / 1024;
+        // (skip_tier1: every block starts flagged -- no attempt, the sample sorter takes them all)
+        hipLaunchKernelGGL(k_fs_clear, dim3(g < 2048 ? g : 2048), dim3(256), 0, st, nblk, s.fs_hist, s.fs_fill, s.fs_flag,
+                           s.skip_tier1 ? 1u : 0u, s.fs_wlcnt, s.fs_dup, s.fs_nflag);
+    }
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
@@ -1265,7 +1285,6 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab, s.fs_dup, s.fs_flag);
     if (s.skip_tier1) {
         // most blocks of the plan's previous call were flagged: no attempt, every block goes to the sample sorter
-        GLC_TRY(hipMemsetAsync(s.fs_flag, 1, (size_t)nblk * 4, st));
         hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
                            s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
         return hipGetLastError();

@@ -12,10 +12,14 @@ no data-path collective.  What crosses GPUs is result collection on a root and, 
   scatter_blocks  the mirror: the root sends every rank its records and its words; each rank then expands them
                   (glcExpandStreams) and decodes its own blocks independently (glcDecompressBatch).
 
-`backend="nccl"` is RCCL on ROCm; with gloo everything is staged through host tensors, which is how the logic is
-covered on CPU (tests/test_dist_gather.py, world_size 2) and on a one-GPU box (tests/test_gpu_dist.py).
-The device-side preparation is in the C ABI: glcCompactStreams / glcExpandStreams (include/cudpp.h).
+The exchange itself is in the C ABI (include/glc_exchange.h, csrc/exchange.cpp: glcGatherCounts / glcGatherStreams /
+glcScatterStreams over RCCL, device-side preparation glcCompactStreams / glcExpandStreams / glcPackRecords); `RcclExchange`
+below is its caller and what bench.py uses when every rank has its own GPU.  RCCL refuses two ranks on one device and
+does not exist on a CPU box, so the SAME protocol is also written over torch.distributed point-to-point operations
+(gather_blocks / scatter_blocks: gloo, host-staged) -- that is how the logic is covered by tests/test_dist_gather.py
+(world_size 2, CPU) and tests/test_gpu_dist.py (two processes on one MI355X).
 """
+import ctypes as C
 
 RECORD_FIXED = 2 + 256          # compressedSize, bwtIndex, hist[256]; followed by encodeOffset[nsub]
 
@@ -150,11 +154,111 @@ def block_of(gathered, g):
     return gathered["buffers"][r][int(o[i].item()):int(o[i + 1].item())], gathered["records"][r][i]
 
 
-# kept for callers of the first round's interface: totals + streams only
-def gather_streams(dist, torch, compact, compact_off, dst=0):
-    nblk = compact_off.numel() - 1
-    sizes = (compact_off[1:] - compact_off[:-1]).to(torch.int32).view(nblk, 1)
-    res = gather_blocks(dist, torch, compact, compact_off, sizes, dst)
-    if res is None:
-        return None
-    return {"total_words": sum(res["words"]), "per_rank_words": res["words"], "buffers": res["buffers"]}
+class RcclExchange:
+    """Caller of the C-ABI exchange (include/glc_exchange.h).  One communicator per process; the unique id travels over
+    torch.distributed (any backend) when the process group has more than one rank.  Results have the shape of
+    gather_blocks / scatter_blocks so that callers can use either."""
+
+    def __init__(self, glc, torch, dist=None):
+        self.L, self.torch = glc.lib(), torch
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            self._chk(self.L.glcCommGetUniqueId(uid.numpy().ctypes.data), "glcCommGetUniqueId")
+        if self.world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = uid.to(dev)
+            dist.broadcast(t, 0)
+            uid = t.cpu()
+        self.comm = C.c_void_p(0)
+        self._chk(self.L.glcCommInitRank(C.byref(self.comm), self.world, uid.numpy().ctypes.data, self.rank), "glcCommInitRank")
+        self.counts = (C.c_ulonglong * (2 * self.world))()
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise RuntimeError("%s -> %d" % (what, rc))
+
+    def close(self):
+        if self.comm:
+            self.L.glcCommDestroy(self.comm)
+            self.comm = C.c_void_p(0)
+
+    def pack_records(self, out, nblk, nsub, first_block=0, stream=None):
+        """device records [nblk, 258 + nsub] of blocks first_block .. first_block + nblk of glcCompressBatch's outputs"""
+        torch = self.torch
+        rec = torch.empty((nblk, RECORD_FIXED + nsub), dtype=torch.int32, device=out["size"].device)
+        b = first_block
+        self._chk(self.L.glcPackRecords(out["bwt_index"].data_ptr() + 4 * b, out["hist"].data_ptr() + 1024 * b,
+                                        out["offsets"].data_ptr() + 4 * nsub * b, nsub, out["size"].data_ptr() + 4 * b, nsub, nblk,
+                                        rec.data_ptr(), stream), "glcPackRecords")
+        return rec
+
+    def gather(self, compact, nwords_dev, records, dst=0, stream=None, out_words=None, out_records=None):
+        """compact: int32 tensor holding this rank's streams back to back from its start; nwords_dev: device pointer to
+        their word count (the last offset glcCompactStreams wrote); records: int32 [nblk, R].  On dst returns the
+        gather_blocks dict (buffers / records are views of two rank-ordered arrays), None elsewhere.  Waits once (the
+        counts); the transfers are only enqueued on `stream`."""
+        torch = self.torch
+        nblk, R = int(records.shape[0]), int(records.shape[1])
+        self._chk(self.L.glcGatherCounts(self.comm, nblk, 0, nwords_dev, self.counts, stream), "glcGatherCounts")
+        nblks = [int(self.counts[2 * r]) for r in range(self.world)]
+        words = [int(self.counts[2 * r + 1]) for r in range(self.world)]
+        allw = allr = None
+        if self.rank == dst:
+            allw = out_words if out_words is not None else torch.empty(max(1, sum(words)), dtype=torch.int32, device=compact.device)
+            allr = out_records if out_records is not None else torch.empty((max(1, sum(nblks)), R), dtype=torch.int32, device=compact.device)
+            if allw.numel() < sum(words) or allr.numel() < sum(nblks) * R:
+                raise RuntimeError("gather: receive buffers too small")
+        self._chk(self.L.glcGatherStreams(self.comm, dst, compact.data_ptr(), records.data_ptr(), R, self.counts,
+                                          allw.data_ptr() if allw is not None else None,
+                                          allr.data_ptr() if allr is not None else None, stream), "glcGatherStreams")
+        if self.rank != dst:
+            return None
+        bufs, recs, offs, wo, bo = [], [], [], 0, 0
+        flat = allr.view(-1)
+        for r in range(self.world):
+            bufs.append(allw[wo:wo + words[r]])
+            recs.append(flat[bo * R:(bo + nblks[r]) * R].view(nblks[r], R))
+            wo += words[r]; bo += nblks[r]
+        return {"nblk": nblks, "words": words, "buffers": bufs, "records": recs, "offsets": None,
+                "all_words": allw, "all_records": allr, "counts": list(self.counts)}
+
+    def finish(self, gathered, stream_sync=True):
+        """after the stream has run: per-rank word offsets from the record sizes (checked against the counts)"""
+        torch = self.torch
+        if gathered is None or gathered["offsets"] is not None:
+            return gathered
+        offs = []
+        for r in range(self.world):
+            o = torch.zeros(gathered["nblk"][r] + 1, dtype=torch.int64, device=gathered["all_words"].device)
+            if gathered["nblk"][r]:
+                o[1:] = torch.cumsum(gathered["records"][r][:, 0].to(torch.int64), 0)
+            if int(o[-1].item()) != gathered["words"][r]:
+                raise RuntimeError("rank %d: record sizes (%d words) do not add up to the gathered stream (%d words)"
+                                   % (r, int(o[-1].item()), gathered["words"][r]))
+            offs.append(o)
+        gathered["offsets"] = offs
+        return gathered
+
+    def scatter(self, gathered, counts, R, src=0, stream=None, device=None):
+        """the mirror: every rank gets (compact words, int64 offsets, records) of ITS blocks.  `counts`: the list the
+        gather produced (known on every rank: glcGatherCounts is an all-gather)."""
+        torch = self.torch
+        cnt = (C.c_ulonglong * (2 * self.world))(*counts)
+        nblk, total = int(cnt[2 * self.rank]), int(cnt[2 * self.rank + 1])
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        buf = torch.empty(max(1, total), dtype=torch.int32, device=device)
+        rec = torch.empty((max(1, nblk), R), dtype=torch.int32, device=device)
+        aw = gathered["all_words"].data_ptr() if gathered is not None else None
+        ar = gathered["all_records"].data_ptr() if gathered is not None else None
+        self._chk(self.L.glcScatterStreams(self.comm, src, aw, ar, R, cnt, buf.data_ptr(), rec.data_ptr(), stream), "glcScatterStreams")
+        if stream is None:
+            torch.cuda.synchronize(device)
+        rec, buf = rec[:nblk], buf[:total]
+        off = torch.zeros(nblk + 1, dtype=torch.int64, device=device)
+        if nblk:
+            off[1:] = torch.cumsum(rec[:, 0].to(torch.int64), 0)
+        return buf, off, rec

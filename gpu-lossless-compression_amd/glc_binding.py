@@ -49,6 +49,8 @@ CULZSS_SYMBOLS = [
     "glcLzssWorkBytes", "culzss_container_bound", "culzss_container_compress", "culzss_container_decompress",
     "culzss_compress_file", "culzss_decompress_file",
 ]
+EXCHANGE_SYMBOLS = ["glcCommGetUniqueId", "glcCommInitRank", "glcCommAdopt", "glcCommDestroy", "glcCommInfo", "glcPackRecords",
+                    "glcUnpackRecords", "glcGatherCounts", "glcGatherStreams", "glcScatterStreams"]
 HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice", "glcHdDecodeDeviceTable"]
 
 
@@ -164,6 +166,20 @@ def lib():
         L.glcHdDecodeDevice.restype = C.c_int
         L.glcHdDecodeDeviceTable.argtypes = [vp, sz, vp, vp, sz, vp, vp]
         L.glcHdDecodeDeviceTable.restype = C.c_int
+    if hasattr(L, "glcGatherStreams"):                             # include/glc_exchange.h
+        ullp = C.POINTER(C.c_ulonglong)
+        L.glcCommGetUniqueId.argtypes = [vp]
+        L.glcCommInitRank.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int]
+        L.glcCommAdopt.argtypes = [C.POINTER(vp), vp]
+        L.glcCommDestroy.argtypes = [vp]
+        L.glcCommInfo.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.glcPackRecords.argtypes = [vp, vp, vp, sz, vp, sz, sz, vp, vp]
+        L.glcUnpackRecords.argtypes = [vp, sz, sz, vp, vp, vp, sz, vp, vp]
+        L.glcGatherCounts.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, vp, ullp, vp]
+        L.glcGatherStreams.argtypes = [vp, C.c_int, vp, vp, sz, ullp, vp, vp, vp]
+        L.glcScatterStreams.argtypes = [vp, C.c_int, vp, vp, sz, ullp, vp, vp, vp]
+        for name in EXCHANGE_SYMBOLS:
+            getattr(L, name).restype = C.c_int
     _lib = L
     return L
 

@@ -186,13 +186,13 @@ def test_lzss_last_chunk_quirks():
 # ---------------------------------------------------------------- C ABI -----
 def test_library_exports_every_declared_symbol(glc):
     L = glc.lib()
-    missing = [s for s in glc.CUDPP_SYMBOLS + glc.CULZSS_SYMBOLS + glc.HD_SYMBOLS if not hasattr(L, s)]
+    missing = [s for s in glc.CUDPP_SYMBOLS + glc.CULZSS_SYMBOLS + glc.HD_SYMBOLS + glc.EXCHANGE_SYMBOLS if not hasattr(L, s)]
     assert not missing, missing
     # every function declared in the headers is in the binding's symbol lists
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for hdr, syms in (("cudpp.h", glc.CUDPP_SYMBOLS), ("culzss.h", glc.CULZSS_SYMBOLS),
-                      ("glc_hd.h", glc.HD_SYMBOLS)):
+                      ("glc_hd.h", glc.HD_SYMBOLS), ("glc_exchange.h", glc.EXCHANGE_SYMBOLS)):
         text = open(os.path.join(root, "include", hdr)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)) - {"defined", "sizeof"}

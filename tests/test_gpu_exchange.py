@@ -1,0 +1,76 @@
+"""The C-ABI exchange (include/glc_exchange.h, csrc/exchange.cpp) on real RCCL (-m gpu).  A one-GPU box can only form a
+communicator of ONE rank (RCCL refuses two ranks on a device), so this runs the whole call sequence a rank of the
+multi-GPU path makes -- unique id, ncclCommInitRank, glcPackRecords, glcGatherCounts (ncclAllGather), glcGatherStreams,
+glcScatterStreams, glcUnpackRecords -- with world size 1: the non-staged device-pointer path, the count exchange, the
+root's own share, and the layouts; the two-rank protocol itself is covered over gloo by tests/test_gpu_dist.py and
+tests/test_dist_gather.py."""
+import ctypes as C
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 1 << 18
+
+
+def _dist_mod():
+    spec = importlib.util.spec_from_file_location("glc_dist", os.path.join(ROOT, "gpu-lossless-compression_amd", "dist_gather.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["glc_dist"] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_exchange_world_of_one_through_the_c_abi(glc, cuda):
+    import torch
+    ex = _dist_mod()
+    L = glc.lib()
+    nblk, nsub, stride = 5, N // 4096, glc.compressed_stride_words(N)
+    x = np.concatenate([datagen.float_bytes(N, seed=70 + i) for i in range(3)] + [datagen.text_bytes(N, seed=3), datagen.zipf_bytes(N, seed=4)])
+    d_in = torch.from_numpy(x).to(cuda)
+    xch = ex.RcclExchange(glc, torch, None)
+    nr, rk = C.c_int(-1), C.c_int(-1)
+    assert L.glcCommInfo(xch.comm, C.byref(nr), C.byref(rk)) == 0 and (nr.value, rk.value) == (1, 0)
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, N, rows=nblk) as plan:
+        out = glc.compress_batch(plan, d_in, N, nblk)
+        compact = torch.empty(nblk * stride, dtype=torch.int32, device=cuda)
+        off = torch.empty(nblk + 1, dtype=torch.int64, device=cuda)
+        assert L.glcCompactStreams(plan.handle, out["words"].data_ptr(), stride, out["size"].data_ptr(), nblk,
+                                   compact.data_ptr(), off.data_ptr()) == 0
+        plan.synchronize()
+        rec = xch.pack_records(out, nblk, nsub)                       # glcPackRecords
+        torch.cuda.synchronize()
+        assert torch.equal(rec, ex.pack_records(torch, out, nblk, nsub))
+        g = xch.gather(compact, off.data_ptr() + 8 * nblk, rec, dst=0)   # counts from the device word count
+        torch.cuda.synchronize()
+        g = xch.finish(g)
+        total = int(off[nblk].item())
+        assert g["nblk"] == [nblk] and g["words"] == [total]
+        assert torch.equal(g["buffers"][0], compact[:total]) and torch.equal(g["records"][0], rec)
+        assert torch.equal(g["offsets"][0], off)
+        buf, boff, brec = xch.scatter(g, g["counts"], rec.shape[1], src=0)
+        assert torch.equal(buf, compact[:total]) and torch.equal(brec, rec) and torch.equal(boff, off)
+        # decode from what came back: glcUnpackRecords + glcExpandStreams + glcDecompressBatch
+        idx = torch.empty(nblk, dtype=torch.int32, device=cuda)
+        hist = torch.empty(nblk * 256, dtype=torch.int32, device=cuda)
+        offs = torch.empty(nblk * nsub, dtype=torch.int32, device=cuda)
+        size = torch.empty(nblk, dtype=torch.int32, device=cuda)
+        assert L.glcUnpackRecords(brec.data_ptr(), nsub, nblk, idx.data_ptr(), hist.data_ptr(), offs.data_ptr(), nsub,
+                                  size.data_ptr(), None) == 0
+        strided = torch.zeros(nblk * stride, dtype=torch.int32, device=cuda)
+        assert L.glcExpandStreams(plan.handle, buf.data_ptr(), boff.data_ptr(), nblk, strided.data_ptr(), stride, None) == 0
+        back = glc.decompress_batch(plan, dict(bwt_index=idx, hist=hist, offsets=offs, words=strided, nsub=nsub, stride=stride), N, nblk)
+        plan.synchronize()
+        assert torch.equal(size, out["size"]) and torch.equal(back, d_in)
+    # argument checks of the ABI
+    cnt = (C.c_ulonglong * 2)(1, 1)
+    assert L.glcGatherStreams(None, 0, None, None, 514, cnt, None, None, None) == glc.CUDPP_ERROR_INVALID_HANDLE
+    assert L.glcGatherStreams(xch.comm, 3, None, None, 514, cnt, None, None, None) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
+    assert L.glcGatherStreams(xch.comm, 0, None, None, 514, cnt, None, None, None) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
+    xch.close()
