@@ -66,6 +66,66 @@ def _load(name, path):
     return mod
 
 
+def kernel_table(getter, alg_bytes, pmc_per64, issue, traffic_tab=None, blocks_in_traffic=256.0, unit_bytes=float(MiB)):
+    """getter(i) -> (name, ms, launches, units) or None past the last slot.  Per kernel: average launch time (hipEvent pairs on
+    the launch stream), algorithmic bytes per launch and the HBM fraction they give, instruction-issue fractions where
+    the committed PMC summary has the kernel, HBM traffic per launch where profiles/pmc_traffic.json has it."""
+    tab, i = {}, 0
+    while True:
+        r = getter(i)
+        i += 1
+        if r is None:
+            break
+        name, ms, launches, units = r
+        if launches <= 0:
+            continue
+        avg = ms / launches
+        per_launch = units / launches
+        ab = alg_bytes.get(name)
+        ach = per_launch * ab / (avg * 1e-3) / 1e9 if (ab and avg > 0) else None
+        e = {"avg_launch_ms": round(avg, 4), "launches": int(launches), "alg_bytes_per_input_byte": ab,
+             "algorithmic_bytes_per_launch": round(per_launch * ab, 1) if ab else None,
+             "achieved_GBps": round(ach, 1) if ach else None, "hbm_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
+        pk = None
+        for key in name.split("+"):
+            if key in pmc_per64:
+                q = pmc_per64[key]
+                pk = q if pk is None else {c: pk.get(c, 0) + q.get(c, 0) for c in set(pk) | set(q) if isinstance(q.get(c, 0), (int, float))}
+        if pk and avg > 0 and pk.get("SQ_INSTS_VALU"):
+            simd_cycles = 1024 * issue["clock_GHz"] * 1e9 * (avg * 1e-3)
+            n64 = per_launch / 64.0
+            e["valu_issue_frac"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["slow_class_cycles_per_inst"] / simd_cycles, 3)
+            e["salu_issue_frac"] = round(n64 * pk.get("SQ_INSTS_SALU", 0.0) / (simd_cycles / 4), 3)
+            e["instructions_per_64_bytes"] = {"valu": round(pk["SQ_INSTS_VALU"], 1), "salu": round(pk.get("SQ_INSTS_SALU", 0), 1),
+                                              "lds": round(pk.get("SQ_INSTS_LDS", 0), 1)}
+        if traffic_tab:
+            t = sum(traffic_tab.get(key, 0) for key in name.split("+"))
+            if t:
+                e["traffic"] = int(round(t * (per_launch / unit_bytes) / blocks_in_traffic))
+        tab[name] = e
+    return tab
+
+
+def roofline_of(tab, note):
+    """the `roofline` object of a kernel table: its dominant kernel (largest summed launch time)"""
+    if not tab:
+        return None
+    dom = max(tab, key=lambda k: tab[k]["avg_launch_ms"] * tab[k]["launches"])
+    d = tab[dom]
+    return {"kernel": "glc::" + dom, "bound": "hbm", "achieved": d.get("achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": d.get("hbm_frac"), "traffic": d.get("traffic"), "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+            "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"), "valu_issue_frac": d.get("valu_issue_frac"),
+            "timing": "hipEvent pairs on the launch stream around every launch", "note": note}
+
+
+def load_traffic():
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return tj.get("hbm_bytes_per_launch", {}), float(tj.get("blocks_per_launch", 256)), tj.get("collected", "?")
+    except Exception:
+        return {}, 256.0, None
+
+
 def zipf_blocks_on_device(torch, dev, nblocks, first_global_block, stride_blocks, seed=0x5EED0002):
     """Zipf(1.0) bytes over 256 symbols, identity symbol permutation.  Block g of the global stream is generated
     from seed+g so any rank / any N produces the same bytes."""
@@ -282,6 +342,19 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
     ms_enc, ms_dec = timed(enc), timed(dec)
     if not torch.equal(d_out, d_in):
         raise RuntimeError("CULZSS round trip failed")
+    # per-kernel launch times (library-side hipEvent pairs on the launch stream), one more pass of each
+    L.glcLzssEnableProfile(1)
+    for _ in range(iters):
+        enc(); dec()
+    torch.cuda.synchronize()
+
+    def lz_get(i):
+        import ctypes
+        nm, o3 = ctypes.create_string_buffer(96), (ctypes.c_double * 3)()
+        if L.glcLzssKernelProfile(i, nm, 96, o3) != 1:
+            return None
+        return nm.value.decode(), o3[0], o3[1], o3[2]
+    pmc_per64, issue, _src = load_pmc_insts()
     sizes = d_sizes.cpu().numpy().astype(np.int64)
     raw = int((sizes == 0).sum())
     comp_bytes = int(sizes.sum()) + raw * MiB
@@ -296,10 +369,37 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
         raise RuntimeError("CULZSS parity failure in bench sample")
     total = nbuf * MiB
     rho = comp_bytes / total
+    ktab = kernel_table(lz_get, {"k_lzss_match": 3.0, "k_lzss_pack_wave+k_lzss_pack": 2.0 + rho,
+                                 "k_lzss_layout+k_lzss_gather": 2.0 * rho, "k_lzss_decode": 1.0 + rho}, pmc_per64, issue)
+    L.glcLzssEnableProfile(0)
+    # the reference's wrapper ABI as culzss.c drives it (host pointers: H2D of the buffer, kernels, D2H of the 2 B/B
+    # candidate stream, packing, D2H of the packed bytes): PCIe inclusive, never `value`
+    import ctypes
+    L.initGPU()
+    buf, bufout = L.initCPUmem(MiB), L.initCPUmem(2 * MiB)
+    in_d, out_d = L.initGPUmem(MiB), L.initGPUmem(2 * MiB)
+    nwrap, nn = 32, ctypes.c_int(0)
+    for i in range(nwrap + 4):
+        if i == 4:
+            tw0 = time.perf_counter()
+        ctypes.memmove(buf, host[(i % uniq) * MiB:].ctypes.data, MiB)
+        L.compression_kernel_wrapper(buf, MiB, bufout, 0, 0, 128, 0, i % 4, in_d, out_d)
+        L.onestream_finish_GPU(i % 4)
+        L.aftercompression_wrapper(buf, MiB, bufout, ctypes.byref(nn))
+    wrap_s = (time.perf_counter() - tw0) / nwrap
+    L.deleteCPUmem(buf); L.deleteCPUmem(bufout); L.deleteGPUmem(in_d); L.deleteGPUmem(out_d)
+    L.deleteGPUStreams()
     return {"workload": "configs[2]: %g GiB log-style ASCII (%d MiB unique, tiled), 1 MiB buffers, 4096-B packets, 128-B window, "
                         "device resident (glcLzssEncodeDevice / glcLzssDecodeDevice)" % (gib, uniq),
             "encode_GBps": round(total / ms_enc / 1e6, 3), "decode_GBps": round(total / ms_dec / 1e6, 3),
             "encode_ms": round(ms_enc, 3), "decode_ms": round(ms_dec, 3), "timing": "median of %d, hipEvents on the launch stream" % iters,
+            "encode_with_pcie_staging_GBps": round(MiB / wrap_s / 1e9, 4),
+            "encode_with_pcie_staging_is": "the reference's host-pointer wrapper ABI, one 1 MiB buffer at a time as culzss.c:85-176 drives it "
+                                           "(compression_kernel_wrapper + onestream_finish_GPU + aftercompression_wrapper): H2D 1 B/B, "
+                                           "D2H 2 B/B of candidates + the packed bytes; %d calls" % nwrap,
+            "roofline": roofline_of(ktab, "k_lzss_match: 1 R + 2 W algorithmic bytes per input byte (the candidate stream is part of the "
+                                          "reference's interface); bound by VALU issue (127 window compares per input byte), see `valu`"),
+            "kernels": ktab,
             "compression_ratio": round(1.0 / rho, 4), "raw_stored_buffers": raw,
             "hbm_frac": {"encode": round((1 + rho) * total / ms_enc / 1e6 / HBM_PEAK_GBPS, 5),
                          "decode": round((1 + rho) * total / ms_dec / 1e6 / HBM_PEAK_GBPS, 5),
@@ -344,6 +444,20 @@ def leg_hd(torch, glc, dev, mib, iters=5):
         e0.record(st); dec(); e1.record(st); torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
     m = statistics.median(ms)
+    L.glcHdEnableProfile(1)
+    for _ in range(iters):
+        dec()
+    torch.cuda.synchronize()
+
+    def hd_get(i):
+        import ctypes
+        nm, o3 = ctypes.create_string_buffer(96), (ctypes.c_double * 3)()
+        if L.glcHdKernelProfile(i, nm, 96, o3) != 1:
+            return None
+        return nm.value.decode(), o3[0], o3[1], o3[2]
+    rho_hd = units.size * 4.0 / n
+    hd_tab = kernel_table(hd_get, {"k_hd_span_functions": rho_hd, "k_hd_walk x3": None, "k_hd_emit": rho_hd + 1.0}, {}, {})
+    L.glcHdEnableProfile(0)
     ns = min(n, 16 << 20)
     su = glc.hd_encode_host(data[:ns], lens, codes)
     t0 = time.perf_counter()
@@ -354,6 +468,9 @@ def leg_hd(torch, glc, dev, mib, iters=5):
                         "32-bit units, glcHdDecodeDevice" % mib,
             "decode_GBps": round(n / m / 1e6, 3), "ms": round(m, 3), "units": int(units.size), "ratio": round(n / comp, 4),
             "hbm_frac": round((comp + n) / m / 1e6 / HBM_PEAK_GBPS, 5), "algorithmic_bytes": "rho R + 1 W per decoded byte",
+            "roofline": roofline_of(hd_tab, "the stream is read twice (span functions, then emit) and the symbols written once; "
+                                            "LDS table look-ups per code bound both kernels"),
+            "kernels": hd_tab,
             "decoded_equals_original": True, "timing": "median of %d, hipEvents" % iters,
             "cpu_port": {"value": round(ns / t_cpu / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
                          "sample": "%d MiB bit-serial oracle decode" % (ns >> 20)}}
@@ -365,7 +482,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gib", type=float, default=4.0, help="input per GPU (GiB)")
-    ap.add_argument("--rows", type=int, default=1024, help="blocks per batched call (plan rows); 47 MiB of plan scratch per row")
+    ap.add_argument("--rows", type=int, default=1024, help="blocks per batched call (plan rows); ~22 MiB of encoder scratch per row")
     ap.add_argument("--plans", type=int, default=3, help="plans (each with its own stream) per GPU")
     ap.add_argument("--enc-threads", type=int, default=1, help="host threads (= plans) used by the timed encode leg")
     ap.add_argument("--dec-threads", type=int, default=3, help="host threads (= plans) used by the decode leg")
@@ -434,14 +551,15 @@ def main():
     compact_off = torch.empty(nblocks + 1, dtype=torch.int64, device=dev)
     ctx = glc.Cudpp()
     nplans = max(1, args.plans)
-    # a plan's scratch is ~47 MiB per row for the encoder and ~9.5 MiB for the decoder (allocated on first decode): batches
-    # shrink if the device does not have that much free (e.g. several ranks sharing one device in a dry run)
+    # a plan's scratch is ~22 MiB per row for the encoder (the general sorter's 24.6 MiB per row are allocated only if a block
+    # ever gets that far) and ~9.5 MiB for the decoder (allocated on first decode): batches shrink if the device does not
+    # have that much free (e.g. several ranks sharing one device in a dry run)
     free_b, _tot = torch.cuda.mem_get_info(dev)
     if one_device:
         free_b //= world
     if world > 1:
         free_b -= 2 * world * nblocks * MiB                   # rank 0 also holds what it gathers (one shot + per batch)
-    while rows > 64 and nplans * rows * 60 * MiB > 0.85 * free_b:
+    while rows > 64 and nplans * rows * 36 * MiB > 0.85 * free_b:
         rows //= 2
     plans, streams = [], []
     for _ in range(nplans):
@@ -729,6 +847,7 @@ def main():
         pl.set_pipelining(False)
     d_back1 = torch.empty(rows * n, dtype=torch.uint8, device=dev)
     plan.synchronize()
+    plan.enable_timing(3)                                     # per-kernel hipEvent pairs for the decoder's roofline block
     t0d = time.perf_counter()
     nrep = min(4, len(batches))
     for b0 in batches[:nrep]:
@@ -738,6 +857,8 @@ def main():
                              d_back1.data_ptr(), n, nb)
     plan.synchronize()
     dec1 = sum(min(rows, nblocks - b0) for b0 in batches[:nrep]) * n / (time.perf_counter() - t0d) / 1e9
+    dec_prof = plan.kernel_profiles()
+    plan.enable_timing(0)
     del d_back1
     dec_elapsed = torch.tensor([td1 - td0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -802,6 +923,25 @@ def main():
                 ktab[name]["valu_issue_frac_if_all_fast_class"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["fast_class_cycles_per_inst"] / simd_cycles, 3)
                 ktab[name]["salu_issue_frac"] = round(n64 * pk.get("SQ_INSTS_SALU", 0.0) / (simd_cycles / 4), 3)
                 ktab[name]["instructions_per_64_bytes"] = {"valu": pk["SQ_INSTS_VALU"], "salu": pk.get("SQ_INSTS_SALU"), "lds": pk.get("SQ_INSTS_LDS")}
+        # decoder: per-kernel table of the one-plan pass (stages back to back) and its dominant kernel
+        dec_names = [k for k in dec_prof if k.startswith(("k_dec", "k_imtf", "k_ibwt"))]
+        dec_alg = {"k_dec_prepare+k_dec_huff": rho + 1.0, "k_imtf_pos": 2.0, "k_imtf_scan+k_imtf_apply": 2.0,
+                   "k_ibwt_hist+k_rs_scan+k_ibwt_lf": 2.0 + 4.0, "k_ibwt_walk": 4.0 + 1.0, "k_ibwt_rank+k_ibwt_emit": 2.0}
+
+        def dec_get(i):
+            if i >= len(dec_names):
+                return None
+            k = dec_prof[dec_names[i]]
+            return dec_names[i], k["ms"], k["launches"], k["units"]
+        dec_pmc = dict(pmc_per64)
+        dec_pmc["k_dec_huff"] = pmc_per64.get("k_dec_huff_lanes", {})
+        dtab = kernel_table(dec_get, dec_alg, dec_pmc, issue)
+        decode_block = {"one_plan_GBps": round(dec1, 4), "pipelined_plans_GBps": round(decode_gbps, 4),
+                        "hbm_frac_algorithmic_rho_plus_1": round((1 + rho) * dec1 / HBM_PEAK_GBPS, 6),
+                        "roofline": roofline_of(dtab, "one plan, stages back to back; algorithmic bytes of the walk = one 4-byte LF entry read + 1 byte "
+                                                      "emitted per symbol; the walk is a dependent random access per output byte (bound: random-access "
+                                                      "rate of L2 / HBM, not streaming bandwidth), k_imtf_pos by VALU issue + LDS"),
+                        "kernels": dtab}
         dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
         d = ktab.get(dom, {})
         traffic, tsrc = None, None
@@ -845,6 +985,7 @@ def main():
             "value_stage_overlap_GBps": round(overlap_gbps, 4) if overlap_gbps else None,
             "decode_GBps": round(decode_gbps, 4),
             "decode_one_plan_GBps": round(dec1, 4),
+            "decode": decode_block,
             "roundtrip": "decode(encode(x)) == x on all %d blocks per GPU" % nblocks,
             "frac_of_hbm_read_roofline": round(value / world / HBM_PEAK_GBPS, 6),
             "frac_of_hbm_roofline_algorithmic_1_plus_rho": round((1 + rho) * value / world / HBM_PEAK_GBPS, 6),

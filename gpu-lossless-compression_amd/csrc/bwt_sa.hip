@@ -842,20 +842,39 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     s.fs_wl_cap = nmax / 8 < 1024 ? 1024 : nmax / 8;
     GLC_TRY(A((void **)&s.fs_wl, (size_t)rows * s.fs_wl_cap * 16));
     GLC_TRY(A((void **)&s.fs_wlcnt, (size_t)rows * 4));
-    GLC_TRY(A((void **)&s.posA, ne * 4)); GLC_TRY(A((void **)&s.posB, ne * 4));
-    GLC_TRY(A((void **)&s.isa, ne * 4));  GLC_TRY(A((void **)&s.sa, ne * 4));
-    GLC_TRY(A((void **)&s.tile_hist, (size_t)rows * s.rs_tiles * SA_MAXRADIX * 4));
+    // (posA/B, hdA/B, isa, sa, tile_hist, tile_state -- 24.6 MiB per 1 MiB block, used by the general sorter alone --
+    //  are allocated by sa_general_reserve the first time a block gets that far)
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * RS_MAXPASS * SA_MAXRADIX * 4));
     GLC_TRY(A((void **)&s.ghist, (size_t)rows * RS_MAXPASS * SA_MAXRADIX * 4));
-    GLC_TRY(A((void **)&s.tile_state, (size_t)rows * s.max_tiles * 8));
     GLC_TRY(A((void **)&s.ticket, (size_t)rows * 4));
-    GLC_TRY(A((void **)&s.hdA, ne * 4)); GLC_TRY(A((void **)&s.hdB, ne * 4));
     GLC_TRY(A((void **)&s.cntA, (size_t)rows * 4)); GLC_TRY(A((void **)&s.cntB, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.d_max_cnt, 16));
     GLC_TRY(A((void **)&s.rl_flag, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.rl_cnt, (size_t)rows * 4));
     GLC_TRY(hipHostMalloc((void **)&s.h_max_cnt, 32, hipHostMallocDefault));
     s.bytes = total;
+    return hipSuccess;
+}
+
+// the general sorter's own arrays (and s.sa, which the other tiers also write when the suffix array itself is the
+// result asked for): allocated on first use -- a plan whose data never leaves the bucket / sample sorters (the 4 GiB
+// benchmark workload: 3 plans x 1024 rows) does not carry 24.6 MiB per row for a tier it does not run
+hipError_t sa_general_reserve(SaScratch &s, bool only_sa)
+{
+    const size_t ne = (size_t)s.nmax * s.rows;
+    auto A = [&](void **p, size_t bytes) -> hipError_t {
+        if (*p) return hipSuccess;
+        s.bytes += bytes;
+        return hipMalloc(p, bytes);
+    };
+    GLC_TRY(A((void **)&s.sa, ne * 4));
+    if (only_sa) return hipSuccess;
+    GLC_TRY(A((void **)&s.posA, ne * 4)); GLC_TRY(A((void **)&s.posB, ne * 4));
+    GLC_TRY(A((void **)&s.isa, ne * 4));
+    GLC_TRY(A((void **)&s.hdA, ne * 4)); GLC_TRY(A((void **)&s.hdB, ne * 4));
+    if (!s.tile_hist) s.epoch = 255;                         // fresh look-back granules: force a clear first
+    GLC_TRY(A((void **)&s.tile_hist, (size_t)s.rows * s.rs_tiles * SA_MAXRADIX * 4));
+    GLC_TRY(A((void **)&s.tile_state, (size_t)s.rows * s.max_tiles * 8));
     return hipSuccess;
 }
 
@@ -938,6 +957,7 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
                                    SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out,
                                    const uint32_t *cnt0, uint32_t nsorted)
 {
+    GLC_TRY(sa_general_reserve(s, false));
     uint32_t tiles = (n + SA_TILE - 1) / SA_TILE;
     uint64_t *cur = s.keyA, *alt = s.keyB;
     double live_total = (double)n * nsorted;
@@ -1049,6 +1069,7 @@ hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_strid
         return e;
     }
     // bucket sorter first; the suffix array itself is only written when it is the result asked for
+    if (!bwt_out) GLC_TRY(sa_general_reserve(s, true));
     s.skip_tier1 = s.sorter == 4;                            // the caller knows its data is text-like: no bucket-sorter attempt
     GLC_TRY(fs_build(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa));
     GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 4, s.fs_nflag, 4, hipMemcpyDeviceToHost, st));

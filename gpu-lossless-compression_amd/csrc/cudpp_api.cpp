@@ -513,12 +513,12 @@ CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable)
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     p->timing = enable != 0;
     p->ev_valid = false;
-    p->prof.on = (enable & 2) != 0;
+    if (!p->prof.enable((enable & 2) != 0)) return CUDPP_ERROR_INSUFFICIENT_RESOURCES;
     p->prof.reset();
     if (SaScratch *s = sa_of(p)) s->prof = &p->prof;
     if (p->config.algorithm == CUDPP_COMPRESS) {
         CompressPlan *cp = static_cast<CompressPlan *>(p);
-        cp->mtf.prof = &p->prof; cp->huff.prof = &p->prof;
+        cp->mtf.prof = &p->prof; cp->huff.prof = &p->prof; cp->dec.prof = &p->prof;
     } else if (p->config.algorithm == CUDPP_MTF) static_cast<MtfPlan *>(p)->mtf.prof = &p->prof;
     return CUDPP_SUCCESS;
 }
@@ -555,13 +555,21 @@ CUDPPResult glcPlanLastSortStatsEx(CUDPPHandle planHandle, unsigned int *out2)
     return CUDPP_SUCCESS;
 }
 
-// call after glcPlanSynchronize (the event pairs are read when the plan's streams are idle)
+// the event pairs are read when the plan's streams are idle: both getters wait for them first
+static void prof_collect(PlanBase *p)
+{
+    if (p->prof.npend == 0) return;
+    if (p->config.algorithm == CUDPP_COMPRESS) static_cast<CompressPlan *>(p)->join_side();
+    (void)hipStreamSynchronize(p->stream);
+    p->prof.collect();
+}
+
 CUDPPResult glcPlanKernelProfileEx(CUDPPHandle planHandle, int index, char *name, size_t nameCap, double *out3)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE || !out3) return CUDPP_ERROR_INVALID_HANDLE;
     if (index < 0 || index >= PROF_NSLOT) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
-    p->prof.collect();
+    prof_collect(p);
     out3[0] = p->prof.ms[index]; out3[1] = (double)p->prof.launches[index]; out3[2] = p->prof.units[index];
     if (name && nameCap) { strncpy(name, p->prof.name[index], nameCap - 1); name[nameCap - 1] = 0; }
     return CUDPP_SUCCESS;
@@ -572,11 +580,21 @@ CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE || !out3) return CUDPP_ERROR_INVALID_HANDLE;
-    p->prof.collect();
+    prof_collect(p);
     int best = 0;
     for (int k = 1; k < PROF_NSLOT; k++) if (p->prof.ms[k] > p->prof.ms[best]) best = k;
     out3[0] = p->prof.ms[best]; out3[1] = (double)p->prof.launches[best]; out3[2] = p->prof.units[best];
     p->prof.reset();
+    return CUDPP_SUCCESS;
+}
+
+// launches the live profile could not account for: out2[0] = not bracketed (more than 4096 launches pending between two
+// reads), out2[1] = bracketed but unreadable
+CUDPPResult glcPlanKernelProfileLost(CUDPPHandle planHandle, unsigned long long *out2)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out2) return CUDPP_ERROR_INVALID_HANDLE;
+    out2[0] = (unsigned long long)p->prof.dropped; out2[1] = (unsigned long long)p->prof.unread;
     return CUDPP_SUCCESS;
 }
 

@@ -702,6 +702,18 @@ __global__ __launch_bounds__(64) void k_lzss_decode(const uint8_t *__restrict__ 
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
+KernelProf &lzss_prof()
+{
+    static KernelProf pr;
+    static bool named = false;
+    if (!named) {
+        named = true;
+        pr.name[LZP_MATCH] = "k_lzss_match"; pr.name[LZP_PACK] = "k_lzss_pack_wave+k_lzss_pack";
+        pr.name[LZP_GATHER] = "k_lzss_layout+k_lzss_gather"; pr.name[LZP_DECODE] = "k_lzss_decode";
+    }
+    return pr;
+}
+
 size_t lzss_work_bytes(int buf_length, int nbuf)
 {
     const size_t npk = (size_t)(buf_length / LZ_PCKT) * nbuf;
@@ -728,7 +740,10 @@ hipError_t lzss_encode(hipStream_t st, const uint8_t *d_in, int buf_length, int 
     carve(d_work, buf_length, nbuf, &stage, &meta, &pk_off, &cand);
     if (d_cand) cand = d_cand;
     const uint32_t npk = buf_length / LZ_PCKT;
+    KernelProf &pr = lzss_prof();
+    const int pi = pr.begin(LZP_MATCH, st);
     hipLaunchKernelGGL(k_lzss_match, dim3(npk * nbuf), dim3(256), 0, st, d_in, cand);
+    pr.end(pi, (double)buf_length * nbuf, st);
     return lzss_pack(st, cand, buf_length, nbuf, d_packed, d_sizes, d_work, d_in);
 }
 
@@ -741,13 +756,19 @@ hipError_t lzss_pack(hipStream_t st, const uint8_t *d_cand, int buf_length, int 
     const uint32_t npk = buf_length / LZ_PCKT;
     const size_t stride = lzss_pack_stride(buf_length);
     // pk_off doubles as the "left to k_lzss_pack" flags until k_lzss_layout writes the offsets
+    KernelProf &pr = lzss_prof();
+    const double units = (double)buf_length * nbuf;
+    int pi = pr.begin(LZP_PACK, st);
     hipLaunchKernelGGL(k_lzss_pack_wave, dim3((npk * nbuf + LP_WAVES - 1) / LP_WAVES), dim3(LP_WAVES * 64), 0, st, d_cand, stage,
                        meta, npk * nbuf, pk_off);
     hipLaunchKernelGGL(k_lzss_pack, dim3(npk * nbuf), dim3(256), 0, st, d_cand, stage, meta, pk_off);
+    pr.end(pi, units, st);
+    pi = pr.begin(LZP_GATHER, st);
     hipLaunchKernelGGL(k_lzss_layout, dim3(nbuf), dim3(256), 0, st, meta, npk, buf_length, pk_off, d_packed, stride,
                        d_sizes);
     hipLaunchKernelGGL(k_lzss_gather, dim3(npk, nbuf), dim3(256), 0, st, stage, meta, pk_off, npk, d_packed, stride,
                        d_sizes, d_raw_in);
+    pr.end(pi, units, st);
     return hipGetLastError();
 }
 
@@ -756,8 +777,11 @@ hipError_t lzss_decode(hipStream_t st, const uint8_t *d_packed, const int *d_siz
 {
     if (buf_length <= 0 || buf_length % LZ_PCKT || nbuf <= 0) return hipErrorInvalidValue;
     const uint32_t npk = buf_length / LZ_PCKT;
+    KernelProf &pr = lzss_prof();
+    const int pi = pr.begin(LZP_DECODE, st);
     hipLaunchKernelGGL(k_lzss_decode, dim3(npk, nbuf), dim3(64), 0, st, d_packed, lzss_pack_stride(buf_length),
                        d_sizes, buf_length, d_out, d_err);
+    pr.end(pi, (double)buf_length * nbuf, st);
     return hipGetLastError();
 }
 

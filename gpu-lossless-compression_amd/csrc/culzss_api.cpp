@@ -13,6 +13,7 @@
 // than exit() (gpu_compress.cu:170-179).
 #include "../../include/culzss.h"
 #include "culzss_internal.h"
+#include "glc_internal.h"
 
 #include <algorithm>
 #include <mutex>
@@ -345,6 +346,20 @@ int glcLzssDecodeDevice(const unsigned char *d_packed, const int *d_sizes, int b
 {
     if (!d_packed || !d_sizes || !d_out || !valid_len(buf_length) || nbuf <= 0) return 0;
     return ok(lzss_decode((hipStream_t)stream, d_packed, d_sizes, buf_length, nbuf, d_out), "decode") ? 1 : 0;
+}
+
+int glcLzssEnableProfile(int on)
+{
+    KernelProf &pr = lzss_prof();
+    (void)hipDeviceSynchronize();
+    pr.collect();
+    pr.reset();
+    return pr.enable(on != 0) ? 1 : 0;
+}
+
+int glcLzssKernelProfile(int index, char *name, size_t nameCap, double *out3)
+{
+    return global_prof_get(lzss_prof(), LZP_NSLOT, index, name, nameCap, out3);
 }
 
 float glcLzssLastKernelMs(void)

@@ -17,6 +17,9 @@ inline size_t lzss_pack_stride(int buf_length)
     return ((size_t)buf_length + (size_t)buf_length / 2048 + 32 + 255) & ~(size_t)255;
 }
 
+struct KernelProf;
+enum { LZP_MATCH = 0, LZP_PACK, LZP_GATHER, LZP_DECODE, LZP_NSLOT };
+KernelProf &lzss_prof();             // process-wide live profile of the launchers below (glcLzssEnableProfile)
 size_t     lzss_work_bytes(int buf_length, int nbuf);
 hipError_t lzss_encode(hipStream_t st, const uint8_t *d_in, int buf_length, int nbuf, uint8_t *d_cand,
                        uint8_t *d_packed, int *d_sizes, void *d_work);

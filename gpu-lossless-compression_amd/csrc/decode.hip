@@ -793,6 +793,8 @@ hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
+    const double units = (double)n * nblk;
+    int pi = s.prof ? s.prof->begin(PROF_DEC_HUFF, st) : -1;
     hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes);
     if ((uint64_t)nsub * nblk >= DL_MIN_SUBS)
         hipLaunchKernelGGL(k_dec_huff_lanes, dim3((nsub + DL_NT - 1) / DL_NT, nblk), dim3(DL_NT), 0, st, d_comp, comp_stride_words,
@@ -800,11 +802,16 @@ hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t
     else
         hipLaunchKernelGGL(k_dec_huff, dim3((nsub + DH_WAVES - 1) / DH_WAVES, nblk), dim3(DH_WAVES * 64), 0, st, d_comp, comp_stride_words,
                            d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
+    if (pi >= 0) s.prof->end(pi, units, st);
+    pi = s.prof ? s.prof->begin(PROF_IMTF_POS, st) : -1;
     hipLaunchKernelGGL(k_imtf_pos, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
                        s.max_chunks, bwt, (size_t)s.nmax);
+    if (pi >= 0) s.prof->end(pi, units, st);
+    pi = s.prof ? s.prof->begin(PROF_IMTF_REST, st) : -1;
     hipLaunchKernelGGL(k_imtf_scan, dim3(nblk), dim3(64), 0, st, s.ilists, n, s.max_chunks);
     hipLaunchKernelGGL(k_imtf_apply, dim3(nchunks, nblk), dim3(256), 0, st, bwt, (size_t)s.nmax, n, s.ilists,
                        s.max_chunks);
+    if (pi >= 0) s.prof->end(pi, units, st);
     return hipGetLastError();
 }
 
@@ -814,18 +821,25 @@ hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t 
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t rows = n + 1, tiles = (rows + LF_TILE - 1) / LF_TILE, nsplit = (rows + SPLIT - 1) / SPLIT;
     const size_t lf_stride = (size_t)s.nmax + 4;
+    const double units = (double)n * nblk;
+    int pi = s.prof ? s.prof->begin(PROF_IBWT_LF, st) : -1;
     hipLaunchKernelGGL(k_ibwt_hist, dim3(tiles, nblk), dim3(256), 0, st, bwt, (size_t)s.nmax, d_bwt_index, n,
                        s.tile_hist, s.max_tiles, d_status);
     GLC_TRY(tile_hist_scan9(st, s.tile_hist, rows, s.digit_base, s.max_tiles, nblk, LF_TILE));
     hipLaunchKernelGGL(k_ibwt_lf, dim3(tiles, nblk), dim3(256), 0, st, bwt, (size_t)s.nmax, d_bwt_index, n,
                        s.tile_hist, s.digit_base, s.max_tiles, s.lf, lf_stride);
     hipLaunchKernelGGL(k_ibwt_seg_init, dim3((nblk + 255) / 256), dim3(256), 0, st, s.seg_count, n, nblk);
+    if (pi >= 0) s.prof->end(pi, units, st);
+    pi = s.prof ? s.prof->begin(PROF_IBWT_WALK, st) : -1;
     hipLaunchKernelGGL(k_ibwt_walk<100>, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,
                        s.max_seg, s.seg_count, s.slots);
+    if (pi >= 0) s.prof->end(pi, units, st);
+    pi = s.prof ? s.prof->begin(PROF_IBWT_EMIT, st) : -1;
     hipLaunchKernelGGL(k_ibwt_rank, dim3(nblk), dim3(RANK_NT), 0, st, s.seg, s.max_seg, s.seg_count, s.seg_pos);
     const uint32_t seg_bound = nsplit + rows / SLOT + 1;
     hipLaunchKernelGGL(k_ibwt_emit, dim3((seg_bound + 4 * EMIT_SEGS - 1) / (4 * EMIT_SEGS), nblk), dim3(256), 0, st,
                        s.slots, s.seg, s.seg_pos, s.max_seg, s.seg_count, n, d_out, (size_t)n);
+    if (pi >= 0) s.prof->end(pi, units, st);
     return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace glc {
 
@@ -30,19 +31,38 @@ constexpr uint32_t ST_CORRUPT        = 4u;       // decoder: an offset, length o
 // the launches of the named kernels; durations are folded in when the plan's streams are idle
 // ---------------------------------------------------------------------------
 enum ProfSlot { PROF_FS_PART = 0, PROF_FS_SORT, PROF_MTF_ENCODE, PROF_HUFF_PACK, PROF_RS_ONESWEEP8, PROF_FS_HIST,
-                PROF_MTF_LISTS, PROF_HUFF_BUILD, PROF_NSLOT };
+                PROF_MTF_LISTS, PROF_HUFF_BUILD,
+                // decoder (decode.hip)
+                PROF_DEC_HUFF, PROF_IMTF_POS, PROF_IMTF_REST, PROF_IBWT_LF, PROF_IBWT_WALK, PROF_IBWT_EMIT,
+                PROF_NSLOT };
 struct KernelProf {
     static constexpr int NPAIR = 4096;
     bool       on = false;
     const char *name[PROF_NSLOT] = {"k_fs_part", "k_fs_sort", "k_mtf_encode", "k_huff_pack", "k_rs_onesweep<8,false>",
-                                    "k_fs_hist", "k_mtf_chunk_lists+k_mtf_scan_lists", "k_huff_build"};
+                                    "k_fs_hist", "k_mtf_chunk_lists+k_mtf_scan_lists", "k_huff_build",
+                                    "k_dec_prepare+k_dec_huff", "k_imtf_pos", "k_imtf_scan+k_imtf_apply",
+                                    "k_ibwt_hist+k_rs_scan+k_ibwt_lf", "k_ibwt_walk", "k_ibwt_rank+k_ibwt_emit"};
     double     ms[PROF_NSLOT] = {}, units[PROF_NSLOT] = {};
     long       launches[PROF_NSLOT] = {};
-    hipEvent_t ev[2 * NPAIR] = {};
-    int        pend_slot[NPAIR] = {};
-    double     pend_units[NPAIR] = {};
+    // event pairs and what they bracket: allocated when profiling is switched on (a plan that never profiles carries
+    // none of it)
+    hipEvent_t *ev = nullptr;                    // [2 * NPAIR]
+    int        *pend_slot = nullptr;             // [NPAIR]
+    double     *pend_units = nullptr;            // [NPAIR]
     int        npend = 0;
-    long       dropped = 0;
+    long       dropped = 0;                      // launches not bracketed because NPAIR pairs were pending
+    long       unread = 0;                       // pairs whose elapsed time could not be read at collect()
+    bool enable(bool want)
+    {
+        if (want && !ev) {
+            ev = (hipEvent_t *)calloc(2 * NPAIR, sizeof(hipEvent_t));
+            pend_slot = (int *)calloc(NPAIR, sizeof(int));
+            pend_units = (double *)calloc(NPAIR, sizeof(double));
+            if (!ev || !pend_slot || !pend_units) { on = false; return false; }
+        }
+        on = want;
+        return true;
+    }
     int begin(int slot, hipStream_t st)
     {
         if (!on) return -1;
@@ -61,19 +81,35 @@ struct KernelProf {
         pend_units[i] = nunits;
         npend = i + 1;
     }
-    void collect()                               // every stream the events were recorded on must be idle
+    void collect()                               // the caller has synchronised every stream the events were recorded on
     {
         for (int i = 0; i < npend; i++) {
             float t = 0.f;
             if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) {
                 ms[pend_slot[i]] += t; units[pend_slot[i]] += pend_units[i]; launches[pend_slot[i]]++;
-            }
+            } else unread++;
         }
         npend = 0;
     }
-    void reset() { for (int k = 0; k < PROF_NSLOT; k++) { ms[k] = 0; units[k] = 0; launches[k] = 0; } npend = 0; dropped = 0; }
-    ~KernelProf() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); }
+    void reset() { for (int k = 0; k < PROF_NSLOT; k++) { ms[k] = 0; units[k] = 0; launches[k] = 0; } npend = 0; dropped = 0; unread = 0; }
+    ~KernelProf()
+    {
+        if (ev) for (int i = 0; i < 2 * NPAIR; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+        free(ev); free(pend_slot); free(pend_units);
+    }
 };
+
+// C-ABI helper for the stateless device entry points (CULZSS, CUHD-shaped decoder), which have no plan to hang a profile
+// on: a process-wide KernelProf with its own slot names.  out3 = {sum of launch ms, launches, units}; returns 0 past the
+// last named slot.  Measurement aid: not thread-safe against concurrent launches.
+inline int global_prof_get(KernelProf &pr, int nslot, int index, char *name, size_t name_cap, double *out3)
+{
+    if (index < 0 || index >= nslot || !out3) return 0;
+    if (pr.npend) { (void)hipDeviceSynchronize(); pr.collect(); }
+    out3[0] = pr.ms[index]; out3[1] = (double)pr.launches[index]; out3[2] = pr.units[index];
+    if (name && name_cap) { size_t i = 0; for (; pr.name[index][i] && i + 1 < name_cap; i++) name[i] = pr.name[index][i]; name[i] = 0; }
+    return 1;
+}
 
 // ---------------------------------------------------------------------------
 // suffix array scratch: everything for `rows` blocks of up to nmax elements
@@ -131,6 +167,7 @@ struct SaScratch {
 };
 
 hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows);
+hipError_t sa_general_reserve(SaScratch &s, bool only_sa);
 void       sa_scratch_free(SaScratch &s);
 
 // Suffix arrays of `nblk` blocks of n bytes (block b at text + b*text_stride).
@@ -217,6 +254,7 @@ hipError_t expand_streams(hipStream_t st, const uint32_t *d_in, const unsigned l
 // decoder (round-trip parity only; the reference has no GPU decoder)
 // ---------------------------------------------------------------------------
 struct DecodeScratch {
+    KernelProf *prof = nullptr;
     uint32_t nmax = 0, rows = 0, max_tiles = 0, max_split = 0, max_chunks = 0;
     uint8_t  *mtf = nullptr, *bwt = nullptr;     // [rows][nmax]
     uint8_t  *bwt2 = nullptr;                    // second BWT buffer for stage pipelining

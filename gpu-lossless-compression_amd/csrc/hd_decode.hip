@@ -20,6 +20,7 @@
 //   reference re-launches phase 2 until a flag copied back to the host says "synced",
 //   cuhd_gpu_decoder.cu:459-495).
 #include "glc_device.h"
+#include "glc_internal.h"
 #include "../../include/glc_hd.h"
 
 #include <algorithm>
@@ -351,6 +352,29 @@ size_t glcHdEncodeHost(const unsigned char *in, size_t nsym, const unsigned char
 
 size_t glcHdWorkBytes(size_t nunits) { return hd_layout(nunits ? nunits : 1).total; }
 
+enum { HDP_SPANS = 0, HDP_WALK, HDP_EMIT, HDP_NSLOT };
+static glc::KernelProf &hd_prof()
+{
+    static glc::KernelProf pr;
+    static bool named = false;
+    if (!named) { named = true; pr.name[HDP_SPANS] = "k_hd_span_functions"; pr.name[HDP_WALK] = "k_hd_walk x3"; pr.name[HDP_EMIT] = "k_hd_emit"; }
+    return pr;
+}
+
+int glcHdEnableProfile(int on)
+{
+    glc::KernelProf &pr = hd_prof();
+    (void)hipDeviceSynchronize();
+    pr.collect();
+    pr.reset();
+    return pr.enable(on != 0) ? 1 : 0;
+}
+
+int glcHdKernelProfile(int index, char *name, size_t nameCap, double *out3)
+{
+    return glc::global_prof_get(hd_prof(), HDP_NSLOT, index, name, nameCap, out3);
+}
+
 static int hd_decode_lut(const unsigned int *d_units, size_t nunits, const uint16_t *lut, unsigned char *d_out,
                          size_t nsym, void *d_work, void *stream)
 {
@@ -364,12 +388,19 @@ static int hd_decode_lut(const unsigned int *d_units, size_t nunits, const uint1
     uint32_t *pexcl = (uint32_t *)(W + L.o_pexcl), *fwg = (uint32_t *)(W + L.o_fwg), *G = (uint32_t *)(W + L.o_g);
     uint32_t *coff = (uint32_t *)(W + L.o_coff), *soff = (uint32_t *)(W + L.o_soff);
     unsigned long long *cbase = (unsigned long long *)(W + L.o_cbase), *sbase = (unsigned long long *)(W + L.o_sbase);
+    glc::KernelProf &pr = hd_prof();
+    int pi = pr.begin(HDP_SPANS, st);
     hipLaunchKernelGGL(k_hd_span_functions, dim3((unsigned)L.nwg), dim3(HD_LANES), 0, st, d_units, nunits, d_lut, pexcl, fwg);
+    pr.end(pi, (double)nsym, st);
+    pi = pr.begin(HDP_WALK, st);
     hipLaunchKernelGGL(k_hd_walk, dim3((unsigned)L.nchunks), dim3(64), 0, st, 0, fwg, L.nwg, G, coff, cbase, soff, sbase);
     hipLaunchKernelGGL(k_hd_walk, dim3(1), dim3(64), 0, st, 1, fwg, L.nchunks, G, coff, cbase, soff, sbase);
     hipLaunchKernelGGL(k_hd_walk, dim3((unsigned)L.nchunks), dim3(64), 0, st, 2, fwg, L.nwg, G, coff, cbase, soff, sbase);
+    pr.end(pi, (double)nsym, st);
+    pi = pr.begin(HDP_EMIT, st);
     hipLaunchKernelGGL(k_hd_emit, dim3((unsigned)L.nwg), dim3(HD_LANES), 0, st, d_units, nunits, d_lut, pexcl, soff, sbase,
                        d_out, nsym);
+    pr.end(pi, (double)nsym, st);
     return hipGetLastError() == hipSuccess ? 1 : 0;
 }
 

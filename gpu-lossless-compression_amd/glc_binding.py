@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcPlanKernelProfileLost",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
@@ -47,11 +47,12 @@ CULZSS_SYMBOLS = [
     "dedeleteGPUmem", "deinitGPU", "culzss_compress", "culzss_decompress",
     "glcLzssEncodeDevice", "glcLzssDecodeDevice", "glcLzssLastKernelMs", "glcLzssPackStride",
     "glcLzssWorkBytes", "culzss_container_bound", "culzss_container_compress", "culzss_container_decompress",
-    "culzss_compress_file", "culzss_decompress_file",
+    "culzss_compress_file", "culzss_decompress_file", "glcLzssEnableProfile", "glcLzssKernelProfile",
 ]
 EXCHANGE_SYMBOLS = ["glcCommGetUniqueId", "glcCommInitRank", "glcCommAdopt", "glcCommDestroy", "glcCommInfo", "glcPackRecords",
                     "glcUnpackRecords", "glcGatherCounts", "glcGatherStreams", "glcScatterStreams"]
-HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice", "glcHdDecodeDeviceTable"]
+HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice", "glcHdDecodeDeviceTable", "glcHdEnableProfile",
+              "glcHdKernelProfile"]
 
 
 class CUDPPConfiguration(C.Structure):
@@ -103,6 +104,7 @@ def lib():
     L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
     L.glcPlanKernelProfile.argtypes = [sz, C.POINTER(C.c_double)]
     L.glcPlanKernelProfileEx.argtypes = [sz, C.c_int, C.c_char_p, sz, C.POINTER(C.c_double)]
+    L.glcPlanKernelProfileLost.argtypes = [sz, C.POINTER(C.c_ulonglong)]
     L.glcCompactStreams.argtypes = [sz, vp, sz, vp, sz, vp, vp]
     L.glcExpandStreams.argtypes = [sz, vp, vp, sz, vp, sz, vp]
     for name in CUDPP_SYMBOLS:
@@ -153,6 +155,10 @@ def lib():
         L.culzss_compress_file.restype = C.c_int
         L.culzss_decompress_file.argtypes = [C.c_char_p, C.c_char_p]
         L.culzss_decompress_file.restype = C.c_int
+        L.glcLzssEnableProfile.argtypes = [C.c_int]
+        L.glcLzssEnableProfile.restype = C.c_int
+        L.glcLzssKernelProfile.argtypes = [C.c_int, C.c_char_p, sz, C.POINTER(C.c_double)]
+        L.glcLzssKernelProfile.restype = C.c_int
         L.glcLzssLastKernelMs.argtypes = []
         L.glcLzssLastKernelMs.restype = C.c_float
     if hasattr(L, "glcHdDecodeDevice"):
@@ -166,6 +172,10 @@ def lib():
         L.glcHdDecodeDevice.restype = C.c_int
         L.glcHdDecodeDeviceTable.argtypes = [vp, sz, vp, vp, sz, vp, vp]
         L.glcHdDecodeDeviceTable.restype = C.c_int
+        L.glcHdEnableProfile.argtypes = [C.c_int]
+        L.glcHdEnableProfile.restype = C.c_int
+        L.glcHdKernelProfile.argtypes = [C.c_int, C.c_char_p, sz, C.POINTER(C.c_double)]
+        L.glcHdKernelProfile.restype = C.c_int
     if hasattr(L, "glcGatherStreams"):                             # include/glc_exchange.h
         ullp = C.POINTER(C.c_ulonglong)
         L.glcCommGetUniqueId.argtypes = [vp]

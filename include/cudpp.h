@@ -200,12 +200,15 @@ CUDPPResult glcPlanEnableTiming(CUDPPHandle planHandle, int enable);
 CUDPPResult glcPlanLastTiming(CUDPPHandle planHandle, float *ms4);
 
 /* With glcPlanEnableTiming(plan, 3) the library also brackets every launch of its main kernels with hipEvents
- * on the stream they are launched on.  After glcPlanSynchronize, glcPlanKernelProfileEx(plan, i, name, cap, out3)
+ * on the stream they are launched on (encoder and decoder).  glcPlanKernelProfileEx(plan, i, name, cap, out3)
  * returns for slot i = 0, 1, ... (CUDPP_ERROR_ILLEGAL_CONFIGURATION past the last) the kernel's name and
  * out3 = {sum of launch durations in ms, number of launches, input bytes those launches processed};
  * glcPlanKernelProfile returns the slot with the largest total and resets the accumulators. */
 CUDPPResult glcPlanKernelProfileEx(CUDPPHandle planHandle, int index, char *name, size_t nameCap, double *out3);
 CUDPPResult glcPlanKernelProfile(CUDPPHandle planHandle, double *out3);
+/* launches the live profile could not account for since it was switched on: out2[0] = not bracketed (more than 4096
+ * launches between two reads), out2[1] = bracketed but unreadable.  Both getters above wait for the plan's streams. */
+CUDPPResult glcPlanKernelProfileLost(CUDPPHandle planHandle, unsigned long long *out2);
 
 /* The Huffman half of cudppCompress on caller-supplied symbols (what the pipeline feeds with the MTF output):
  * histogram, tree + codes, bit packer and offsets -- huffman_build_histogram_kernel / huffman_build_tree_kernel /

@@ -118,6 +118,12 @@ unsigned long long glcLzssWorkBytes(int buf_length, int nbuf);
 int glcLzssDecodeDevice(const unsigned char *d_packed, const int *d_sizes, int buf_length, int nbuf,
                         unsigned char *d_out, void *stream);
 float glcLzssLastKernelMs(void);
+/* Measurement aid: live per-kernel profile of the device entry points above (hipEvent pairs on the call's stream around
+ * k_lzss_match / the token walk + packer / layout + gather / k_lzss_decode).  glcLzssEnableProfile(1) switches it on and
+ * resets it; glcLzssKernelProfile(i, name, cap, out3) waits for the device and returns 1 with the slot's name and
+ * out3 = {sum of launch durations in ms, launches, input bytes processed}, 0 past the last slot. */
+int glcLzssEnableProfile(int on);
+int glcLzssKernelProfile(int index, char *name, size_t nameCap, double *out3);
 
 #ifdef __cplusplus
 }

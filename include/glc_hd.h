@@ -57,6 +57,13 @@ int glcHdDecodeDevice(const unsigned int *d_units, size_t nunits, const unsigned
 int glcHdDecodeDeviceTable(const unsigned int *d_units, size_t nunits, const unsigned char *table2048,
                            unsigned char *d_out, size_t nsym, void *d_work, void *stream);
 
+/* Measurement aid: live per-kernel profile of the two decode entry points (hipEvent pairs on the call's stream around
+ * k_hd_span_functions / the three k_hd_walk launches / k_hd_emit).  glcHdEnableProfile(1) switches it on and resets it;
+ * glcHdKernelProfile(i, name, cap, out3) waits for the device and returns 1 with the slot's name and
+ * out3 = {sum of launch durations in ms, launches, decoded bytes}, 0 past the last slot. */
+int glcHdEnableProfile(int on);
+int glcHdKernelProfile(int index, char *name, size_t nameCap, double *out3);
+
 #ifdef __cplusplus
 }
 #endif

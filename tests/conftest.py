@@ -11,6 +11,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_long: opt-in sweeps on the GPU box (minutes): run with -m gpu_long; never part of "
+                                       "-m gpu or -m 'not gpu'")
+
+
+def pytest_collection_modifyitems(config, items):
+    """gpu_long tests run only when asked for by name (-m gpu_long): they are neither CPU tests nor part of the driver's
+    -m gpu run"""
+    if "gpu_long" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("gpu_long") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def load_pkg_module(name):

@@ -11,6 +11,7 @@ import datagen
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
+
 _OFFSET = 100000 * int(os.environ.get("GLC_FUZZ_OFFSET", "0"))      # other seed ranges for one-off sweeps
 
 
@@ -132,3 +133,20 @@ def test_compress_reports_a_block_that_does_not_fit(glc, ctx, cuda):
         comp = glc.compress_batch(plan, ok, n, rows)
         plan.synchronize()
         assert torch.equal(glc.decompress_batch(plan, comp, n, rows), ok)
+
+
+# --- the sweeps DESIGN.md quotes, reproducible: python -m pytest tests/test_gpu_fuzz.py -m gpu_long -q  (about 10 minutes) ---
+@pytest.mark.gpu_long
+@pytest.mark.parametrize("offset", list(range(1, 58)))
+def test_fuzz_sweep_long(glc, ctx, cuda, offset):
+    """57 further seed ranges of the two fuzz tests above (24 BWT batches + 6 round trips each: 1 710 cases)"""
+    global _OFFSET
+    saved = _OFFSET
+    _OFFSET = 100000 * offset
+    try:
+        for seed in range(24):
+            test_fuzz_bwt_batches(glc, ctx, cuda, seed)
+        for seed in range(6):
+            test_fuzz_compress_round_trip(glc, ctx, cuda, seed)
+    finally:
+        _OFFSET = saved
