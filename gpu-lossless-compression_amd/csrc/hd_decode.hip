@@ -375,16 +375,31 @@ int glcHdKernelProfile(int index, char *name, size_t nameCap, double *out3)
     return glc::global_prof_get(hd_prof(), HDP_NSLOT, index, name, nameCap, out3);
 }
 
+// the reference's device table {num_bits, symbol}[2048] -> the u16 form (bits << 8 | symbol) the kernels read
+__global__ void k_hd_table_from_device(const unsigned char *__restrict__ table2048, uint16_t *__restrict__ lut)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2048) {
+        uint32_t bits = table2048[2 * i];
+        const uint32_t sym = table2048[2 * i + 1];
+        if (bits == 0 || bits > GLC_HD_MAX_LEN) bits = 1;     // prefixes no codeword reaches / out of range: never met in a valid stream
+        lut[i] = (uint16_t)((bits << 8) | sym);
+    }
+}
+
+// lut: host table (copied in), or nullptr with d_table = the reference's table already in device memory
 static int hd_decode_lut(const unsigned int *d_units, size_t nunits, const uint16_t *lut, unsigned char *d_out,
-                         size_t nsym, void *d_work, void *stream)
+                         size_t nsym, void *d_work, void *stream, const unsigned char *d_table = nullptr)
 {
     const HdLayout L = hd_layout(nunits);
     if (L.nchunks > HD_CHUNK) return 0;
     uint8_t *W = (uint8_t *)d_work;
     hipStream_t st = (hipStream_t)stream;
     uint16_t *d_lut = (uint16_t *)(W + L.o_lut);
-    if (hipMemcpyAsync(d_lut, lut, 2048 * sizeof(uint16_t), hipMemcpyHostToDevice, st) != hipSuccess) return 0;
-    if (hipStreamSynchronize(st) != hipSuccess) return 0;     // lut is a stack array of the caller
+    if (lut) {
+        if (hipMemcpyAsync(d_lut, lut, 2048 * sizeof(uint16_t), hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+        if (hipStreamSynchronize(st) != hipSuccess) return 0; // lut is a stack array of the caller
+    } else hipLaunchKernelGGL(k_hd_table_from_device, dim3(8), dim3(256), 0, st, d_table, d_lut);
     uint32_t *pexcl = (uint32_t *)(W + L.o_pexcl), *fwg = (uint32_t *)(W + L.o_fwg), *G = (uint32_t *)(W + L.o_g);
     uint32_t *coff = (uint32_t *)(W + L.o_coff), *soff = (uint32_t *)(W + L.o_soff);
     unsigned long long *cbase = (unsigned long long *)(W + L.o_cbase), *sbase = (unsigned long long *)(W + L.o_sbase);
@@ -436,6 +451,15 @@ int glcHdDecodeDeviceTable(const unsigned int *d_units, size_t nunits, const uns
         lut[i] = (uint16_t)(((bits ? bits : 1u) << 8) | sym);   // prefixes no codeword reaches: never met in a valid stream
     }
     return hd_decode_lut(d_units, nunits, lut, d_out, nsym, d_work, stream);
+}
+
+// As glcHdDecodeDeviceTable, with the table where cuhd::CUHDGPUCodetable keeps it: in DEVICE memory.  Nothing is copied
+// and the host is not held: the whole decode is enqueued on `stream`.
+int glcHdDecodeDeviceTableOnDevice(const unsigned int *d_units, size_t nunits, const unsigned char *d_table2048,
+                                   unsigned char *d_out, size_t nsym, void *d_work, void *stream)
+{
+    if (!d_units || !d_table2048 || !d_out || !d_work || nunits == 0 || nunits > (1ull << 31)) return 0;
+    return hd_decode_lut(d_units, nunits, nullptr, d_out, nsym, d_work, stream, d_table2048);
 }
 
 } // extern "C"

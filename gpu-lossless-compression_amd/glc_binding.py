@@ -51,7 +51,7 @@ CULZSS_SYMBOLS = [
 ]
 EXCHANGE_SYMBOLS = ["glcCommGetUniqueId", "glcCommInitRank", "glcCommAdopt", "glcCommDestroy", "glcCommInfo", "glcPackRecords",
                     "glcUnpackRecords", "glcGatherCounts", "glcGatherStreams", "glcScatterStreams"]
-HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice", "glcHdDecodeDeviceTable", "glcHdEnableProfile",
+HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice", "glcHdDecodeDeviceTable", "glcHdDecodeDeviceTableOnDevice", "glcHdEnableProfile",
               "glcHdKernelProfile"]
 
 
@@ -172,6 +172,8 @@ def lib():
         L.glcHdDecodeDevice.restype = C.c_int
         L.glcHdDecodeDeviceTable.argtypes = [vp, sz, vp, vp, sz, vp, vp]
         L.glcHdDecodeDeviceTable.restype = C.c_int
+        L.glcHdDecodeDeviceTableOnDevice.argtypes = [vp, sz, vp, vp, sz, vp, vp]
+        L.glcHdDecodeDeviceTableOnDevice.restype = C.c_int
         L.glcHdEnableProfile.argtypes = [C.c_int]
         L.glcHdEnableProfile.restype = C.c_int
         L.glcHdKernelProfile.argtypes = [C.c_int, C.c_char_p, sz, C.POINTER(C.c_double)]

@@ -1,0 +1,70 @@
+// glc_cuhd_adapter.hpp -- the reference's C++ call for config 5, over the C ABI of glc_hd.h.  Header only.
+//
+// Replaces  cuhd::CUHDGPUDecoder::decode  (cuhd-icpp/include/cuhd_gpu_decoder.h:22-31, implementation
+// cuhd-icpp/src/cuhd_gpu_decoder.cu:422-523): same argument list, same meaning -- `input` holds `input_size` 32-bit
+// units in device memory (incl. the zero pad unit, cuhd_input_buffer.cc:20-27), `output` receives `output_size`
+// symbols, `table` is the 2048-entry {num_bits, symbol} device table of cuhd::CUHDGPUCodetable
+// (cuhd_codetable.h:20-23).  The reference's buffer classes are used AS THEY ARE: anything whose get() returns the
+// device pointer fits, so a caller keeps cuhd::CUHDGPUInputBuffer / CUHDGPUOutputBuffer / CUHDGPUCodetable (their
+// allocate / cpy_host_to_device members become hipMalloc / hipMemcpy in the caller's port) and only this call changes:
+//
+//     cuhd::CUHDGPUDecoder::decode(in, n_units, out, n_sym, table, aux, 11, 4, 128);      // reference
+//     glc::cuhd::CUHDGPUDecoder::decode(in, n_units, out, n_sym, table, aux, 11, 4, 128); // here
+//
+// Differences, deliberate: `aux` (the reference's synchronisation scratch, cuhd_gpu_decoder_memory.h) may be any type --
+// a null pointer of `DecoderMemory` below makes the adapter allocate and cache its own work buffer; the subsequence
+// size and threads-per-block hints are accepted and ignored (the span functions of hd_decode.hip need no
+// self-synchronisation rounds, so there is nothing to tune and no device->host flag copy per round,
+// cuhd_gpu_decoder.cu:459-495); codewords longer than 11 bits are refused, as the reference's table format does.
+#pragma once
+#include <cstddef>
+#include <memory>
+#include <stdexcept>
+#include <hip/hip_runtime.h>
+#include "glc_hd.h"
+
+namespace glc { namespace cuhd {
+
+// work buffer of a decode (what cuhd::CUHDGPUDecoderMemory is to the reference): sized for the largest stream seen
+class DecoderMemory {
+  public:
+    DecoderMemory() = default;
+    DecoderMemory(const DecoderMemory &) = delete;
+    DecoderMemory &operator=(const DecoderMemory &) = delete;
+    ~DecoderMemory() { if (ptr_) (void)hipFree(ptr_); }
+    void *reserve(std::size_t units)
+    {
+        const std::size_t need = glcHdWorkBytes(units);
+        if (need > bytes_) {
+            if (ptr_) (void)hipFree(ptr_);
+            ptr_ = nullptr; bytes_ = 0;
+            if (hipMalloc(&ptr_, need) != hipSuccess) throw std::runtime_error("glc::cuhd::DecoderMemory: hipMalloc failed");
+            bytes_ = need;
+        }
+        return ptr_;
+    }
+  private:
+    void *ptr_ = nullptr;
+    std::size_t bytes_ = 0;
+};
+
+class CUHDGPUDecoder {
+  public:
+    template <class InputBuffer, class OutputBuffer, class Codetable, class Aux>
+    static void decode(std::shared_ptr<InputBuffer> input, std::size_t input_size, std::shared_ptr<OutputBuffer> output,
+                       std::size_t output_size, std::shared_ptr<Codetable> table, std::shared_ptr<Aux> /*aux*/,
+                       std::size_t max_codeword_length, std::size_t /*preferred_subsequence_size*/,
+                       std::size_t /*threads_per_block*/, hipStream_t stream = nullptr)
+    {
+        if (!input || !output || !table) throw std::invalid_argument("glc::cuhd::CUHDGPUDecoder::decode: null buffer");
+        if (max_codeword_length > GLC_HD_MAX_LEN) throw std::invalid_argument("glc::cuhd::CUHDGPUDecoder::decode: codewords longer than 11 bits");
+        static thread_local DecoderMemory work;                // one per calling thread, grown on demand
+        void *w = work.reserve(input_size);
+        const int ok = glcHdDecodeDeviceTableOnDevice(reinterpret_cast<const unsigned int *>(input->get()), input_size,
+                                                      reinterpret_cast<const unsigned char *>(table->get()),
+                                                      reinterpret_cast<unsigned char *>(output->get()), output_size, w, stream);
+        if (!ok) throw std::runtime_error("glc::cuhd::CUHDGPUDecoder::decode: glcHdDecodeDeviceTableOnDevice failed");
+    }
+};
+
+}} // namespace glc::cuhd

@@ -57,6 +57,12 @@ int glcHdDecodeDevice(const unsigned int *d_units, size_t nunits, const unsigned
 int glcHdDecodeDeviceTable(const unsigned int *d_units, size_t nunits, const unsigned char *table2048,
                            unsigned char *d_out, size_t nsym, void *d_work, void *stream);
 
+/* Same again, with the table where cuhd::CUHDGPUCodetable keeps it -- in DEVICE memory (its get() pointer).  Nothing is
+ * copied and the host is not held: the decode is only enqueued on `stream`.  include/glc_cuhd_adapter.hpp wraps this in
+ * the reference's own call signature. */
+int glcHdDecodeDeviceTableOnDevice(const unsigned int *d_units, size_t nunits, const unsigned char *d_table2048,
+                                   unsigned char *d_out, size_t nsym, void *d_work, void *stream);
+
 /* Measurement aid: live per-kernel profile of the two decode entry points (hipEvent pairs on the call's stream around
  * k_hd_span_functions / the three k_hd_walk launches / k_hd_emit).  glcHdEnableProfile(1) switches it on and resets it;
  * glcHdKernelProfile(i, name, cap, out3) waits for the device and returns 1 with the slot's name and

@@ -61,3 +61,42 @@ def test_c_caller_culzss_pipeline_sequence(glc, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
     assert r.stdout.count("packed_equal=1") == 4 and r.stdout.count("candidates_equal=1") == 4
+
+
+def _build_cpp(tmp_path):
+    exe = str(tmp_path / "cuhd_adapter_rig")
+    cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_caller", "cuhd_adapter_rig.cpp"), "-o", exe,
+           "-L", PKG, "-lglc_amd", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cuhd_adapter_compiles_with_gpp(glc, tmp_path):
+    """include/glc_cuhd_adapter.hpp (the reference's cuhd::CUHDGPUDecoder::decode signature over the C ABI) is plain
+    host C++: g++, not hipcc"""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    glc.lib()
+    assert os.path.exists(_build_cpp(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 1])
+def test_cuhd_adapter_decodes_reference_encoded_stream(glc, tmp_path, case):
+    """a C++ caller with the reference's call shape decodes a stream written by the reference's own encoder
+    (tests/golden/ref_cuhd_gold.npz) -- table in device memory, as cuhd::CUHDGPUCodetable holds it"""
+    import numpy as np
+    glc.lib()
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_cuhd_gold.npz"))
+    name = [str(c) for c in ref["cases"]][case]
+    import test_hd
+    sym = test_hd._ref_symbols(name)
+    ref[name + "_units"].astype(np.uint32).tofile(str(tmp_path / "units.bin"))
+    np.ascontiguousarray(ref[name + "_table"]).astype(np.uint8).tofile(str(tmp_path / "table.bin"))
+    sym.astype(np.uint8).tofile(str(tmp_path / "symbols.bin"))
+    exe = _build_cpp(tmp_path)
+    r = subprocess.run([exe, str(tmp_path / "units.bin"), str(tmp_path / "table.bin"), str(tmp_path / "symbols.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "decoded_equals_original=1" in r.stdout, r.stdout + r.stderr

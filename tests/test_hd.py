@@ -159,3 +159,10 @@ def test_device_decodes_reference_encoded_stream(glc, cuda, name):
     back = glc.hd_decode_device(d_units, REF[name + "_lens"], REF[name + "_codes"].astype(np.uint16), sym.size)
     torch.cuda.synchronize()
     assert np.array_equal(back.cpu().numpy(), sym)
+    # the table where cuhd::CUHDGPUCodetable keeps it: in device memory (glcHdDecodeDeviceTableOnDevice)
+    d_table = torch.from_numpy(table.view(np.uint8).reshape(-1).copy()).cuda()
+    out.zero_()
+    assert L.glcHdDecodeDeviceTableOnDevice(d_units.data_ptr(), units.size, d_table.data_ptr(), out.data_ptr(), sym.size,
+                                            work.data_ptr(), None) == 1
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), sym)
