@@ -309,6 +309,7 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
     if (e == hipSuccess && (nflag || !speculate)) {
         // sa_build_finish has queued the other sorters for the flagged blocks on st; this pass is ordered after the
         // last of them (ev_sorted) and touches only those blocks
+        tm.mark(1);                                            // the sort stage ends here: the other tiers' time is the sort's
         after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr);
     }
     tm.done();

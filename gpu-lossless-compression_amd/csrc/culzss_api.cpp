@@ -533,7 +533,10 @@ int culzss_container_decompress(const unsigned char *in, unsigned long long len,
         for (int i = 0; good && i < G.nbuf; i++) {
             const size_t a = cumat(first + i), b = cumat(first + i + 1);
             const size_t sz = b - a;
-            if (b < a || sz > (size_t)CBUF || payload + b > len) { good = false; break; }
+            // (a packed chunk may be LONGER than the buffer: the reference's packer only gives up when the bytes flushed
+            //  before the last group outgrow it, so up to BUFSIZE + 535 bytes reach the file -- include/culzss.h -- and
+            //  its decoder takes everything that is not exactly BUFSIZE as packed, deculzss.c:92-98)
+            if (b < a || sz > stride || payload + b > len) { good = false; break; }
             const uint8_t *src = in + payload + a;
             if (sz != (size_t)CBUF) {                                          // packed: must hold its trailer, and the trailer
                 constexpr size_t TR = 2 * (CBUF / GLC_LZSS_PACKET) + 6;        // must describe a 1 MiB buffer without padding

@@ -265,12 +265,19 @@ hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride
 __global__ __launch_bounds__(256) void k_expand_copy(const uint32_t *__restrict__ in,
                                                      const unsigned long long *__restrict__ off, size_t stride,
                                                      uint32_t *__restrict__ comp, uint32_t *__restrict__ sizes,
-                                                     uint32_t *__restrict__ d_status)
+                                                     uint32_t *__restrict__ d_status, uint32_t nblk)
 {
     const uint32_t b = blockIdx.y;
-    unsigned long long sz = off[b + 1] - off[b];
+    // the offsets come from another process (the exchange): they must ascend and stay inside the total the caller's
+    // buffer holds (off[nblk]); a block that does not is reported and nothing of it is read
+    const unsigned long long lo = off[b], hi = off[b + 1], total = off[nblk];
+    unsigned long long sz = hi - lo;
+    if (hi < lo || hi > total) {
+        sz = 0;
+        if (d_status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(d_status, ST_CORRUPT);
+    }
     if (sz > stride) { sz = stride; if (d_status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(d_status, ST_CAPACITY); }
-    const uint32_t *src = in + off[b];
+    const uint32_t *src = in + lo;
     uint32_t *dst = comp + (size_t)b * stride;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < (uint32_t)sz; i += gridDim.x * 256) dst[i] = src[i];
     if (sizes && blockIdx.x == 0 && threadIdx.x == 0) sizes[b] = (uint32_t)sz;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void k_expand_copy(const uint32_t *__restrict_
 hipError_t expand_streams(hipStream_t st, const uint32_t *d_in, const unsigned long long *d_off, uint32_t nblk,
                           uint32_t *d_comp, size_t stride, uint32_t *d_sizes, uint32_t *d_status)
 {
-    hipLaunchKernelGGL(k_expand_copy, dim3(32, nblk), dim3(256), 0, st, d_in, d_off, stride, d_comp, d_sizes, d_status);
+    hipLaunchKernelGGL(k_expand_copy, dim3(32, nblk), dim3(256), 0, st, d_in, d_off, stride, d_comp, d_sizes, d_status, nblk);
     return hipGetLastError();
 }
 

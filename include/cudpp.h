@@ -241,7 +241,8 @@ CUDPPResult glcCompactStreams(CUDPPHandle planHandle, const unsigned int *d_comp
 
 /* The mirror of glcCompactStreams (decode side of the multi-GPU exchange): block b's words move from
  * d_in[d_inOffsets[b] .. d_inOffsets[b+1]) back to the strided layout glcDecompressBatch reads;
- * d_compressedSize (optional) receives the word counts. */
+ * d_compressedSize (optional) receives the word counts.  d_in holds d_inOffsets[numBlocks] words; offsets that do
+ * not ascend or pass that total are reported (glcPlanSynchronize -> CUDPP_ERROR_UNKNOWN) and the block is left empty. */
 CUDPPResult glcExpandStreams(CUDPPHandle planHandle, const unsigned int *d_in, const unsigned long long *d_inOffsets,
                              size_t numBlocks, unsigned int *d_compressed, size_t compressedStrideWords,
                              unsigned int *d_compressedSize);

@@ -377,3 +377,23 @@ def test_randomised_parity_sweep(glc, cuda):
         assert L.glcLzssDecodeDevice(d_packed.data_ptr(), d_size.data_ptr(), n, 1, d_out.data_ptr(), None) == 1
         torch.cuda.synchronize()
         assert np.array_equal(d_out.cpu().numpy(), x), tag + " round trip"
+
+
+def test_container_with_a_packed_chunk_longer_than_the_buffer(glc, cuda):
+    """ADVICE.md (round 2): a file written by the REFERENCE can hold a packed chunk of up to BUFSIZE + 535 bytes (its packer
+    gives up only when the bytes flushed before the last group outgrow the buffer), and its decoder takes anything that
+    is not exactly BUFSIZE as packed (deculzss.c:92-98).  Such a container -- built here by hand from the packed form
+    the reference's rules give for the 118 685-byte-run input, 1 049 103 bytes -- must decode to the input."""
+    L = glc.lib()
+    x = datagen.lzss_gold_inputs()["run_118685"]
+    packed = O.lzss_pack(O.lzss_candidates(x), MiB)
+    assert packed is not None and packed.size == 1049103 > MiB
+    blob = np.concatenate([np.array([1, 0, packed.size], dtype=np.uint32).view(np.uint8), packed])
+    back = np.zeros(MiB, dtype=np.uint8)
+    k = C.c_ulonglong(0)
+    assert L.culzss_container_decompress(blob.ctypes.data, blob.size, back.ctypes.data, back.size, C.byref(k)) == 1
+    assert k.value == MiB and np.array_equal(back, x)
+    # one byte more than a slot can hold is refused, not followed
+    too_long = np.concatenate([np.array([1, 0, int(L.glcLzssPackStride(MiB)) + 1], dtype=np.uint32).view(np.uint8),
+                               np.zeros(int(L.glcLzssPackStride(MiB)) + 1, dtype=np.uint8)])
+    assert L.culzss_container_decompress(too_long.ctypes.data, too_long.size, back.ctypes.data, back.size, C.byref(k)) == 0

@@ -74,3 +74,23 @@ def test_exchange_world_of_one_through_the_c_abi(glc, cuda):
     assert L.glcGatherStreams(xch.comm, 3, None, None, 514, cnt, None, None, None) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
     assert L.glcGatherStreams(xch.comm, 0, None, None, 514, cnt, None, None, None) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
     xch.close()
+
+
+def test_expand_streams_refuses_offsets_that_do_not_ascend(glc, cuda):
+    """ADVICE.md (round 2): the offsets glcExpandStreams reads come from another process; off[b+1] < off[b] used to turn
+    into a copy of `stride` words from wherever in + off[b] pointed.  Now: reported, block left empty."""
+    import torch
+    L = glc.lib()
+    nblk, stride = 3, glc.compressed_stride_words(N)
+    words = torch.arange(1000, dtype=torch.int32, device=cuda)
+    for off in ([0, 400, 300, 1000], [0, 400, 1200, 1000]):               # descending / past the total
+        d_off = torch.tensor(off, dtype=torch.int64, device=cuda)
+        strided = torch.full((nblk * stride,), -1, dtype=torch.int32, device=cuda)
+        sizes = torch.full((nblk,), -1, dtype=torch.int32, device=cuda)
+        with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, N, rows=nblk) as plan:
+            assert L.glcExpandStreams(plan.handle, words.data_ptr(), d_off.data_ptr(), nblk, strided.data_ptr(), stride, sizes.data_ptr()) == 0
+            with pytest.raises(glc.CudppError):
+                plan.synchronize()
+        s = sizes.cpu().numpy()
+        assert s[0] == 400 and s[1] == 0, s
+        assert torch.equal(strided[:400], words[:400]) and int(strided[stride].item()) == -1
