@@ -499,34 +499,47 @@ __device__ __forceinline__ uint32_t row_symbol(const uint8_t *__restrict__ B, ui
     return (r == index + 1) ? 0u : x + 1;
 }
 
+// (8 copies of the 512-bin histogram per workgroup, copy = lane & 7 at a stride of 513 words: equal symbols inside a wave
+//  serialise on an LDS atomic, and Zipf data puts ten lanes of a wave on the most frequent symbol -- the form k_fs_hist
+//  uses on the encode side; with one copy per wave this kernel ran at 1.1 TB/s, a third of that one)
 __global__ __launch_bounds__(256) void k_ibwt_hist(const uint8_t *__restrict__ bwt, size_t bwt_stride,
                                                    const int *__restrict__ d_index, uint32_t n,
                                                    uint32_t *__restrict__ tile_hist, uint32_t max_tiles,
                                                    uint32_t *__restrict__ d_status)
 {
-    __shared__ uint32_t s_h[4][512];
-    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
+    __shared__ uint32_t s_h[8 * 513];
+    const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     const uint32_t rows = n + 1, base = t * LF_TILE;
     if (base >= rows) return;
-    for (uint32_t i = tid; i < 4 * 512; i += 256) (&s_h[0][0])[i] = 0;
+    for (uint32_t i = tid; i < 8 * 513; i += 256) s_h[i] = 0;
     __syncthreads();
     const uint8_t *B = bwt + (size_t)b * bwt_stride;
     uint32_t index = (uint32_t)d_index[b];
     if (index >= n) { index = n - 1; if (d_status && t == 0 && tid == 0) atomicOr(d_status, ST_CORRUPT); }   // row index from the stream
-    uint32_t sy[LF_TILE / 256];
+    uint32_t *H8 = s_h + (tid & 7) * 513;
+    // rows base .. base + LF_TILE are the bytes bwt[base - 1 ..]: thread = 8 consecutive rows, read as one unaligned
+    // 8-byte load where that stays inside the block and clear of the two special rows
+    const uint32_t r0 = base + tid * 8;
+    if (r0 >= 1 && r0 + 8 <= rows && !(index + 1 >= r0 && index + 1 < r0 + 8)) {
+        uint64_t q;
+        __builtin_memcpy(&q, B + r0 - 1, 8);
 #pragma unroll
-    for (int k = 0; k < LF_TILE / 256; k++) {
-        const uint32_t r = base + k * 256 + tid;
-        sy[k] = row_symbol(B, r < rows ? r : 0u, index);
-    }
+        for (int k = 0; k < 8; k++) atomicAdd(&H8[(uint32_t)((q >> (8 * k)) & 0xFFu) + 1u], 1u);
+    } else {
 #pragma unroll
-    for (int k = 0; k < LF_TILE / 256; k++) {
-        const uint32_t r = base + k * 256 + tid;
-        if (r < rows) atomicAdd(&s_h[w][sy[k]], 1u);
+        for (int k = 0; k < 8; k++) {
+            const uint32_t r = r0 + k;
+            if (r < rows) atomicAdd(&H8[row_symbol(B, r, index)], 1u);
+        }
     }
     __syncthreads();
     uint32_t *H = tile_hist + ((size_t)b * max_tiles + t) * 512;
-    for (uint32_t d = tid; d < 512; d += 256) H[d] = s_h[0][d] + s_h[1][d] + s_h[2][d] + s_h[3][d];
+    for (uint32_t d = tid; d < 512; d += 256) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c += s_h[k * 513 + d];
+        H[d] = c;
+    }
 }
 
 // LF(r) = start of the symbol's bucket + number of equal symbols in earlier rows
@@ -537,6 +550,9 @@ __global__ __launch_bounds__(256) void k_ibwt_lf(const uint8_t *__restrict__ bwt
                                                  uint32_t *__restrict__ lf, size_t lf_stride)
 {
     __shared__ uint32_t s_wc[4][512];
+    // (peers found by a ballot per symbol bit, wave_match<9>.  Measured against it: every lane ORs its bit into a per-symbol
+    //  64-bit LDS entry and reads the entry back -- the form k_mtf_encode uses -- 548 us per 256 blocks against 523: the
+    //  same-address atomics of the frequent symbols cost what the ballots do.)
     const uint32_t b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x, l = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t rows = n + 1, base = t * LF_TILE;
