@@ -439,6 +439,185 @@ __global__ __launch_bounds__(64) void k_imtf_pos(const uint8_t *__restrict__ in,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pass 1, second form (the default): the list as a DEQUE WITH HOLES.  Moving entry r to the front of an array shifts r
+// entries; the ring form above cuts that to one byte per 16-entry group below the hit, and still spends ~135 of its 212
+// wave instructions per step in the loop over those groups -- executed as often as the LARGEST index of the wave asks
+// for, and MTF indices of near-incompressible data are large.  Here nothing is shifted at all.  A lane's list lives in
+// 512 POSITIONS (lower = nearer the front): a 512-byte array A and a 512-bit bitmap V of the positions in use, exactly
+// 256 of them.  A step with index r
+//     finds the r-th position in use, p   -- SELECT on the bitmap: a 3-level tree of counts kept in registers names the
+//                                            64-bit word, byte counts (SWAR) name the byte, a 2 KB table the bit;
+//     reads the entry A[p], clears V[p], and writes the entry at the front: position f - 1, V[f - 1] set, f -= 1
+// (f is the same for all lanes: it steps down by one per symbol whatever the data is).  After 256 steps the front has
+// reached position 0 and the 256 live entries are packed back to positions 256..511, four bytes at a time (v_perm with
+// a 16-entry selector table, no divergence: every lane holds exactly 256 entries).  ~75 VALU + 6 LDS instructions per
+// step instead of 212 + 41; 36 KB of LDS per wave (one wave per SIMD), so a step is the latency of its chain
+// (tree descent -> word -> byte -> bit: three LDS round trips), ~420 cycles.
+// Same outputs as the ring form: the position byte of every symbol and the chunk's final list (its permutation).
+// ---------------------------------------------------------------------------
+constexpr uint32_t IMD_POS = 512;
+
+__global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict__ in, size_t in_stride, uint32_t n,
+                                                       uint8_t *__restrict__ lists, uint32_t max_chunks,
+                                                       uint8_t *__restrict__ pos_out, size_t out_stride)
+{
+    __shared__ uint32_t s_a[(IMD_POS / 4) * 64];              // entry at position p of lane l: byte p & 3 of s_a[(p >> 2) * 64 + l] (lane l = bank l)
+    __shared__ uint2 s_v[8 * 64];                             // bitmap word k of lane l: s_v[k * 64 + l]
+    __shared__ uint8_t s_sel[256 * 8];                        // s_sel[b * 8 + j] = index of the j-th set bit of byte b
+    __shared__ uint32_t s_pack[16];                           // v_perm selector that moves the bytes of mask m to the top of a dword, in order
+    const uint32_t b = blockIdx.y, l = threadIdx.x;
+    const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
+    const uint32_t chunk = blockIdx.x * 64 + l;
+    const bool live = chunk < nchunks;
+    const uint32_t lo = chunk * IMTF_CHUNK;
+    const uint32_t cnt = live ? min(IMTF_CHUNK, n - lo) : 0u;
+    const uint8_t *src = in + (size_t)b * in_stride + lo;
+    uint8_t *dst = pos_out + (size_t)b * out_stride + lo;
+    const bool vec_ok = ((reinterpret_cast<size_t>(src) | reinterpret_cast<size_t>(dst)) & 15) == 0;
+    uint8_t *s_ab = reinterpret_cast<uint8_t *>(s_a);
+    // tables
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) {
+        const uint32_t byte = l * 4 + t;
+        uint32_t j = 0;
+        for (uint32_t bit = 0; bit < 8; bit++)
+            if ((byte >> bit) & 1u) s_sel[byte * 8 + j++] = (uint8_t)bit;
+        for (; j < 8; j++) s_sel[byte * 8 + j] = 0;
+    }
+    if (l < 16) {
+        // bytes of the dword whose mask bit is set, kept in order, moved to the top; 0x0C selects a zero byte
+        uint32_t sel = 0x0C0C0C0Cu, c = (uint32_t)__popc(l), at = 4 - c;
+        for (uint32_t i = 0; i < 4; i++)
+            if ((l >> i) & 1u) { sel = (sel & ~(0xFFu << (8 * at))) | (i << (8 * at)); at++; }
+        s_pack[l] = sel;
+    }
+    // identity list at positions 256 .. 511
+#pragma unroll
+    for (uint32_t d = 0; d < 64; d++) s_a[(64 + d) * 64 + l] = 0x03020100u + 0x04040404u * d;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) s_v[k * 64 + l] = k < 4 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    __builtin_amdgcn_wave_barrier();
+    // counts of positions in use: words 0-3 | words 0-1, 4-5 | words 0, 2, 4, 6
+    uint32_t c03 = 0, c01 = 0, c45 = 128, c0 = 0, c2 = 0, c4 = 64, c6 = 64;
+    const uint32_t lbase = l * 4;
+
+    // the 256 entries in use back to positions 256 .. 511 (order kept); resets the counts
+    auto compact = [&]() {
+        uint32_t acc_hi = 0, acc_lo = 0, nacc = 0, dd = 127;        // bytes waiting at the top of acc; next dword to fill
+#pragma unroll 1
+        for (int k = 7; k >= 0; k--) {
+            const uint2 w = s_v[k * 64 + l];
+#pragma unroll
+            for (int q = 15; q >= 0; q--) {
+                const uint32_t d = (uint32_t)k * 16u + (uint32_t)q;
+                const uint32_t m = ((q >= 8 ? w.y : w.x) >> (4 * (q & 7))) & 15u;
+                const uint32_t a = s_a[d * 64 + l];
+                const uint32_t packed = __builtin_amdgcn_perm(0u, a, s_pack[m]);     // the bytes in use, top-aligned
+                // below the nacc bytes already waiting
+                const uint64_t sh = ((uint64_t)packed << 32) >> (8 * nacc);
+                acc_hi |= (uint32_t)(sh >> 32); acc_lo |= (uint32_t)sh;
+                nacc += (uint32_t)__popc(m);
+                if (nacc >= 4) { s_a[dd * 64 + l] = acc_hi; dd--; acc_hi = acc_lo; acc_lo = 0; nacc -= 4; }
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) s_v[k * 64 + l] = k < 4 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        c03 = 0; c01 = 0; c45 = 128; c0 = 0; c2 = 0; c4 = 64; c6 = 64;
+    };
+
+    auto load16 = [&](uint32_t j, uint32_t *rv) {
+        rv[0] = rv[1] = rv[2] = rv[3] = 0;
+        if (vec_ok && j + 16 <= cnt) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(src + j);
+            rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
+        } else if (j < cnt) {
+            for (uint32_t t = 0; t < min(16u, cnt - j); t++) rv[t >> 2] |= (uint32_t)src[j + t] << (8 * (t & 3));
+        }
+    };
+    uint32_t nx[4];
+    load16(0, nx);
+    uint32_t f = 256;                                              // front: the next entry goes to position f - 1 (wave-uniform)
+    for (uint32_t j = 0; j < IMTF_CHUNK; j += 16) {
+        if (__ballot(j < cnt) == 0) break;
+        uint32_t rv[4] = {nx[0], nx[1], nx[2], nx[3]}, ov[4] = {0, 0, 0, 0};
+        load16(j + 16, nx);                                        // in flight while these 16 are processed
+#pragma unroll
+        for (uint32_t t = 0; t < 16; t++) {
+            // past the end of the chunk: index 0 (the front entry moves to the front: the order stays)
+            uint32_t rr = (j + t < cnt) ? (rv[t >> 2] >> (8 * (t & 3))) & 0xFFu : 0u;
+            // ---- select: word
+            const bool g1 = rr >= c03;
+            rr -= g1 ? c03 : 0u;
+            const uint32_t cm = g1 ? c45 : c01;
+            const bool g2 = rr >= cm;
+            rr -= g2 ? cm : 0u;
+            const uint32_t ce = g1 ? (g2 ? c6 : c4) : (g2 ? c2 : c0);
+            const bool g3 = rr >= ce;
+            rr -= g3 ? ce : 0u;
+            const uint32_t k = (g1 ? 4u : 0u) + (g2 ? 2u : 0u) + (g3 ? 1u : 0u);
+            uint2 w = s_v[k * 64 + l];
+            // ---- half, byte, bit
+            const uint32_t ch = (uint32_t)__popc(w.x);
+            const bool gh = rr >= ch;
+            rr -= gh ? ch : 0u;
+            const uint32_t x = gh ? w.y : w.x;
+            const uint32_t x1 = x - ((x >> 1) & 0x55555555u);
+            const uint32_t x2 = (x1 & 0x33333333u) + ((x1 >> 2) & 0x33333333u);
+            const uint32_t x4 = (x2 + (x2 >> 4)) & 0x0F0F0F0Fu;
+            const uint32_t cum = x4 * 0x01010101u;                 // byte i = entries in use in bytes 0 .. i of x
+            const uint32_t jb = (rr >= (cum & 0xFFu) ? 1u : 0u) + (rr >= ((cum >> 8) & 0xFFu) ? 1u : 0u) +
+                                (rr >= ((cum >> 16) & 0xFFu) ? 1u : 0u);
+            rr -= ((cum << 8) >> (8 * jb)) & 0xFFu;                // entries in the bytes below jb
+            const uint32_t byte = (x >> (8 * jb)) & 0xFFu;
+            const uint32_t bit = s_sel[byte * 8 + rr];
+            const uint32_t pin = (gh ? 32u : 0u) + jb * 8u + bit;  // position inside the word
+            const uint32_t p = k * 64u + pin;
+            const uint32_t sym = s_ab[((p >> 2) << 8) + lbase + (p & 3u)];
+            // ---- out of its place ...
+            const uint32_t clr = ~(1u << (pin & 31u));
+            if (gh) w.y &= clr; else w.x &= clr;
+            s_v[k * 64 + l] = w;
+            c03 -= g1 ? 0u : 1u;
+            c01 -= (!g1 && !g2) ? 1u : 0u;
+            c45 -= (g1 && !g2) ? 1u : 0u;
+            c0 -= (!g1 && !g2 && !g3) ? 1u : 0u;
+            c2 -= (!g1 && g2 && !g3) ? 1u : 0u;
+            c4 -= (g1 && !g2 && !g3) ? 1u : 0u;
+            c6 -= (g1 && g2 && !g3) ? 1u : 0u;
+            // ---- ... to the front (f, and with it everything below, is the same for every lane)
+            f -= 1;
+            const uint32_t kf = f >> 6;
+            s_ab[((f >> 2) << 8) + lbase + (f & 3u)] = (uint8_t)sym;
+            {
+                const uint32_t fb = 1u << (f & 31u);
+                uint2 *vw = &s_v[kf * 64 + l];
+                if (f & 32u) atomicOr(&vw->y, fb); else atomicOr(&vw->x, fb);
+            }
+            c03 += 1;                                              // (f < 256: words 0 - 3)
+            c01 += kf < 2 ? 1u : 0u;
+            c0 += kf == 0 ? 1u : 0u;
+            c2 += kf == 2 ? 1u : 0u;
+            ov[t >> 2] |= sym << (8 * (t & 3));
+        }
+        if (vec_ok && j + 16 <= cnt) {
+            *reinterpret_cast<uint4 *>(dst + j) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+        } else if (j < cnt) {
+            for (uint32_t t = 0; t < min(16u, cnt - j); t++) dst[j + t] = (uint8_t)(ov[t >> 2] >> (8 * (t & 3)));
+        }
+        if (f == 0) { __builtin_amdgcn_wave_barrier(); compact(); f = 256; __builtin_amdgcn_wave_barrier(); }
+    }
+    if (live && chunk + 1 < nchunks) {                           // nobody needs the last permutation
+        if (f != 256) { __builtin_amdgcn_wave_barrier(); compact(); }
+        __builtin_amdgcn_wave_barrier();
+        uint4 *LW = reinterpret_cast<uint4 *>(lists + ((size_t)b * max_chunks + chunk) * 256);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++)
+            LW[k] = make_uint4(s_a[(64 + 4 * k) * 64 + l], s_a[(64 + 4 * k + 1) * 64 + l], s_a[(64 + 4 * k + 2) * 64 + l],
+                               s_a[(64 + 4 * k + 3) * 64 + l]);
+    }
+}
+
 // lists[c] <- list at the start of chunk c ; state' [k] = state[perm_c[k]]
 __global__ __launch_bounds__(64) void k_imtf_scan(uint8_t *__restrict__ lists, uint32_t n, uint32_t max_chunks)
 {
@@ -820,8 +999,13 @@ hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t
                            d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_IMTF_POS, st) : -1;
-    hipLaunchKernelGGL(k_imtf_pos, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
-                       s.max_chunks, bwt, (size_t)s.nmax);
+    static const bool rings = getenv("GLC_IMTF_RINGS") != nullptr;   // A/B: the ring form of pass 1
+    if (rings)
+        hipLaunchKernelGGL(k_imtf_pos, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
+                           s.max_chunks, bwt, (size_t)s.nmax);
+    else
+        hipLaunchKernelGGL(k_imtf_pos_deque, dim3((nchunks + 63) / 64, nblk), dim3(64), 0, st, s.mtf, (size_t)s.nmax, n, s.ilists,
+                           s.max_chunks, bwt, (size_t)s.nmax);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_IMTF_REST, st) : -1;
     hipLaunchKernelGGL(k_imtf_scan, dim3(nblk), dim3(64), 0, st, s.ilists, n, s.max_chunks);
