@@ -26,6 +26,7 @@
 //             of 128, each piece is walked ONCE emitting into a bounded slot, pieces are
 //             ordered by list ranking in LDS and copied to their text positions.
 #include <stdlib.h>
+#include <type_traits>
 #include "glc_device.h"
 #include "glc_internal.h"
 #include "huff_tree.h"
@@ -449,7 +450,8 @@ __global__ __launch_bounds__(64) void k_imtf_pos(const uint8_t *__restrict__ in,
 //     finds the r-th position in use, p   -- SELECT on the bitmap: a 3-level tree of counts kept in registers names the
 //                                            64-bit word, byte counts (SWAR) name the byte, a 2 KB table the bit;
 //     reads the entry A[p], clears V[p], and writes the entry at the front: position f - 1, V[f - 1] set, f -= 1
-// (f is the same for all lanes: it steps down by one per symbol whatever the data is).  After 256 steps the front has
+// (f is the same for all lanes: it steps down by one per symbol whatever the data is; the counts are bytes packed in
+// two registers, so a word's share of them is one multiply away).  After 256 steps the front has
 // reached position 0 and the 256 live entries are packed back to positions 256..511, four bytes at a time (v_perm with
 // a 16-entry selector table, no divergence: every lane holds exactly 256 entries).  ~75 VALU + 6 LDS instructions per
 // step instead of 212 + 41; 36 KB of LDS per wave (one wave per SIMD), so a step is the latency of its chain
@@ -498,8 +500,6 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) s_v[k * 64 + l] = k < 4 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     __builtin_amdgcn_wave_barrier();
-    // counts of positions in use: words 0-3 | words 0-1, 4-5 | words 0, 2, 4, 6
-    uint32_t c03 = 0, c01 = 0, c45 = 128, c0 = 0, c2 = 0, c4 = 64, c6 = 64;
     const uint32_t lbase = l * 4;
 
     // the 256 entries in use back to positions 256 .. 511 (order kept); resets the counts
@@ -523,7 +523,6 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
         }
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) s_v[k * 64 + l] = k < 4 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        c03 = 0; c01 = 0; c45 = 128; c0 = 0; c2 = 0; c4 = 64; c6 = 64;
     };
 
     auto load16 = [&](uint32_t j, uint32_t *rv) {
@@ -538,26 +537,59 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
     uint32_t nx[4];
     load16(0, nx);
     uint32_t f = 256;                                              // front: the next entry goes to position f - 1 (wave-uniform)
-    for (uint32_t j = 0; j < IMTF_CHUNK; j += 16) {
-        if (__ballot(j < cnt) == 0) break;
-        uint32_t rv[4] = {nx[0], nx[1], nx[2], nx[3]}, ov[4] = {0, 0, 0, 0};
-        load16(j + 16, nx);                                        // in flight while these 16 are processed
+    // positions in use per bitmap word, a byte each: words 0-3 in cnt_lo, 4-7 in cnt_hi; tot_lo = all of words 0-3
+    // (it reaches 256, one more than a byte holds)
+    uint32_t cnt_lo = 0, cnt_hi = 0x40404040u, tot_lo = 0;
+
+    // which word holds the rr-th position in use: k = 4 g1 + kk, rr becomes the index inside the word
+    struct Sel { uint32_t k, rr, kk; bool g1; };
+    auto word_select = [&](uint32_t r) -> Sel {
+        Sel o;
+        o.g1 = r >= tot_lo;
+        uint32_t rr = r - (o.g1 ? tot_lo : 0u);
+        const uint32_t P = (o.g1 ? cnt_hi : cnt_lo) * 0x00010101u;   // bytes 0..2: positions in use in the half's words 0 / 0-1 / 0-2
+        o.kk = (rr >= (P & 0xFFu) ? 1u : 0u) + (rr >= ((P >> 8) & 0xFFu) ? 1u : 0u) + (rr >= ((P >> 16) & 0xFFu) ? 1u : 0u);
+        rr -= ((P << 8) >> (8 * o.kk)) & 0xFFu;
+        o.rr = rr;
+        o.k = (o.g1 ? 4u : 0u) + o.kk;
+        return o;
+    };
+    // one batch of 16 steps.  FULL: every lane's chunk has all 16 symbols (no bounds).  Everything that depends on the
+    // front alone is the same for all lanes and, inside a batch, a fixed offset from its value at the batch's start (f is
+    // a multiple of 16 there): with one wave per SIMD every instruction is on the critical path, scalar ones included.
+    auto batch = [&](uint32_t j, const uint32_t *rv, uint32_t *ov, auto FULL) {
+        constexpr bool full = decltype(FULL)::value;
+        const uint32_t F0 = f;                                     // positions F0 - 1 .. F0 - 16 are filled by this batch
+        const uint32_t kf = (F0 - 1) >> 6;                         // one bitmap word for the whole batch
+        const uint32_t inc = 1u << (8 * kf);
+        const bool fy = ((F0 - 1) & 32u) != 0;
+        uint32_t *vfront = fy ? &s_v[kf * 64 + l].y : &s_v[kf * 64 + l].x;
+        uint32_t fb = (F0 & 16u) ? 0x8000u : 0x80000000u;          // bit of position F0 - 1 in its 32-bit half; one to the right per step
+        uint8_t *afront = s_ab + ((((F0 >> 2) - 4u) << 8) + lbase);   // dwords F0/4 - 4 .. F0/4 - 1 of this lane
+        auto index_at = [&](uint32_t t) {
+            const uint32_t r = (rv[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+            return full ? r : ((j + t < cnt) ? r : 0u);            // past the end: index 0, the order stays
+        };
+        Sel cur = word_select(index_at(0));
+        uint2 w = s_v[cur.k * 64 + l];
 #pragma unroll
         for (uint32_t t = 0; t < 16; t++) {
-            // past the end of the chunk: index 0 (the front entry moves to the front: the order stays)
-            uint32_t rr = (j + t < cnt) ? (rv[t >> 2] >> (8 * (t & 3))) & 0xFFu : 0u;
-            // ---- select: word
-            const bool g1 = rr >= c03;
-            rr -= g1 ? c03 : 0u;
-            const uint32_t cm = g1 ? c45 : c01;
-            const bool g2 = rr >= cm;
-            rr -= g2 ? cm : 0u;
-            const uint32_t ce = g1 ? (g2 ? c6 : c4) : (g2 ? c2 : c0);
-            const bool g3 = rr >= ce;
-            rr -= g3 ? ce : 0u;
-            const uint32_t k = (g1 ? 4u : 0u) + (g2 ? 2u : 0u) + (g3 ? 1u : 0u);
-            uint2 w = s_v[k * 64 + l];
-            // ---- half, byte, bit
+            // ---- the counts after this step: one position less in word cur.k, one more in the front's word
+            {
+                const uint32_t dec = 1u << (8 * cur.kk);
+                cnt_lo += inc - (cur.g1 ? 0u : dec);
+                cnt_hi -= cur.g1 ? dec : 0u;
+                tot_lo += cur.g1 ? 1u : 0u;                        // (+1 for the front, -1 if the entry came out of words 0-3)
+            }
+            // ---- next step: word, and its load
+            Sel nxt = cur;
+            uint2 wn = w;
+            if (t < 15) {
+                nxt = word_select(index_at(t + 1));
+                wn = s_v[nxt.k * 64 + l];
+            }
+            // ---- this step: half, byte, bit
+            uint32_t rr = cur.rr;
             const uint32_t ch = (uint32_t)__popc(w.x);
             const bool gh = rr >= ch;
             rr -= gh ? ch : 0u;
@@ -565,47 +597,54 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
             const uint32_t x1 = x - ((x >> 1) & 0x55555555u);
             const uint32_t x2 = (x1 & 0x33333333u) + ((x1 >> 2) & 0x33333333u);
             const uint32_t x4 = (x2 + (x2 >> 4)) & 0x0F0F0F0Fu;
-            const uint32_t cum = x4 * 0x01010101u;                 // byte i = entries in use in bytes 0 .. i of x
+            const uint32_t cum = x4 * 0x00010101u;                 // bytes 0..2: positions in use in bytes 0 / 0-1 / 0-2 of x
             const uint32_t jb = (rr >= (cum & 0xFFu) ? 1u : 0u) + (rr >= ((cum >> 8) & 0xFFu) ? 1u : 0u) +
                                 (rr >= ((cum >> 16) & 0xFFu) ? 1u : 0u);
-            rr -= ((cum << 8) >> (8 * jb)) & 0xFFu;                // entries in the bytes below jb
+            rr -= ((cum << 8) >> (8 * jb)) & 0xFFu;
             const uint32_t byte = (x >> (8 * jb)) & 0xFFu;
             const uint32_t bit = s_sel[byte * 8 + rr];
             const uint32_t pin = (gh ? 32u : 0u) + jb * 8u + bit;  // position inside the word
-            const uint32_t p = k * 64u + pin;
+            const uint32_t p = cur.k * 64u + pin;
             const uint32_t sym = s_ab[((p >> 2) << 8) + lbase + (p & 3u)];
-            // ---- out of its place ...
+            // ---- out of its place, to the front (position F0 - 1 - t)
             const uint32_t clr = ~(1u << (pin & 31u));
-            if (gh) w.y &= clr; else w.x &= clr;
-            s_v[k * 64 + l] = w;
-            c03 -= g1 ? 0u : 1u;
-            c01 -= (!g1 && !g2) ? 1u : 0u;
-            c45 -= (g1 && !g2) ? 1u : 0u;
-            c0 -= (!g1 && !g2 && !g3) ? 1u : 0u;
-            c2 -= (!g1 && g2 && !g3) ? 1u : 0u;
-            c4 -= (g1 && !g2 && !g3) ? 1u : 0u;
-            c6 -= (g1 && g2 && !g3) ? 1u : 0u;
-            // ---- ... to the front (f, and with it everything below, is the same for every lane)
-            f -= 1;
-            const uint32_t kf = f >> 6;
-            s_ab[((f >> 2) << 8) + lbase + (f & 3u)] = (uint8_t)sym;
-            {
-                const uint32_t fb = 1u << (f & 31u);
-                uint2 *vw = &s_v[kf * 64 + l];
-                if (f & 32u) atomicOr(&vw->y, fb); else atomicOr(&vw->x, fb);
-            }
-            c03 += 1;                                              // (f < 256: words 0 - 3)
-            c01 += kf < 2 ? 1u : 0u;
-            c0 += kf == 0 ? 1u : 0u;
-            c2 += kf == 2 ? 1u : 0u;
+            const uint32_t clrx = gh ? 0xFFFFFFFFu : clr, clry = gh ? clr : 0xFFFFFFFFu;
+            w.x &= clrx; w.y &= clry;
+            s_v[cur.k * 64 + l] = w;
+            afront[((3u - (t >> 2)) << 8) + (3u - (t & 3u))] = (uint8_t)sym;
+            atomicOr(vfront, fb);
             ov[t >> 2] |= sym << (8 * (t & 3));
+            // ---- what this step did to the word the next step has already loaded
+            if (t < 15) {
+                const bool same = nxt.k == cur.k, front = nxt.k == kf;
+                wn.x = (wn.x & (same ? clrx : 0xFFFFFFFFu)) | ((front && !fy) ? fb : 0u);
+                wn.y = (wn.y & (same ? clry : 0xFFFFFFFFu)) | ((front && fy) ? fb : 0u);
+            }
+            fb >>= 1;
+            cur = nxt; w = wn;
         }
+        f = F0 - 16;
+    };
+    for (uint32_t j = 0; j < IMTF_CHUNK; j += 16) {
+        if (__ballot(j < cnt) == 0) break;
+        uint32_t rv[4] = {nx[0], nx[1], nx[2], nx[3]}, ov[4] = {0, 0, 0, 0};
+        load16(j + 16, nx);                                        // in flight while these 16 are processed
+        // Steps are software-pipelined: the word of step t + 1 is chosen and its load issued BEFORE step t has found its
+        // bit -- the counts already know which words step t takes from and gives to -- and what step t then changes in
+        // that word is applied to the loaded copy in registers.  (One wave per SIMD: nothing else hides the round trips.)
+        if (__ballot(j + 16 > cnt) == 0) batch(j, rv, ov, std::true_type{});
+        else batch(j, rv, ov, std::false_type{});
         if (vec_ok && j + 16 <= cnt) {
             *reinterpret_cast<uint4 *>(dst + j) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
         } else if (j < cnt) {
             for (uint32_t t = 0; t < min(16u, cnt - j); t++) dst[j + t] = (uint8_t)(ov[t >> 2] >> (8 * (t & 3)));
         }
-        if (f == 0) { __builtin_amdgcn_wave_barrier(); compact(); f = 256; __builtin_amdgcn_wave_barrier(); }
+        if (f == 0) {
+            __builtin_amdgcn_wave_barrier();
+            compact();
+            f = 256; cnt_lo = 0; cnt_hi = 0x40404040u; tot_lo = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     if (live && chunk + 1 < nchunks) {                           // nobody needs the last permutation
         if (f != 256) { __builtin_amdgcn_wave_barrier(); compact(); }
