@@ -882,8 +882,14 @@ __global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ 
 //  a window reaches 125 G steps/s with 64 K lanes (tools/probes/window_probe.hip), but with the real
 //  step (symbol packing, slot stores, piece bookkeeping) and one wave per SIMD the issue time of the
 //  step is no longer hidden: wave-pooled tickets 5.2-5.6 ms, strided static pieces 6.3-6.9 ms
-//  (imbalance), against 5.2 ms for the plain launch below.  The way forward is more pieces per block
-//  (16-row splitters, two-level ordering) so that a small window still fills the machine.)
+//  (imbalance), against 5.2 ms for the plain launch below.  Round 3, a fourth time, with what round 2 added -- the
+//  XCD-aware order -- built in: persistent lanes that take the next (block, splitter) piece from a pool their wave
+//  refills from ONE counter per XCD, so that every lane stays busy (in the plain launch a wave lasts as long as its
+//  longest walk, ~4.7 x the mean: four lanes of five idle) and all the waves of an XCD work through the same block's
+//  table.  1 / 2 / 4 / 8 waves per SIMD: walk 4.07 / 4.6 / 5.2 / 5.3 ms per 256 blocks against 3.6 for the plain
+//  launch -- MORE lanes on one table is slower, fewer blocks in flight is not faster: the walk is not short of
+//  parallelism or of cache, it runs at the rate the memory system takes dependent random 4-byte reads.
+//  The way forward is more pieces per block (16-row splitters, two-level ordering) only if that rate can be raised.)
 __global__ void k_ibwt_seg_init(uint32_t *__restrict__ seg_count, uint32_t n, uint32_t nblk)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
