@@ -15,7 +15,7 @@ UNITS = float(256 << 20)          # the counters were collected on launches over
 SHORT = {"k_fs_part": "k_fs_part<false>(", "k_fs_sort": "k_fs_sort(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
          "k_mtf_encode": "k_mtf_encode<", "k_huff_pack": "k_huff_pack(", "k_huff_build": "k_huff_build(",
          "k_mtf_chunk_lists": "k_mtf_chunk_lists(", "k_mtf_scan_lists": "k_mtf_scan_lists(",
-         "k_ibwt_walk": "k_ibwt_walk<", "k_imtf_pos": "k_imtf_pos(", "k_dec_huff_lanes": "k_dec_huff_lanes(",
+         "k_ibwt_walk": "k_ibwt_walk<", "k_imtf_pos": "k_imtf_pos_deque(", "k_dec_huff_lanes": "k_dec_huff_lanes(",
          "k_ibwt_lf": "k_ibwt_lf(", "k_ibwt_emit": "k_ibwt_emit(", "k_ibwt_hist": "k_ibwt_hist(",
          "k_imtf_apply": "k_imtf_apply(", "k_imtf_scan": "k_imtf_scan(", "k_ibwt_rank": "k_ibwt_rank(",
          "k_dec_prepare": "k_dec_prepare("}
@@ -63,6 +63,9 @@ def main():
                     "(0.59 per ns per SIMD-equivalent); `s_nop` is free at the issue stage.  LDS: a `ds_read_b32/b64/u8` wave "
                     "instruction per ~8 cycles per CU-quarter (0.28 per ns per SIMD), `b128`, writes and returning atomics half "
                     "of that, `ds_bpermute` a third.\n")
+    # the issue-rate probe is not rerun with every counter collection: cite the newest summary there is
+    vr_md = sorted(f for f in os.listdir(HERE) if f.endswith("_valu_rate.md"))
+    vr_tag = vr_md[-1][:-len("_valu_rate.md")] if vr_md else tag
     pj = os.path.join(out, tag + "_pmc_insts.json")
     if not os.path.exists(pj):
         print("no", pj)
@@ -90,7 +93,7 @@ def main():
     res = {"collected": tag, "command": raw["command"],
            "unit": "wave64 instructions per 64 input bytes (counter sum of a launch over 256 blocks of 1 MiB / 2^22)",
            "per_64_bytes": per64,
-           "issue_rate": {"source": "profiles/%s_valu_rate.json (tools/probes/valu_rate_probe.hip)" % tag,
+           "issue_rate": {"source": "profiles/%s_valu_rate.json (tools/probes/valu_rate_probe.hip)" % vr_tag,
                           "slow_class_cycles_per_inst": 4.0, "fast_class_cycles_per_inst": 2.1,
                           "slow_class": "DPP, SDWA, compares, carry ops, shifts left, min/max, multiplies, bit-field / permute ops, 3-operand integer ops, SGPR-operand forms",
                           "fast_class": "v_add_u32, v_sub_u32, v_and/or/xor_b32, v_lshrrev_b32, v_mov_b32, v_add_f32, v_fma_f32 (VGPR operands)",
@@ -100,7 +103,7 @@ def main():
         f.write("# per-kernel instruction counters (rocprofv3 --pmc, three passes, --kernel-trace only; MI355X; tag %s)\n\n`%s`\n\n" % (tag, raw["command"]))
         f.write("wave64 instructions per 64 input bytes; `us` = average launch duration under the counters (256 blocks of 1 MiB per launch);\n"
                 "`VALU x 4 cyc` = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x launch cycles at 2.4 GHz): the share of the VALU issue slots if every\n"
-                "instruction were of the 4-cycle class (profiles/%s_valu_rate.md); `SALU` = SQ_INSTS_SALU / (256 CUs x launch cycles).\n\n" % tag)
+                "instruction were of the 4-cycle class (profiles/%s_valu_rate.md); `SALU` = SQ_INSTS_SALU / (256 CUs x launch cycles).\n\n" % vr_tag)
         f.write("| kernel | VALU | SALU | LDS | VMEM rd | VMEM wr | us | VALU x 4 cyc | SALU pipe | LDS bank-conflict share |\n|---|---|---|---|---|---|---|---|---|---|\n")
         for short, e in rows:
             cyc = e["avg_us_under_counters_256_blocks"] * 1e-6 * 2.4e9

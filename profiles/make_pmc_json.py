@@ -71,7 +71,12 @@ def main():
     short = {"k_fs_part": "k_fs_part<false>(", "k_fs_sort": "k_fs_sort(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
              "k_mtf_encode": "k_mtf_encode<", "k_huff_pack": "k_huff_pack(", "k_huff_build": "k_huff_build(",
              "k_mtf_chunk_lists": "k_mtf_chunk_lists(", "k_mtf_scan_lists": "k_mtf_scan_lists(",
-             "k_rs_onesweep<8,false>": "k_rs_onesweep<8, false"}
+             "k_rs_onesweep<8,false>": "k_rs_onesweep<8, false",
+             # decoder
+             "k_dec_huff": "k_dec_huff_lanes(", "k_dec_prepare": "k_dec_prepare(", "k_imtf_pos": "k_imtf_pos_deque(",
+             "k_imtf_scan": "k_imtf_scan(", "k_imtf_apply": "k_imtf_apply(", "k_ibwt_hist": "k_ibwt_hist(",
+             "k_rs_scan": "k_rs_scan<9>", "k_ibwt_lf": "k_ibwt_lf(", "k_ibwt_walk": "k_ibwt_walk<", "k_ibwt_rank": "k_ibwt_rank(",
+             "k_ibwt_emit": "k_ibwt_emit("}
     per_launch = {}
     for nm, sub in short.items():
         v = find(sub)
@@ -96,6 +101,9 @@ def main():
         "encode_hbm_bytes_per_input_byte": round(enc_bytes / float(256 << 20), 2) if enc_bytes else None,
         "encode_hbm_bytes_note": "sum over the encode kernels of one 256-block launch each / 256 MiB "
                                  "(BWT: k_fs_hist, k_fs_part, k_fs_sort, k_fs_ties; MTF; Huffman)",
+        "decode_hbm_bytes_per_input_byte": round(sum(per_launch.get(k, 0) for k in (
+            "k_dec_huff", "k_dec_prepare", "k_imtf_pos", "k_imtf_scan", "k_imtf_apply", "k_ibwt_hist", "k_rs_scan", "k_ibwt_lf",
+            "k_ibwt_walk", "k_ibwt_rank", "k_ibwt_emit")) / float(256 << 20), 2),
         "k_rs_onesweep8_hbm_bytes_per_launch": o8["avg_hbm_bytes_per_launch"] if o8 else None,
         "kernels": kernels,
     }
