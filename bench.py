@@ -935,12 +935,18 @@ def main():
             return dec_names[i], k["ms"], k["launches"], k["units"]
         dec_pmc = dict(pmc_per64)
         dec_pmc["k_dec_huff"] = pmc_per64.get("k_dec_huff_lanes", {})
-        dtab = kernel_table(dec_get, dec_alg, dec_pmc, issue)
+        ttab, tblocks, tcollected = load_traffic()
+        ttab = dict(ttab)
+        ttab.setdefault("k_dec_huff", 0)
+        dtab = kernel_table(dec_get, dec_alg, dec_pmc, issue, traffic_tab=ttab, blocks_in_traffic=tblocks)
         decode_block = {"one_plan_GBps": round(dec1, 4), "pipelined_plans_GBps": round(decode_gbps, 4),
                         "hbm_frac_algorithmic_rho_plus_1": round((1 + rho) * dec1 / HBM_PEAK_GBPS, 6),
                         "roofline": roofline_of(dtab, "one plan, stages back to back; algorithmic bytes of the walk = one 4-byte LF entry read + 1 byte "
-                                                      "emitted per symbol; the walk is a dependent random access per output byte (bound: random-access "
-                                                      "rate of L2 / HBM, not streaming bandwidth), k_imtf_pos by VALU issue + LDS"),
+                                                      "emitted per symbol; `traffic` (profiles/pmc_traffic.json, offline rocprofv3 --pmc passes, scaled to this "
+                                                      "run's launch size) is ~80 B per symbol: every step is a dependent scattered 4-byte read that brings a "
+                                                      "64-byte sector past L2, so the launch moves ~6 TB/s -- the streaming ceiling measured in this run -- "
+                                                      "for 5 useful bytes per step; with tables that fit L2 (n = 2^17) it is no faster: see DESIGN.md section 5"),
+                        "traffic_source": "profiles/pmc_traffic.json (%s)" % tcollected,
                         "kernels": dtab}
         dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
         d = ktab.get(dom, {})
