@@ -10,11 +10,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libglc_amd.so")
+# A/B builds: GLC_CXXFLAGS adds compiler flags (e.g. -DGLC_IMD_POS=512), GLC_LIB_OUT names the library; such a build
+# keeps its objects apart.  tests / bench pick a library with GLC_LIB (glc_binding.py).
+_VARIANT = bool(os.environ.get("GLC_CXXFLAGS") or os.environ.get("GLC_LIB_OUT"))
+OBJ = os.path.join(HERE, "build_variant" if _VARIANT else "build")
+LIB = os.environ.get("GLC_LIB_OUT") or os.path.join(HERE, "libglc_amd.so")
 SOURCES = ["cudpp_api.cpp", "bwt_sa.hip", "bwt_bucket.hip", "mtf.hip", "huffman.hip", "decode.hip", "culzss.hip",
            "culzss_api.cpp", "hd_decode.hip", "probe.hip", "exchange.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"] + os.environ.get("GLC_CXXFLAGS", "").split()
 
 
 def _header_mtime():

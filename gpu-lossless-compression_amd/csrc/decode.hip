@@ -458,14 +458,20 @@ __global__ __launch_bounds__(64) void k_imtf_pos(const uint8_t *__restrict__ in,
 // (tree descent -> word -> byte -> bit: three LDS round trips), ~420 cycles.
 // Same outputs as the ring form: the position byte of every symbol and the chunk's final list (its permutation).
 // ---------------------------------------------------------------------------
-constexpr uint32_t IMD_POS = 512;
+#ifndef GLC_IMD_POS
+#define GLC_IMD_POS 512
+#endif
+constexpr uint32_t IMD_POS = GLC_IMD_POS;                     // 512: 4 waves per CU, packed back every 256 steps: 1156 us per 256 blocks; 384: 5 waves, every 128 steps: 1404
+constexpr uint32_t IMD_FRONT = IMD_POS - 256;                 // positions ahead of the 256 entries after packing
+constexpr uint32_t IMD_WORDS = IMD_POS / 64;
+static_assert(IMD_POS == 512 || IMD_POS == 384, "the count bytes hold words 0-3 and 4-7");
 
 __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict__ in, size_t in_stride, uint32_t n,
                                                        uint8_t *__restrict__ lists, uint32_t max_chunks,
                                                        uint8_t *__restrict__ pos_out, size_t out_stride)
 {
     __shared__ uint32_t s_a[(IMD_POS / 4) * 64];              // entry at position p of lane l: byte p & 3 of s_a[(p >> 2) * 64 + l] (lane l = bank l)
-    __shared__ uint2 s_v[8 * 64];                             // bitmap word k of lane l: s_v[k * 64 + l]
+    __shared__ uint2 s_v[IMD_WORDS * 64];                     // bitmap word k of lane l: s_v[k * 64 + l]
     __shared__ uint8_t s_sel[256 * 8];                        // s_sel[b * 8 + j] = index of the j-th set bit of byte b
     __shared__ uint32_t s_pack[16];                           // v_perm selector that moves the bytes of mask m to the top of a dword, in order
     const uint32_t b = blockIdx.y, l = threadIdx.x;
@@ -494,19 +500,20 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
             if ((l >> i) & 1u) { sel = (sel & ~(0xFFu << (8 * at))) | (i << (8 * at)); at++; }
         s_pack[l] = sel;
     }
-    // identity list at positions 256 .. 511
+    // identity list at the top 256 positions
+    constexpr uint32_t D0 = IMD_FRONT / 4, K0 = IMD_FRONT / 64;  // first dword / bitmap word of the packed list
 #pragma unroll
-    for (uint32_t d = 0; d < 64; d++) s_a[(64 + d) * 64 + l] = 0x03020100u + 0x04040404u * d;
+    for (uint32_t d = 0; d < 64; d++) s_a[(D0 + d) * 64 + l] = 0x03020100u + 0x04040404u * d;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) s_v[k * 64 + l] = k < 4 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (uint32_t k = 0; k < IMD_WORDS; k++) s_v[k * 64 + l] = k < K0 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     __builtin_amdgcn_wave_barrier();
     const uint32_t lbase = l * 4;
 
     // the 256 entries in use back to positions 256 .. 511 (order kept); resets the counts
     auto compact = [&]() {
-        uint32_t acc_hi = 0, acc_lo = 0, nacc = 0, dd = 127;        // bytes waiting at the top of acc; next dword to fill
+        uint32_t acc_hi = 0, acc_lo = 0, nacc = 0, dd = IMD_POS / 4 - 1;   // bytes waiting at the top of acc; next dword to fill
 #pragma unroll 1
-        for (int k = 7; k >= 0; k--) {
+        for (int k = (int)IMD_WORDS - 1; k >= 0; k--) {
             const uint2 w = s_v[k * 64 + l];
 #pragma unroll
             for (int q = 15; q >= 0; q--) {
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
             }
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) s_v[k * 64 + l] = k < 4 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        for (uint32_t k = 0; k < IMD_WORDS; k++) s_v[k * 64 + l] = k < K0 ? make_uint2(0u, 0u) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
     };
 
     auto load16 = [&](uint32_t j, uint32_t *rv) {
@@ -536,10 +543,12 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
     };
     uint32_t nx[4];
     load16(0, nx);
-    uint32_t f = 256;                                              // front: the next entry goes to position f - 1 (wave-uniform)
+    uint32_t f = IMD_FRONT;                                        // front: the next entry goes to position f - 1 (wave-uniform)
     // positions in use per bitmap word, a byte each: words 0-3 in cnt_lo, 4-7 in cnt_hi; tot_lo = all of words 0-3
     // (it reaches 256, one more than a byte holds)
-    uint32_t cnt_lo = 0, cnt_hi = 0x40404040u, tot_lo = 0;
+    constexpr uint32_t CNT_LO0 = IMD_POS == 512 ? 0u : 0x40400000u, CNT_HI0 = IMD_POS == 512 ? 0x40404040u : 0x00004040u;
+    constexpr uint32_t TOT_LO0 = IMD_POS == 512 ? 0u : 128u;
+    uint32_t cnt_lo = CNT_LO0, cnt_hi = CNT_HI0, tot_lo = TOT_LO0;
 
     // which word holds the rr-th position in use: k = 4 g1 + kk, rr becomes the index inside the word
     struct Sel { uint32_t k, rr, kk; bool g1; };
@@ -642,18 +651,18 @@ __global__ __launch_bounds__(64) void k_imtf_pos_deque(const uint8_t *__restrict
         if (f == 0) {
             __builtin_amdgcn_wave_barrier();
             compact();
-            f = 256; cnt_lo = 0; cnt_hi = 0x40404040u; tot_lo = 0;
+            f = IMD_FRONT; cnt_lo = CNT_LO0; cnt_hi = CNT_HI0; tot_lo = TOT_LO0;
             __builtin_amdgcn_wave_barrier();
         }
     }
     if (live && chunk + 1 < nchunks) {                           // nobody needs the last permutation
-        if (f != 256) { __builtin_amdgcn_wave_barrier(); compact(); }
+        if (f != IMD_FRONT) { __builtin_amdgcn_wave_barrier(); compact(); }
         __builtin_amdgcn_wave_barrier();
         uint4 *LW = reinterpret_cast<uint4 *>(lists + ((size_t)b * max_chunks + chunk) * 256);
 #pragma unroll
         for (uint32_t k = 0; k < 16; k++)
-            LW[k] = make_uint4(s_a[(64 + 4 * k) * 64 + l], s_a[(64 + 4 * k + 1) * 64 + l], s_a[(64 + 4 * k + 2) * 64 + l],
-                               s_a[(64 + 4 * k + 3) * 64 + l]);
+            LW[k] = make_uint4(s_a[(D0 + 4 * k) * 64 + l], s_a[(D0 + 4 * k + 1) * 64 + l], s_a[(D0 + 4 * k + 2) * 64 + l],
+                               s_a[(D0 + 4 * k + 3) * 64 + l]);
     }
 }
 
