@@ -251,23 +251,34 @@ __global__ __launch_bounds__(DL_NT) void k_dec_huff_lanes(const uint32_t *__rest
     w++;
     uint32_t *ring = s_ring + tid * DL_PITCH;
     uint32_t wi = 0, rd = 0, have = 0;                          // next word to fetch / ring read position / words in the ring
-    auto refill = [&]() {                                       // 16 more words behind the ones in the ring
-        const uint32_t at = (rd + have) & (DL_RING - 1);        // (0 or 16: refills come in halves of the ring)
+    // 16 words at a time, PREFETCHED: the loads issued at one refill are written to the ring at the next one, a batch of
+    // 16 symbols later -- a lane that loaded and stored in the same breath sat out a global-memory round trip (~1 us)
+    // per 16 symbols, a third of the kernel
+    uint4 pre[4];
+    auto fetch = [&]() {                                        // words wi .. wi + 16 -> pre (zeros past the end of the stream)
         if (wi + 16 <= nwords) {
-            uint4 q[4];                                         // four 16-byte loads at a 4-byte-aligned address
 #pragma unroll
-            for (int k = 0; k < 4; k++) __builtin_memcpy(&q[k], w + wi + 4 * k, 16);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                ring[(at + 4 * k + 0) & (DL_RING - 1)] = q[k].x; ring[(at + 4 * k + 1) & (DL_RING - 1)] = q[k].y;
-                ring[(at + 4 * k + 2) & (DL_RING - 1)] = q[k].z; ring[(at + 4 * k + 3) & (DL_RING - 1)] = q[k].w;
-            }
+            for (int k = 0; k < 4; k++) __builtin_memcpy(&pre[k], w + wi + 4 * k, 16);   // 16-byte loads at a 4-byte-aligned address
         } else {
+            uint32_t t[16];
 #pragma unroll
-            for (uint32_t k = 0; k < 16; k++) ring[(at + k) & (DL_RING - 1)] = wi + k < nwords ? w[wi + k] : 0u;
+            for (uint32_t k = 0; k < 16; k++) t[k] = wi + k < nwords ? w[wi + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) pre[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
         }
-        wi += 16; have += 16;
+        wi += 16;
     };
+    auto refill = [&]() {                                       // pre -> the 16 ring slots behind the ones in use; next fetch issued
+        const uint32_t at = (rd + have) & (DL_RING - 1);        // (0 or 16: refills come in halves of the ring)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ring[(at + 4 * k + 0) & (DL_RING - 1)] = pre[k].x; ring[(at + 4 * k + 1) & (DL_RING - 1)] = pre[k].y;
+            ring[(at + 4 * k + 2) & (DL_RING - 1)] = pre[k].z; ring[(at + 4 * k + 3) & (DL_RING - 1)] = pre[k].w;
+        }
+        have += 16;
+        fetch();
+    };
+    fetch();
     refill();
     refill();
     auto next_word = [&]() -> uint32_t { const uint32_t x = ring[rd]; rd = (rd + 1) & (DL_RING - 1); have--; return x; };
