@@ -985,30 +985,23 @@ __global__ __launch_bounds__(256) void k_ibwt_emit(const uint8_t *__restrict__ t
         pos[k] = seg_pos[(size_t)b * max_seg + (ok ? id : 0u)];
         len[k] = ok ? (si & 511u) : 0u;
     }
-    // a lane takes ONE dword of each slot (SLOT / 4 = 64 dwords: the wave reads a slot as one 256-byte access) and
-    // writes it byte-reversed as one dword wherever all four bytes exist (byte lanes: four loads and four stores per
-    // segment, and the kernel is bound by its memory instructions: 5.7 per 64 output bytes)
-    static_assert(SLOT == 256, "one dword of the slot per lane");
-    uint32_t q[EMIT_SEGS];
+    uint8_t v[EMIT_SEGS][SLOT / 64];
 #pragma unroll
     for (uint32_t k = 0; k < EMIT_SEGS; k++) {
-        const uint32_t *S = reinterpret_cast<const uint32_t *>(tmp + ((size_t)b * max_seg + min(id0 + k, max_seg - 1)) * SLOT);
-        q[k] = S[4 * l < len[k] ? l : 0u];
+        const uint8_t *S = tmp + ((size_t)b * max_seg + min(id0 + k, max_seg - 1)) * SLOT;
+#pragma unroll
+        for (uint32_t j = 0; j < SLOT / 64; j++) {
+            const uint32_t i = l + 64 * j;
+            v[k][j] = S[i < len[k] ? i : 0u];
+        }
     }
 #pragma unroll
     for (uint32_t k = 0; k < EMIT_SEGS; k++) {
-        const uint32_t i0 = 4 * l;
-        if (i0 >= len[k]) continue;
-        const int64_t top = (int64_t)pos[k] - (int64_t)i0;       // text position of the dword's byte 0; bytes 1..3 go below it
-        if (i0 + 4 <= len[k] && top - 3 >= 0 && top < (int64_t)n) {
-            const uint32_t r = __builtin_bswap32(q[k]);
-            __builtin_memcpy(O + (top - 3), &r, 4);              // (any alignment)
-        } else {
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t t = (uint32_t)(pos[k] - (int)(i0 + j));
-                if (i0 + j < len[k] && t < n) O[t] = (uint8_t)(q[k] >> (8 * j));
-            }
+        for (uint32_t j = 0; j < SLOT / 64; j++) {
+            const uint32_t i = l + 64 * j;
+            const uint32_t t = (uint32_t)(pos[k] - (int)i);
+            if (i < len[k] && t < n) O[t] = v[k][j];
         }
     }
 }
