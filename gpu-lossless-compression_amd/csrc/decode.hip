@@ -35,7 +35,10 @@ namespace glc {
 
 constexpr int      DEC_LUT_BITS = 12;
 constexpr uint32_t DEC_FLAG     = 0x80000000u;
-constexpr int      LF_TILE      = 2048;
+#ifndef GLC_LF_TILE
+#define GLC_LF_TILE 4096
+#endif
+constexpr int      LF_TILE      = GLC_LF_TILE;                 // rows per tile of the LF construction (a 512-bin histogram per tile: 1 KiB per 2 KiB of rows at 2048)
 constexpr uint32_t LF_MASK      = (1u << 21) - 1;
 #ifndef GLC_SPLIT
 #define GLC_SPLIT 128
@@ -755,19 +758,22 @@ __global__ __launch_bounds__(256) void k_ibwt_hist(const uint8_t *__restrict__ b
     uint32_t index = (uint32_t)d_index[b];
     if (index >= n) { index = n - 1; if (d_status && t == 0 && tid == 0) atomicOr(d_status, ST_CORRUPT); }   // row index from the stream
     uint32_t *H8 = s_h + (tid & 7) * 513;
-    // rows base .. base + LF_TILE are the bytes bwt[base - 1 ..]: thread = 8 consecutive rows, read as one unaligned
-    // 8-byte load where that stays inside the block and clear of the two special rows
-    const uint32_t r0 = base + tid * 8;
-    if (r0 >= 1 && r0 + 8 <= rows && !(index + 1 >= r0 && index + 1 < r0 + 8)) {
-        uint64_t q;
-        __builtin_memcpy(&q, B + r0 - 1, 8);
+    // rows base .. base + LF_TILE are the bytes bwt[base - 1 ..]: a thread takes groups of 8 consecutive rows, each read
+    // as one unaligned 8-byte load where that stays inside the block and clear of the two special rows
 #pragma unroll
-        for (int k = 0; k < 8; k++) atomicAdd(&H8[(uint32_t)((q >> (8 * k)) & 0xFFu) + 1u], 1u);
-    } else {
+    for (uint32_t g = 0; g < LF_TILE / 2048; g++) {
+        const uint32_t r0 = base + g * 2048 + tid * 8;
+        if (r0 >= 1 && r0 + 8 <= rows && !(index + 1 >= r0 && index + 1 < r0 + 8)) {
+            uint64_t q;
+            __builtin_memcpy(&q, B + r0 - 1, 8);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t r = r0 + k;
-            if (r < rows) atomicAdd(&H8[row_symbol(B, r, index)], 1u);
+            for (int k = 0; k < 8; k++) atomicAdd(&H8[(uint32_t)((q >> (8 * k)) & 0xFFu) + 1u], 1u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t r = r0 + k;
+                if (r < rows) atomicAdd(&H8[row_symbol(B, r, index)], 1u);
+            }
         }
     }
     __syncthreads();
