@@ -337,7 +337,11 @@ __global__ __launch_bounds__(DL_NT) void k_dec_huff_lanes(const uint32_t *__rest
 // -- the LDS data path is no longer the limit (active 105 -> 64 quad-cycles per 64 symbols, FIFO-full 40 -> 0.6), the
 // kernel now runs at ~62 % of the VALU issue rate (~210 instructions per 64 symbols: a read, a write and a nested EXEC
 // level per group) with 2.25 waves per SIMD (16.6 KB of LDS per wave) to cover three dependent LDS round trips per symbol.
-constexpr uint32_t IMTF_CHUNK = 2048;
+#ifndef GLC_IMTF_CHUNK
+#define GLC_IMTF_CHUNK 4096
+#endif
+constexpr uint32_t IMTF_CHUNK = GLC_IMTF_CHUNK;              // symbols per lane of pass 1 (4096 against 2048: permutation scan 251 -> 125, apply 535 -> 413 us per 1024 blocks)
+static_assert(IMTF_CHUNK % 2048 == 0, "k_imtf_apply works in pieces of 2048 symbols");
 
 // w rotated right by h bytes: byte i of the result = byte (i + h) & 15 of w
 __device__ __forceinline__ uint4 imtf_rotr(uint4 w, uint32_t h)
@@ -714,18 +718,21 @@ __global__ __launch_bounds__(256) void k_imtf_apply(uint8_t *__restrict__ buf, s
         reinterpret_cast<uint32_t *>(s_lut)[tid] =
             reinterpret_cast<const uint32_t *>(lists + ((size_t)b * max_chunks + chunk) * 256)[tid];
     __syncthreads();
-    const uint32_t lo = chunk * IMTF_CHUNK + tid * 8;
-    uint8_t *P = buf + (size_t)b * stride + lo;
-    if (lo + 8 <= n && (reinterpret_cast<size_t>(P) & 7) == 0) {
-        const uint2 q = *reinterpret_cast<const uint2 *>(P);
-        uint2 o;
-        o.x = (uint32_t)s_lut[q.x & 0xFF] | ((uint32_t)s_lut[(q.x >> 8) & 0xFF] << 8) |
-              ((uint32_t)s_lut[(q.x >> 16) & 0xFF] << 16) | ((uint32_t)s_lut[q.x >> 24] << 24);
-        o.y = (uint32_t)s_lut[q.y & 0xFF] | ((uint32_t)s_lut[(q.y >> 8) & 0xFF] << 8) |
-              ((uint32_t)s_lut[(q.y >> 16) & 0xFF] << 16) | ((uint32_t)s_lut[q.y >> 24] << 24);
-        *reinterpret_cast<uint2 *>(P) = o;
-    } else {
-        for (uint32_t i = lo; i < n && i < lo + 8; i++) P[i - lo] = s_lut[P[i - lo]];
+#pragma unroll
+    for (uint32_t g = 0; g < IMTF_CHUNK / 2048; g++) {
+        const uint32_t lo = chunk * IMTF_CHUNK + g * 2048 + tid * 8;
+        uint8_t *P = buf + (size_t)b * stride + lo;
+        if (lo + 8 <= n && (reinterpret_cast<size_t>(P) & 7) == 0) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(P);
+            uint2 o;
+            o.x = (uint32_t)s_lut[q.x & 0xFF] | ((uint32_t)s_lut[(q.x >> 8) & 0xFF] << 8) |
+                  ((uint32_t)s_lut[(q.x >> 16) & 0xFF] << 16) | ((uint32_t)s_lut[q.x >> 24] << 24);
+            o.y = (uint32_t)s_lut[q.y & 0xFF] | ((uint32_t)s_lut[(q.y >> 8) & 0xFF] << 8) |
+                  ((uint32_t)s_lut[(q.y >> 16) & 0xFF] << 16) | ((uint32_t)s_lut[q.y >> 24] << 24);
+            *reinterpret_cast<uint2 *>(P) = o;
+        } else {
+            for (uint32_t i = lo; i < n && i < lo + 8; i++) P[i - lo] = s_lut[P[i - lo]];
+        }
     }
 }
 
