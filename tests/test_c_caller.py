@@ -63,6 +63,24 @@ def test_c_caller_culzss_pipeline_sequence(glc, tmp_path):
     assert r.stdout.count("packed_equal=1") == 4 and r.stdout.count("candidates_equal=1") == 4
 
 
+def test_exchange_rig_compiles_with_gcc(glc, tmp_path):
+    """include/glc_exchange.h needs neither hipcc nor the RCCL headers on the caller's side"""
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    glc.lib()
+    assert os.path.exists(_build(tmp_path, os.path.join(ROOT, "tests", "c_caller", "exchange_rig.c"), "exchange_rig"))
+
+
+@pytest.mark.gpu
+def test_c_caller_exchange_sequence_world_of_one(glc, tmp_path):
+    """a rank of the multi-GPU path written in C: encode, compact, records, RCCL count exchange, gather, scatter,
+    unpack, expand, decode -- the input comes back (tests/c_caller/exchange_rig.c)"""
+    glc.lib()
+    exe = _build(tmp_path, os.path.join(ROOT, "tests", "c_caller", "exchange_rig.c"), "exchange_rig")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and "round_trip=1" in r.stdout, r.stdout + r.stderr
+
+
 def _build_cpp(tmp_path):
     exe = str(tmp_path / "cuhd_adapter_rig")
     cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
