@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_dec_prepare(const uint32_t *__restrict_
     s_hist[tid] = d_hist[(size_t)b * 256 + tid];
     if (tid == 0) s_hist[256] = 1;
     __syncthreads();
-    if ((tid >> 6) == 0) huff_tree_build(T, s_hist, tid & 63);
+    huff_tree_build<256>(T, s_hist, tid);
     __syncthreads();
     const int head = T.head, used = 2 * T.nl - 1;
     for (int s = (int)tid; s < HUFF_NODES; s += 256) {

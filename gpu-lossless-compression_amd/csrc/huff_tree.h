@@ -4,8 +4,8 @@
 //
 // Restates huffman_build_tree_kernel's merge loop (cudpp-inpar/src/cudpp/kernel/
 // compress_kernel.cuh:2306-2392) with FindMinimumCount's order (cta/compress_cta.cuh:
-// 550-571: lowest count, then lowest level, then lowest slot) as a wave-wide arg-min
-// over packed 64-bit keys  count<<32 | level<<16 | slot.
+// 550-571: lowest count, then lowest level, then lowest slot) with two sorted queues
+// held in the registers of one wave (see huff_tree_build).
 #pragma once
 #include "glc_device.h"
 
@@ -15,9 +15,9 @@ constexpr int      HUFF_NODES = 2 * 257 - 1;          // 513
 constexpr uint64_t HUFF_KEY_NONE = ~0ull;
 
 struct HuffTreeLds {
-    uint64_t key[320];                                 // leaf keys on their way into the registers (slots < nl <= 257)
-    uint32_t count[HUFF_NODES];
-    int16_t  level[HUFF_NODES], value[HUFF_NODES];     // value = symbol, -1 for a composite node
+    uint32_t key[320], sorted[320], rank[320];         // leaf keys (count << 9 | slot) by slot and by rank (nl <= 257)
+    uint32_t ones;                                     // leaves of count 1 besides EOF
+    int16_t  value[HUFF_NODES];                        // symbol, -1 for a composite node
     int16_t  left[HUFF_NODES], right[HUFF_NODES], parent[HUFF_NODES];
     int      nl, head;
 };
@@ -54,91 +54,174 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t k)
     return (uint32_t)__builtin_amdgcn_readlane((int)k, 63);
 }
 
-// Called by ONE full wave (l = lane).  hist257[256] must already hold the EOF count 1.
-// The candidates live in REGISTERS: slot s (< 320) is register s >> 6 of lane s & 63 and holds count << 5 | level
-// (count <= 2^20 + 1, level < 32; ~0 = no candidate).  The slot itself need not be stored -- it is where the value
-// sits -- so FindMinimumCount's order (count, level, slot) is two 32-bit wave minima: the smallest value, then the
-// smallest slot among the lanes that hold it.  (64-bit keys in LDS: five reads and a barrier per arg-min, 512 arg-mins
-// per block back to back; 64-bit keys in registers: 12 DPP steps of compare-and-select on register pairs.)
-__device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *hist257, unsigned l)
+// Called by ALL NT threads of the workgroup (contains barriers).  hist257[256] must already hold the EOF count 1.
+//
+// The reference finds the two minima by (count, level, slot) among ALL live nodes for every merge (257-slot scans,
+// compress_cta.cuh:550-571).  A wave-wide arg-min over register-held candidates does the same in ~1100 cycles per merge
+// -- 24 dependent DPP steps, and a wave on its own issues one instruction every ~4.5 cycles -- 0.11 ms per tree with
+// the rest of the CU idle.  Here the same order comes out of two sorted queues and scalar code:
+//   * leaves, ranked once by (count, slot) -- their level is 0, so this IS their order among themselves (the ranking
+//     is the one step every thread of the workgroup takes part in: a leaf per thread counts the keys below its own);
+//   * composites in creation order.  Minima leave in non-decreasing order of count, so a new composite's count is
+//     >= that of every composite made before it: it belongs at the TAIL of the composite queue, except among the
+//     composites of the SAME count at the tail, where (level, slot) decides -- an insertion among those few (rare:
+//     ties between the counts of composites; exact, not a heuristic).
+// The minimum of all live nodes is the smaller of the two queue heads; a leaf and a composite never tie (level 0
+// against level >= 1), so that is ONE scalar compare of count << 5 | level.  Both queues live in the registers of
+// wave 0 and are read / written with v_readlane / v_writelane: a merge is ~70 scalar instructions and a few lane
+// reads -- no LDS round trip, no cross-lane reduction.
+//
+// Node numbering (any numbering gives the same codes; the decoder stores whatever ids it is given): leaves 0 .. nl-1 in
+// ascending symbol order -- the reference's slots, which is what the tie-break compares -- composite k is node nl + k,
+// the root is 2 nl - 2.  A composite takes the SLOT (tie-break rank) of its first minimum, which becomes its LEFT
+// child; the second minimum is the RIGHT child (compress_kernel.cuh:2344-2385).
+template <int NT>
+__device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *hist257, unsigned tid)
 {
     constexpr uint32_t NONE = 0xFFFFFFFFu;
-    // leaves: present symbols in ascending order -> slots 0..nl-1 (compress_kernel.cuh:2310-2321)
-    uint32_t nl = 0;
-    for (int r = 0; r < 5; r++) {
-        const uint32_t sym = r * 64 + l;
-        const uint32_t c = sym < 257 ? hist257[sym] : 0u;
-        const uint64_t bal = __ballot(c > 0);
-        if (c > 0) {
-            const uint32_t slot = nl + mbcnt(bal);
-            T.count[slot] = c; T.level[slot] = 0; T.value[slot] = (int16_t)sym;
-            T.left[slot] = -1; T.right[slot] = -1; T.parent[slot] = -1;
-            T.key[slot] = (uint64_t)(c << 5);
-        }
-        nl += (uint32_t)__popcll(bal);
-    }
-    for (uint32_t s = nl + l; s < 320; s += 64) T.key[s] = NONE;
-    __builtin_amdgcn_wave_barrier();
-    // Q = value << 9 | slot for values below 2^23 (count < 2^18), else ~0: while the smallest candidate is that small
-    // -- all but the last few merges of a 1 MiB block, whose counts add up to 2^20 + 1 -- ONE wave minimum finds it
-    uint32_t P[5], Q[5];
-    auto packed = [&](uint32_t v, int r) -> uint32_t { return v < (1u << 23) ? (v << 9) | (uint32_t)(r * 64 + (int)l) : NONE; };
-#pragma unroll
-    for (int r = 0; r < 5; r++) { P[r] = (uint32_t)T.key[r * 64 + l]; Q[r] = packed(P[r], r); }
-    __builtin_amdgcn_wave_barrier();
-
-    // (value, slot) of the smallest candidate; value NONE if there is none
-    auto arg_min = [&](uint32_t &val) -> uint32_t {
-        {
-            uint32_t qb = Q[0];
-#pragma unroll
-            for (int r = 1; r < 5; r++) qb = Q[r] < qb ? Q[r] : qb;
-            const uint32_t q = wave_min_u32(qb);
-            if (q != NONE) { val = q >> 9; return q & 511u; }
-        }
-        uint32_t best = P[0], br = 0;
-#pragma unroll
-        for (int r = 1; r < 5; r++) { const bool lt = P[r] < best; best = lt ? P[r] : best; br = lt ? (uint32_t)r : br; }
-        val = wave_min_u32(best);
-        return wave_min_u32(best == val ? br * 64 + l : NONE);
-    };
-    int head = -1;
-    for (uint32_t k = 0;; k++) {
-        uint32_t v1, v2;
-        const uint32_t m1 = arg_min(v1);
-        if (v1 == NONE) break;
-        const int min1 = (int)m1;
-        head = min1;
-#pragma unroll
-        for (int r = 0; r < 5; r++) if (m1 == r * 64 + l) { P[r] = NONE; Q[r] = NONE; }
-        const uint32_t m2 = arg_min(v2);
-        if (v2 == NONE) break;
-        const int min2 = (int)m2;
-        // min1 moves to the next free slot >= nl and becomes the LEFT child; min2 stays and
-        // is the RIGHT child; the composite takes min1's slot (compress_kernel.cuh:2344-2385)
-        const uint32_t c1 = v1 >> 5, c2 = v2 >> 5;
-        const int l1 = (int)(v1 & 31u), l2 = (int)(v2 & 31u);
-        const int lv = (l1 > l2 ? l1 : l2) + 1;
-        const uint32_t nk = ((c1 + c2) << 5) | (uint32_t)lv;
-#pragma unroll
+    const uint32_t l = tid & 63u;
+    const bool wave0 = tid < 64;
+    // leaves: present symbols in ascending order -> slots 0..nl-1 (compress_kernel.cuh:2310-2321); key = count << 9 | slot
+    if (wave0) {
+        uint32_t nl = 0;
         for (int r = 0; r < 5; r++) {
-            if (m1 == r * 64 + l) { P[r] = nk; Q[r] = packed(nk, r); }
-            if (m2 == r * 64 + l) { P[r] = NONE; Q[r] = NONE; }
+            const uint32_t sym = r * 64 + l;
+            const uint32_t c = sym < 257 ? hist257[sym] : 0u;
+            const uint64_t bal = __ballot(c > 0);
+            if (c > 0) {
+                const uint32_t slot = nl + mbcnt(bal);
+                T.value[slot] = (int16_t)sym; T.left[slot] = -1; T.right[slot] = -1;
+                T.key[slot] = (c << 9) | slot;
+            }
+            nl += (uint32_t)__popcll(bal);
         }
-        if (l == 0) {
-            const int i = (int)(nl + k);
-            const int lf = T.left[min1], rt = T.right[min1];
-            T.count[i] = c1; T.level[i] = (int16_t)l1; T.value[i] = T.value[min1];
-            T.left[i] = (int16_t)lf; T.right[i] = (int16_t)rt; T.parent[i] = (int16_t)min1;
-            if (lf >= 0) T.parent[lf] = (int16_t)i;
-            if (rt >= 0) T.parent[rt] = (int16_t)i;
-            T.left[min1] = (int16_t)i; T.right[min1] = (int16_t)min2; T.value[min1] = -1;
-            T.count[min1] = c1 + c2; T.level[min1] = (int16_t)lv; T.parent[min1] = -1;
-            T.parent[min2] = (int16_t)min1;
+        if (l == 0) { T.nl = (int)nl; T.ones = 0; }
+    }
+    for (uint32_t i = tid; i < 320; i += NT) T.rank[i] = 0;
+    __syncthreads();
+    // rank of every leaf among the leaves.  The EOF leaf (count 1, the last slot) is left out of the loops: it sorts
+    // behind every other leaf of count 1 and ahead of everything else.
+    {
+        constexpr uint32_t P = NT / 256;                       // threads per leaf
+        const uint32_t nlm = (uint32_t)T.nl - 1u;
+        const uint32_t i = tid / P, part = tid % P;
+        if (i < nlm) {
+            const uint32_t ki = T.key[i];
+            const uint32_t per = (nlm + P - 1) / P, j0 = part * per, j1 = j0 + per < nlm ? j0 + per : nlm;
+            uint32_t cnt = 0;
+            for (uint32_t j = j0; j < j1; j++) cnt += T.key[j] < ki ? 1u : 0u;
+            if (part == 0) {
+                cnt += (ki >> 9) >= 2u ? 1u : 0u;
+                if ((ki >> 9) == 1u) atomicAdd(&T.ones, 1u);
+            }
+            if (P == 1) T.rank[i] = cnt; else atomicAdd(&T.rank[i], cnt);
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (l == 0) { T.nl = (int)nl; T.head = head; }
+    __syncthreads();
+    {
+        const uint32_t nlm = (uint32_t)T.nl - 1u;
+        if (tid < nlm) T.sorted[T.rank[tid]] = T.key[tid];
+        if (tid == 0) T.sorted[T.ones] = T.key[nlm];
+    }
+    __syncthreads();
+    if (!wave0) return;
+
+    const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane(T.nl);
+    // leaf queue: the 64 leaves around the head in one register, refilled from T.sorted every 64 leaves.
+    // composite queue: a ring of 128 entries in two registers (entry q = lane q & 63 of register (q >> 6) & 1): live
+    // composites are disjoint subtrees of >= 2 leaves, so at most 128 are live, and at most 127 when one is added (a
+    // merge out of 128 live composites takes at least one of them) -- entry k never lands on a live entry k - 128.
+    uint32_t curL = l < nl ? T.sorted[l] : NONE;
+    uint32_t QA[2] = {NONE, NONE}, QB[2] = {0, 0}, CH[4] = {0, 0, 0, 0};   // count << 5 | level, slot << 10 | node; children by composite
+    auto rl = [](uint32_t v, uint32_t lane) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); };
+    // v_writelane_b32 with value and lane select both in SGPRs passes the constant-bus limit only with the lane select in
+    // M0 (this compiler has no builtin for it); M0 is handed back as it was
+    auto wl = [](uint32_t &reg, uint32_t lane, uint32_t v) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\ts_mov_b32 m0, %1"
+                     : "+v"(reg), "=&s"(keep) : "s"(lane), "s"(v));
+    };
+    auto wl3 = [](uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t lane, uint32_t v0, uint32_t v1, uint32_t v2) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
+                     "v_writelane_b32 %2, %7, m0\n\ts_mov_b32 m0, %3"
+                     : "+v"(r0), "+v"(r1), "+v"(r2), "=&s"(keep) : "s"(lane), "s"(v0), "s"(v1), "s"(v2));
+    };
+    auto get2 = [&](const uint32_t (&R)[2], uint32_t q) -> uint32_t {
+        const uint32_t v0 = rl(R[0], q & 63u), v1 = rl(R[1], q & 63u);
+        return (q & 64u) ? v1 : v0;
+    };
+    auto set2 = [&](uint32_t (&R)[2], uint32_t q, uint32_t v) {                  // (rare path)
+        if (q & 64u) wl(R[1], q & 63u, v); else wl(R[0], q & 63u, v);
+    };
+    const uint32_t nm = nl - 1u;                               // merges
+    uint32_t lh = 0, lx = rl(curL, 0);                         // leaves taken, the head leaf (NONE past the last)
+    uint32_t ch = 0, cA = NONE, cB = 0;                        // composites taken, the head composite (cA = NONE: queue empty)
+    uint32_t tA = 0, tB = 0;                                   // the composite at the tail
+#pragma unroll
+    for (int seg = 0; seg < 4; seg++) {
+        const uint32_t kend = nm < (uint32_t)(seg + 1) * 64u ? nm : (uint32_t)(seg + 1) * 64u;
+        for (uint32_t k = (uint32_t)seg * 64u; k < kend; k++) {          // composite k is queue entry k when it is made
+            uint32_t a0, b0, a1, b1;
+#define GLC_TAKE(a, b)                                                                                              \
+            {                                                                                                       \
+                const uint32_t lA = (lx >> 9) << 5;            /* NONE >> 9 << 5 is above every real key, below NONE */ \
+                if (lA < cA) {                                 /* a leaf (both queues empty cannot happen: k < nm) */ \
+                    const uint32_t slot = lx & 511u;                                                                \
+                    a = lA; b = slot * 1025u;                  /* slot << 10 | node, node = slot */                \
+                    lh++;                                                                                           \
+                    if ((lh & 63u) == 0) {                                                                          \
+                        asm volatile("" ::: "memory");         /* a real branch: taken four times per tree */      \
+                        curL = lh + l < nl ? T.sorted[lh + l] : NONE;                                               \
+                    }                                                                                               \
+                    lx = rl(curL, lh & 63u);                                                                        \
+                } else {                                                                                            \
+                    a = cA; b = cB;                                                                                 \
+                    ch++;                                                                                           \
+                    cA = NONE;                                 /* entries ch .. k-1 are live */                     \
+                    if (ch != k) { cA = get2(QA, ch); cB = get2(QB, ch); }                                          \
+                }                                                                                                   \
+            }
+            GLC_TAKE(a0, b0)
+            GLC_TAKE(a1, b1)
+#undef GLC_TAKE
+            const uint32_t l0 = a0 & 31u, l1 = a1 & 31u;
+            const uint32_t A = (((a0 >> 5) + (a1 >> 5)) << 5) | ((l0 > l1 ? l0 : l1) + 1u);
+            const uint32_t B = (b0 & ~1023u) | (nl + k);
+            const uint32_t kids = (b0 & 1023u) | ((b1 & 1023u) << 16);
+            const uint32_t pl = k & 63u;
+            if (k > ch && tA == A && tB > B) {
+                // composites of the same count and level at the tail with a larger slot move up by one
+                wl(CH[seg], pl, kids);
+                uint32_t q = k;
+                while (q > ch) {
+                    const uint32_t pa = get2(QA, q - 1), pb = get2(QB, q - 1);
+                    if (pa != A || pb < B) break;
+                    set2(QA, q, pa); set2(QB, q, pb);
+                    q--;
+                }
+                set2(QA, q, A); set2(QB, q, B);
+                if (q == ch) { cA = A; cB = B; }
+            } else {
+                wl3(QA[seg & 1], QB[seg & 1], CH[seg], pl, A, B, kids);
+                if (k == ch) { cA = A; cB = B; }
+                tA = A; tB = B;
+            }
+        }
+    }
+    // the tree, written by all lanes: composite k = node nl + k with the children recorded above
+    const uint32_t root = nm ? nl + nm - 1u : 0u;              // 2 nl - 2; node 0 when the EOF leaf is alone
+    if (l == 0) T.parent[root] = -1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t k = r * 64 + l;
+        if (k < nm) {
+            const uint32_t id = nl + k, lf = CH[r] & 0xFFFFu, rt = CH[r] >> 16;
+            T.left[id] = (int16_t)lf; T.right[id] = (int16_t)rt; T.value[id] = -1;
+            T.parent[lf] = (int16_t)id; T.parent[rt] = (int16_t)id;
+        }
+    }
+    if (l == 0) T.head = (int)root;
 }
 
 } // namespace glc

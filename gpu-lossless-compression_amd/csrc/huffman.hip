@@ -30,9 +30,23 @@
 
 namespace glc {
 
-// one 1024-thread workgroup per 1 MiB block: the two passes over the 256 partial histograms use all 16 waves (they
-// are loads and nothing else; a workgroup per CU is all this kernel has), the tree is built by one wave
-constexpr int HB_NT = 1024;
+// One workgroup per 1 MiB block.  The kernel is a chain of latencies (two passes over the block's 256 partial
+// histograms, a serial tree build in one wave), not a throughput problem: what matters in a batch is that EVERY block
+// of the launch is resident at once.  512 threads = 4 workgroups per CU = 1024 blocks on the chip (1024 threads: two
+// rounds of 512 blocks, 0.22 ms per 1024 blocks against 0.16; 256 threads: the same 0.16 with longer passes).
+#ifndef GLC_HB_NT
+#define GLC_HB_NT 512
+#endif
+constexpr int HB_NT = GLC_HB_NT;
+constexpr int HB_PARTS = HB_NT / 256, HB_NW = HB_NT / 64;
+static_assert(HB_NT == 256 || HB_NT == 512 || HB_NT == 1024, "k_huff_build: 256, 512 or 1024 threads");
+#ifdef GLC_HB_TIMING
+__device__ unsigned long long g_hb_stamp[8];
+#define HB_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_hb_stamp[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int glcDebugHuffStamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hb_stamp), sizeof(g_hb_stamp)); }
+#else
+#define HB_STAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict__ sub_hist, uint32_t max_sub,
                                                     uint32_t n, uint32_t *__restrict__ d_hist,
@@ -45,7 +59,7 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
                                                     const uint32_t *__restrict__ only)
 {
     __shared__ uint32_t s_hist[257];
-    __shared__ uint32_t s_part[4][256];
+    __shared__ uint32_t s_part[HB_PARTS][256];
     __shared__ HuffTreeLds T;
     __shared__ uint32_t s_code[257], s_len[257];
     __shared__ uint32_t s_words[256];
@@ -56,14 +70,15 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const uint32_t *SH = sub_hist + (size_t)b * max_sub * 256;
+    HB_STAMP(0);
 
     // ---- total histogram (huffman_build_tree_kernel merges partial histograms,
     //      compress_kernel.cuh:2284-2299; EOF gets count 1, :2250) ----
     {
-        // thread = (symbol, quarter of the sub-blocks), 16 loads in flight
+        // thread = (symbol, part of the sub-blocks), 16 loads in flight
         const uint32_t sym = tid & 255, qt = tid >> 8;
         uint32_t c = 0;
-        for (uint32_t s = qt * 16; s < nsub; s += 64) {
+        for (uint32_t s = qt * 16; s < nsub; s += 16 * HB_PARTS) {
             uint32_t v[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = s + k < nsub ? SH[(size_t)(s + k) * 256 + sym] : 0u;
@@ -74,7 +89,9 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
     }
     __syncthreads();
     if (tid < 256) {
-        const uint32_t c = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < HB_PARTS; q++) c += s_part[q][tid];
         s_hist[tid] = c;
         d_hist[(size_t)b * 256 + tid] = c;
         s_code[tid] = 0; s_len[tid] = 0;
@@ -82,8 +99,10 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
     }
     __syncthreads();
 
-    if (w == 0) huff_tree_build(T, s_hist, l);
+    HB_STAMP(1);
+    huff_tree_build<HB_NT>(T, s_hist, tid);
     __syncthreads();
+    HB_STAMP(2);
 
     // ---- codes: every leaf walks to the root; the k-th step up supplies bit k
     //      (left = 0, right = 1: compress_kernel.cuh:2416-2496) ----
@@ -109,22 +128,23 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
         lens_out[(size_t)b * 257 + i] = s_len[i];
     }
 
+    HB_STAMP(3);
     // ---- words per 4096-symbol block = ceil(sub_hist . len / 32) ----
     {
         uint32_t ln[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) ln[r] = s_len[r * 64 + l];
-        for (uint32_t s0 = w; s0 < 256; s0 += 64) {            // four sub-blocks of this wave at a time: 16 loads in flight
+        for (uint32_t s0 = w; s0 < 256; s0 += 4 * HB_NW) {     // four sub-blocks of this wave at a time: 16 loads in flight
             uint32_t h[4][4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t sb = s0 + 16 * k;
+                const uint32_t sb = s0 + HB_NW * k;
 #pragma unroll
                 for (int r = 0; r < 4; r++) h[k][r] = sb < nsub ? SH[(size_t)sb * 256 + r * 64 + l] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t sb = s0 + 16 * k;
+                const uint32_t sb = s0 + HB_NW * k;
                 uint32_t bits = h[k][0] * ln[0] + h[k][1] * ln[1] + h[k][2] * ln[2] + h[k][3] * ln[3];
                 bits = wave_sum(bits);
                 if (l == 0) s_words[sb] = (sb < nsub) ? (bits + 31) / 32 : 0u;
@@ -132,6 +152,7 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
         }
     }
     __syncthreads();
+    HB_STAMP(4);
     {
         const uint32_t wd = tid < 256 ? s_words[tid] : 0u;
         const uint32_t item = (tid < nsub) ? 1 + wd : 0;
@@ -146,6 +167,7 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
             if ((uint64_t)total > capacity_words && !(redo_flag && redo_flag[b])) atomicOr(d_status, ST_CAPACITY);
         }
     }
+    HB_STAMP(5);
 }
 
 // grid (sub-blocks, blocks); 256 threads x 16 symbols

@@ -1,0 +1,8 @@
+for v in amd hb512 hb256 amd hb512 hb256; do
+  GLC_LIB=/root/repo/gpu-lossless-compression_amd/libglc_$v.so timeout 300 python bench.py --no-cpu-baseline --main-only --no-overlap-pass --no-verify > /tmp/o.json 2>/tmp/o.err
+  python - <<PY
+import json
+s=open("/tmp/o.json").read(); d=json.loads(s[s.index('{"metric"'):])
+print("$v", d["value"], "huff_build", d["kernels"]["k_huff_build"]["avg_launch_ms"], "decode", d["decode"]["one_plan_GBps"], d["decode"]["pipelined_plans_GBps"])
+PY
+done
