@@ -33,13 +33,8 @@ namespace glc {
 // One workgroup per 1 MiB block.  The kernel is a chain of latencies (two passes over the block's 256 partial
 // histograms, a serial tree build in one wave), not a throughput problem: what matters in a batch is that EVERY block
 // of the launch is resident at once.  512 threads = 4 workgroups per CU = 1024 blocks on the chip (1024 threads: two
-// rounds of 512 blocks, 0.22 ms per 1024 blocks against 0.16; 256 threads: the same 0.16 with longer passes).
-#ifndef GLC_HB_NT
-#define GLC_HB_NT 512
-#endif
-constexpr int HB_NT = GLC_HB_NT;
-constexpr int HB_PARTS = HB_NT / 256, HB_NW = HB_NT / 64;
-static_assert(HB_NT == 256 || HB_NT == 512 || HB_NT == 1024, "k_huff_build: 256, 512 or 1024 threads");
+// rounds of 512 blocks, 0.22 ms per 1024 blocks against 0.16; 256 threads: the same 0.16 with longer passes); up to
+// 512 blocks fit with 1024 threads, whose passes are half as long.
 #ifdef GLC_HB_TIMING
 __device__ unsigned long long g_hb_stamp[8];
 #define HB_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_hb_stamp[i] = __builtin_readcyclecounter(); } while (0)
@@ -48,6 +43,7 @@ extern "C" int glcDebugHuffStamps(unsigned long long *out) { return (int)hipMemc
 #define HB_STAMP(i) do { } while (0)
 #endif
 
+template <int HB_NT>
 __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict__ sub_hist, uint32_t max_sub,
                                                     uint32_t n, uint32_t *__restrict__ d_hist,
                                                     uint32_t *__restrict__ codes_out,
@@ -58,6 +54,8 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
                                                     const uint32_t *__restrict__ redo_flag,
                                                     const uint32_t *__restrict__ only)
 {
+    static_assert(HB_NT == 256 || HB_NT == 512 || HB_NT == 1024, "k_huff_build: 256, 512 or 1024 threads");
+    constexpr int HB_PARTS = HB_NT / 256, HB_NW = HB_NT / 64;
     __shared__ uint32_t s_hist[257];
     __shared__ uint32_t s_part[HB_PARTS][256];
     __shared__ HuffTreeLds T;
@@ -369,8 +367,12 @@ hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s,
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const int pi = s.prof ? s.prof->begin(PROF_HUFF_BUILD, st) : -1;
-    hipLaunchKernelGGL(k_huff_build, dim3(nblk), dim3(HB_NT), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
-                       s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status, redo_flag, only);
+    if (nblk <= 512)                                           // resident either way: more threads, shorter passes
+        hipLaunchKernelGGL(k_huff_build<1024>, dim3(nblk), dim3(1024), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
+                           s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status, redo_flag, only);
+    else
+        hipLaunchKernelGGL(k_huff_build<512>, dim3(nblk), dim3(512), 0, st, s.sub_hist, s.max_sub, n, d_hist, s.codes,
+                           s.lens, d_offsets, offset_stride, d_size, (uint64_t)capacity_words, d_status, redo_flag, only);
     if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
 }

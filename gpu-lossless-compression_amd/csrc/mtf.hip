@@ -100,11 +100,11 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_chunk_lists(const uint8_
 // --- 2. exclusive scan of the lists (in place: lists[c] becomes the MTF list
 //        in force at the start of chunk c) -----------------------------------
 // The operator  S' = P ++ (S \ P)  is associative, so the 256 folds of a 1 MiB block need not be one chain
-// (one wave per block, 0.15 ms with the rest of the machine idle): 16 waves per block
-//   A  each wave folds the lists of its 16 chunks into the group's combined list,
-//   B  wave 0 folds the 16 combined lists into the state at the start of every group,
-//   C  each wave walks its 16 chunks again from that state, publishing the start list of every chunk.
-constexpr int MSC_WAVES = 16, MSC_GROUP = 16;
+// (one wave per block, 0.15 ms with the rest of the machine idle): W waves per block, groups of G = 256 / W chunks
+//   A  each wave folds the lists of its G chunks into the group's combined list,
+//   B  wave 0 folds the W combined lists into the state at the start of every group,
+//   C  each wave walks its G chunks again from that state, publishing the start list of every chunk.
+
 
 // next[0 .. m) = P (entries 4l .. 4l+3 in p4), then the entries of cur[0 .. ls) not in P, in order.  Returns the new length.
 __device__ __forceinline__ uint32_t mtf_fold(const uint8_t *cur, uint8_t *next, uint8_t *inp, uint32_t p4, uint32_t m,
@@ -132,10 +132,12 @@ __device__ __forceinline__ uint32_t mtf_fold(const uint8_t *cur, uint8_t *next, 
     return base;
 }
 
+template <int MSC_WAVES>
 __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__restrict__ lists,
                                                                   const uint16_t *__restrict__ lens, uint32_t n,
                                                                   uint32_t max_chunks, const uint32_t *__restrict__ only)
 {
+    constexpr int MSC_GROUP = 256 / MSC_WAVES;
     __shared__ __attribute__((aligned(16))) uint8_t s_state[MSC_WAVES][2][256];
     __shared__ __attribute__((aligned(16))) uint8_t s_inp[MSC_WAVES][256];
     __shared__ __attribute__((aligned(16))) uint8_t s_comb[MSC_WAVES][256];      // combined list of every group
@@ -229,8 +231,18 @@ __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__re
 //     instruction rate, so every instruction of either kind shows.)
 constexpr int MTF_ROWS = 4;                                 // chunks per wave (one per 16-lane DPP row)
 constexpr int MTF_NWORDS = 80;                              // bitmap words per chunk: 68 used, 5 per lane of the row
+#ifndef GLC_MTF_QUARTERS_MAX
+#define GLC_MTF_QUARTERS_MAX 2048
+#endif
+constexpr uint32_t MTF_QUARTERS_MAX_CHUNKS = GLC_MTF_QUARTERS_MAX;   // up to this many chunks in a launch: one wave per chunk
 
-template <bool WITH_HIST>
+//
+// QUARTERS (small batches): the rows of a wave are the four QUARTERS of one chunk instead of four chunks, so a block on
+// its own is 256 waves of 64 batches, not 64 waves of 256 (0.145 -> ~0.05 ms with the rest of the machine idle; the
+// batch loop is a chain of LDS round trips, ~1400 cycles per batch for a wave alone on its SIMD).  The start lists of
+// quarters 1..3 are made here: recency list of the quarter before (as k_mtf_chunk_lists does for a chunk) folded into
+// its start list (the operator of k_mtf_scan_lists), three times, by the whole wave.
+template <bool WITH_HIST, bool QUARTERS>
 __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__restrict__ in,
                                                               size_t in_stride, uint32_t n,
                                                               const uint8_t *__restrict__ lists,
@@ -246,23 +258,96 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
     // prefix counts of bitmap word 5 q + k at entry 8 q + k: a lane's five counts are one aligned 16-byte store (packed
     // ten bytes apart they were an unaligned 8-byte store, which alone cost a quarter of the kernel)
     __shared__ __attribute__((aligned(16))) uint16_t s_cum[MTF_WAVES * MTF_ROWS][16 * 8 + 16];
+    // QUARTERS: start lists of the four quarters, and the scratch of the recency list + fold that make them
+    __shared__ __attribute__((aligned(16))) uint8_t s_qstart[QUARTERS ? MTF_WAVES : 1][MTF_ROWS][256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_qlist[QUARTERS ? MTF_WAVES : 1][256], s_qinp[QUARTERS ? MTF_WAVES : 1][256];
+    __shared__ uint32_t s_qfirst[QUARTERS ? MTF_WAVES : 1][256], s_qcum[QUARTERS ? MTF_WAVES : 1][16];
+    __shared__ unsigned long long s_qbm[QUARTERS ? MTF_WAVES : 1][16];
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63, lr = l & 15, row = l >> 4;
     if (only && !only[b]) return;
     const uint32_t w = threadIdx.x >> 6, slot = w * MTF_ROWS + row;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
-    const uint32_t chunk0 = (blockIdx.x * MTF_WAVES + w) * MTF_ROWS;       // first chunk of this wave
+    constexpr uint32_t QLEN = MTF_CHUNK / MTF_ROWS;                          // 1024
+    // QUARTERS: chunk0 = the wave's chunk, row = quarter.  Otherwise chunk0 = first of the wave's four chunks.
+    const uint32_t chunk0 = QUARTERS ? blockIdx.x * MTF_WAVES + w : (blockIdx.x * MTF_WAVES + w) * MTF_ROWS;
     if (chunk0 >= nchunks) return;                                           // whole wave exits together
-    const uint32_t chunk = chunk0 + row;
-    const bool live = chunk < nchunks;
-    const uint32_t lo = (live ? chunk : chunk0) * MTF_CHUNK, C = live ? min(n, lo + MTF_CHUNK) - lo : 0u;
-    const uint32_t Cmax = min(n, chunk0 * MTF_CHUNK + MTF_CHUNK) - chunk0 * MTF_CHUNK;   // the wave's first chunk is its longest
+    const uint32_t chunk = QUARTERS ? chunk0 : chunk0 + row;
+    const uint32_t Cc0 = min(n, chunk0 * MTF_CHUNK + MTF_CHUNK) - chunk0 * MTF_CHUNK;   // length of the wave's first chunk
+    bool live;
+    uint32_t lo, C, Cmax;
+    if (QUARTERS) {
+        live = Cc0 > QLEN * row;
+        lo = chunk0 * MTF_CHUNK + (live ? QLEN * row : 0u);
+        C = live ? min(Cc0 - QLEN * row, QLEN) : 0u;
+        Cmax = min(Cc0, QLEN);                                               // the first quarter is the longest
+    } else {
+        live = chunk < nchunks;
+        lo = (live ? chunk : chunk0) * MTF_CHUNK;
+        C = live ? min(n, lo + MTF_CHUNK) - lo : 0u;
+        Cmax = Cc0;                                                          // the wave's first chunk is its longest
+    }
     const uint8_t *src = in + (size_t)b * in_stride + lo;
     uint8_t *dst = out + (size_t)b * out_stride + lo;
     uint32_t *tab = s_tab[slot];
     unsigned long long *bm = s_bm[slot];
     uint16_t *cum = s_cum[slot];
+    uint4 lw;
+    if (QUARTERS) {
+        uint8_t (*S)[256] = s_qstart[w];
+        reinterpret_cast<uint32_t *>(S[0])[l] = reinterpret_cast<const uint32_t *>(lists + ((size_t)b * max_chunks + chunk0) * 256)[l];
+        const uint8_t *cbase = in + (size_t)b * in_stride + chunk0 * MTF_CHUNK;
+        const bool vec = (reinterpret_cast<uintptr_t>(cbase) & 15) == 0;
+        for (uint32_t q = 0; q + 1 < MTF_ROWS && Cc0 > QLEN * (q + 1); q++) {    // quarter q is full whenever q + 1 exists
+            uint32_t *first = s_qfirst[w];
+            for (int i = l; i < 256; i += 64) first[i] = 0xFFFFFFFFu;
+            if (l < 16) s_qbm[w][l] = 0;
+            __builtin_amdgcn_wave_barrier();
+            const uint8_t *qs = cbase + QLEN * q;
+            if (vec) {
+                // lane l holds order indices [16 l, 16 l + 16) (0 = the quarter's last byte): byte k sits at 16 l + 15 - k
+                const uint4 v = *reinterpret_cast<const uint4 *>(qs + QLEN - 16 * (l + 1));
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 15; k >= 0; k--) {
+                    const uint32_t sym = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu, o = 16u * l + 15u - k;
+                    if (o < first[sym]) atomicMin(&first[sym], o);
+                }
+            } else {
+                for (uint32_t o = l; o < QLEN; o += 64) {
+                    const uint32_t sym = qs[QLEN - 1 - o];
+                    if (o < first[sym]) atomicMin(&first[sym], o);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t f[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                f[j] = first[4 * l + j];
+                if (f[j] != 0xFFFFFFFFu) atomicOr(&s_qbm[w][f[j] >> 6], 1ull << (f[j] & 63));
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t c = l < 16 ? (uint32_t)__popcll(s_qbm[w][l]) : 0u;
+            const uint32_t inc = wave_incl_add(c);
+            if (l < 16) s_qcum[w][l] = inc - c;
+            __builtin_amdgcn_wave_barrier();
+            uint8_t *L = s_qlist[w];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (f[j] != 0xFFFFFFFFu) {
+                    const uint32_t wd = f[j] >> 6, r = f[j] & 63;
+                    L[s_qcum[w][wd] + (uint32_t)__popcll(s_qbm[w][wd] & ((1ull << r) - 1ull))] = (uint8_t)(4 * l + j);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            (void)mtf_fold(S[q], S[q + 1], s_qinp[w], reinterpret_cast<const uint32_t *>(L)[l], m, 256, l);
+        }
+        __builtin_amdgcn_wave_barrier();
+        lw = reinterpret_cast<const uint4 *>(S[live ? row : 0])[lr];
+    } else {
+        lw = reinterpret_cast<const uint4 *>(lists + ((size_t)b * max_chunks + (live ? chunk : chunk0)) * 256)[lr];
+    }
     {
-        const uint4 lw = reinterpret_cast<const uint4 *>(lists + ((size_t)b * max_chunks + (live ? chunk : chunk0)) * 256)[lr];
         const uint32_t q[4] = {lw.x, lw.y, lw.z, lw.w};
 #pragma unroll
         for (int j = 0; j < 16; j++) tab[(q[j >> 2] >> (8 * (j & 3))) & 0xFF] = (255u - (16 * lr + j)) << 16;   // time -1-q, biased by 256
@@ -337,7 +422,16 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (WITH_HIST && live) {
+    if (WITH_HIST && QUARTERS) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t *H = sub_hist + ((size_t)b * max_chunks + chunk0) * 256;
+        for (int i = l; i < 256; i += 64) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r < MTF_ROWS; r++) c += (s_hist[w * MTF_ROWS + r][i & 127] >> (16 * (i >> 7))) & 0xFFFFu;
+            H[i] = c;
+        }
+    } else if (WITH_HIST && live) {
         __builtin_amdgcn_wave_barrier();
         uint32_t *H = sub_hist + ((size_t)b * max_chunks + chunk) * 256;
         for (int i = lr; i < 256; i += 16) H[i] = (s_hist[slot][i & 127] >> (16 * (i >> 7))) & 0xFFFFu;
@@ -374,14 +468,27 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_MTF_LISTS, st) : -1;
     hipLaunchKernelGGL(k_mtf_chunk_lists, g, t, 0, st, in, in_stride, n, s.lists, s.lens, s.max_chunks, only);
-    hipLaunchKernelGGL(k_mtf_scan_lists, dim3(nblk), dim3(MSC_WAVES * 64), 0, st, s.lists, s.lens, n, s.max_chunks, only);
+    // 16 waves of 16 chunks: the shortest chain of folds (48) for a block on its own; 8 waves of 32 (72 folds): four
+    // workgroups per CU, so a batch of 1024 blocks is resident at once instead of in two rounds (0.156 -> 0.126 ms)
+    if (nblk <= 512)
+        hipLaunchKernelGGL(k_mtf_scan_lists<16>, dim3(nblk), dim3(16 * 64), 0, st, s.lists, s.lens, n, s.max_chunks, only);
+    else
+        hipLaunchKernelGGL(k_mtf_scan_lists<8>, dim3(nblk), dim3(8 * 64), 0, st, s.lists, s.lens, n, s.max_chunks, only);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_MTF_ENCODE, st) : -1;
-    if (sub_hist)
-        hipLaunchKernelGGL(k_mtf_encode<true>, ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
+    // few chunks in all (a cudppCompress call, small batches): a wave per chunk, its rows the chunk's quarters
+    const bool quarters = (uint64_t)nchunks * nblk <= MTF_QUARTERS_MAX_CHUNKS;
+    if (quarters && sub_hist)
+        hipLaunchKernelGGL((k_mtf_encode<true, true>), g, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
+                           out_stride, sub_hist, only);
+    else if (quarters)
+        hipLaunchKernelGGL((k_mtf_encode<false, true>), g, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
+                           out_stride, sub_hist, only);
+    else if (sub_hist)
+        hipLaunchKernelGGL((k_mtf_encode<true, false>), ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
                            out_stride, sub_hist, only);
     else
-        hipLaunchKernelGGL(k_mtf_encode<false>, ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
+        hipLaunchKernelGGL((k_mtf_encode<false, false>), ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
                            out_stride, sub_hist, only);
     if (pi >= 0) s.prof->end(pi, units, st);
     return hipGetLastError();

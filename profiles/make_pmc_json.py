@@ -69,8 +69,8 @@ def main():
     # per-launch HBM bytes of the kernels bench.py profiles live (its `roofline.traffic` reads this table), and the
     # whole encode's HBM bytes per input byte (every glc:: kernel of one 256-block batch / 256 MiB)
     short = {"k_fs_part": "k_fs_part<false>(", "k_fs_sort": "k_fs_sort(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
-             "k_mtf_encode": "k_mtf_encode<", "k_huff_pack": "k_huff_pack(", "k_huff_build": "k_huff_build(",
-             "k_mtf_chunk_lists": "k_mtf_chunk_lists(", "k_mtf_scan_lists": "k_mtf_scan_lists(",
+             "k_mtf_encode": "k_mtf_encode<", "k_huff_pack": "k_huff_pack(", "k_huff_build": "k_huff_build<",
+             "k_mtf_chunk_lists": "k_mtf_chunk_lists(", "k_mtf_scan_lists": "k_mtf_scan_lists<",
              "k_rs_onesweep<8,false>": "k_rs_onesweep<8, false",
              # decoder
              "k_dec_huff": "k_dec_huff_lanes(", "k_dec_prepare": "k_dec_prepare(", "k_imtf_pos": "k_imtf_pos_deque(",
