@@ -23,6 +23,7 @@
 namespace glc {
 
 constexpr int MTF_WAVES = 4;                       // waves per workgroup
+constexpr int MTF_INP = 256 + 8;                   // membership bytes of mtf_fold + its spill slot
 
 // --- 1. chunk-local recency lists ------------------------------------------
 // list = distinct symbols of the chunk, most recent first = the symbols sorted by the ORDER INDEX o (0 = last byte
@@ -107,29 +108,38 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_chunk_lists(const uint8_
 
 
 // next[0 .. m) = P (entries 4l .. 4l+3 in p4), then the entries of cur[0 .. ls) not in P, in order.  Returns the new length.
+// Every lane filters the four CONSECUTIVE entries 4l .. 4l+3 of cur: one dword read, four membership reads in flight
+// together, one wave scan of the kept counts.  (A lane per entry and four rounds of 64 -- read the entry, read its
+// membership byte, ballot, write -- is eight LDS round trips one after the other, and a fold is one link of a chain
+// of 48: 0.74 us per fold, 35 us per block.)
 __device__ __forceinline__ uint32_t mtf_fold(const uint8_t *cur, uint8_t *next, uint8_t *inp, uint32_t p4, uint32_t m,
-                                             uint32_t ls, uint32_t l)
+                                             uint32_t ls, uint32_t l, uint32_t *cur4 = nullptr)
 {
+    // inp: 256 membership bytes + a slot (256 + lane's byte) that takes the writes of the entries of p4 past m.  The
+    // dword of P goes to next whole: what lies past m is overwritten by the kept entries or is past the new length.
+    const uint32_t c4 = reinterpret_cast<const uint32_t *>(cur)[l];
     reinterpret_cast<uint32_t *>(inp)[l] = 0;
     __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<uint32_t *>(next)[l] = p4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) inp[4 * l + j < m ? (p4 >> (8 * j)) & 0xFFu : 256u + j] = 1;
+    __builtin_amdgcn_wave_barrier();
+    if (cur4) *cur4 = c4;
+    uint32_t in[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) in[j] = inp[(c4 >> (8 * j)) & 0xFFu];
+    uint32_t keep[4], cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { keep[j] = (4 * l + j < ls && !in[j]) ? 1u : 0u; cnt += keep[j]; }
+    const uint32_t inc = wave_incl_add(cnt);
+    uint32_t pos = m + inc - cnt;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t e = 4 * l + j;
-        if (e < m) { const uint8_t sy = (uint8_t)(p4 >> (8 * j)); inp[sy] = 1; next[e] = sy; }
+        if (keep[j]) next[pos] = (uint8_t)(c4 >> (8 * j));
+        pos += keep[j];
     }
     __builtin_amdgcn_wave_barrier();
-    uint32_t base = m;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t idx = r * 64 + l;
-        const uint8_t sy = cur[idx];
-        const bool keep = idx < ls && !inp[sy];
-        const uint64_t bal = __ballot(keep);
-        if (keep) next[base + mbcnt(bal)] = sy;
-        base += (uint32_t)__popcll(bal);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return base;
+    return m + (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
 }
 
 template <int MSC_WAVES>
@@ -139,10 +149,10 @@ __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__re
 {
     constexpr int MSC_GROUP = 256 / MSC_WAVES;
     __shared__ __attribute__((aligned(16))) uint8_t s_state[MSC_WAVES][2][256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_inp[MSC_WAVES][256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_inp[MSC_WAVES][MTF_INP];
     __shared__ __attribute__((aligned(16))) uint8_t s_comb[MSC_WAVES][256];      // combined list of every group
     __shared__ uint32_t s_clen[MSC_WAVES];
-    __shared__ __attribute__((aligned(16))) uint8_t s_start[MSC_WAVES][256];     // state at the start of every group
+    __shared__ __attribute__((aligned(16))) uint8_t s_start[MSC_WAVES + 1][256]; // state at the start of every group (and after the last)
     __shared__ __attribute__((aligned(16))) uint8_t s_carry[256];                // state at the start of the round
     const uint32_t b = blockIdx.x, l = threadIdx.x & 63;
     if (only && !only[b]) return;
@@ -174,21 +184,21 @@ __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__re
             if (l == 0) s_clen[w] = ls;
         }
         __syncthreads();
-        // B: state at the start of every group, and the state the next round starts from
+        // B: state at the start of every group (s_start[g + 1] = s_start[g] folded with group g), and the state the next
+        //    round starts from
         if (w == 0) {
-            int cur = 0;
-            reinterpret_cast<uint32_t *>(s_state[0][0])[l] = reinterpret_cast<const uint32_t *>(s_carry)[l];
+            reinterpret_cast<uint32_t *>(s_start[0])[l] = reinterpret_cast<const uint32_t *>(s_carry)[l];
+            uint32_t cp[MSC_WAVES], cl[MSC_WAVES];
+#pragma unroll
+            for (int g = 0; g < MSC_WAVES; g++) { cp[g] = reinterpret_cast<const uint32_t *>(s_comb[g])[l]; cl[g] = s_clen[g]; }
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t g = 0; g < ngroups; g++) {
-                reinterpret_cast<uint32_t *>(s_start[g])[l] = reinterpret_cast<const uint32_t *>(s_state[0][cur])[l];
-                (void)mtf_fold(s_state[0][cur], s_state[0][cur ^ 1], s_inp[0], reinterpret_cast<const uint32_t *>(s_comb[g])[l],
-                               s_clen[g], 256, l);
-                cur ^= 1;
-            }
-            reinterpret_cast<uint32_t *>(s_carry)[l] = reinterpret_cast<const uint32_t *>(s_state[0][cur])[l];
+#pragma unroll
+            for (int g = 0; g < MSC_WAVES; g++)
+                if ((uint32_t)g < ngroups) (void)mtf_fold(s_start[g], s_start[g + 1], s_inp[0], cp[g], cl[g], 256, l);
+            reinterpret_cast<uint32_t *>(s_carry)[l] = reinterpret_cast<const uint32_t *>(s_start[ngroups])[l];
         }
         __syncthreads();
-        // C: start list of every chunk of the group
+        // C: start list of every chunk of the group (the dword of the state a fold reads is the one to publish)
         if (w < ngroups) {
             int cur = 0;
             reinterpret_cast<uint32_t *>(s_state[w][0])[l] = reinterpret_cast<const uint32_t *>(s_start[w])[l];
@@ -196,8 +206,10 @@ __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__re
 #pragma unroll
             for (int k = 0; k < MSC_GROUP; k++) {
                 if (c0 + k < c1) {
-                    reinterpret_cast<uint32_t *>(LB + (size_t)(c0 + k) * 256)[l] = reinterpret_cast<const uint32_t *>(s_state[w][cur])[l];
-                    if (c0 + k + 1 < c1) { (void)mtf_fold(s_state[w][cur], s_state[w][cur ^ 1], s_inp[w], p4[k], mm[k], 256, l); cur ^= 1; }
+                    uint32_t st4;
+                    if (c0 + k + 1 < c1) { (void)mtf_fold(s_state[w][cur], s_state[w][cur ^ 1], s_inp[w], p4[k], mm[k], 256, l, &st4); cur ^= 1; }
+                    else st4 = reinterpret_cast<const uint32_t *>(s_state[w][cur])[l];
+                    reinterpret_cast<uint32_t *>(LB + (size_t)(c0 + k) * 256)[l] = st4;
                 }
             }
         }
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
     __shared__ __attribute__((aligned(16))) uint16_t s_cum[MTF_WAVES * MTF_ROWS][16 * 8 + 16];
     // QUARTERS: start lists of the four quarters, and the scratch of the recency list + fold that make them
     __shared__ __attribute__((aligned(16))) uint8_t s_qstart[QUARTERS ? MTF_WAVES : 1][MTF_ROWS][256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_qlist[QUARTERS ? MTF_WAVES : 1][256], s_qinp[QUARTERS ? MTF_WAVES : 1][256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_qlist[QUARTERS ? MTF_WAVES : 1][256], s_qinp[QUARTERS ? MTF_WAVES : 1][MTF_INP];
     __shared__ uint32_t s_qfirst[QUARTERS ? MTF_WAVES : 1][256], s_qcum[QUARTERS ? MTF_WAVES : 1][16];
     __shared__ unsigned long long s_qbm[QUARTERS ? MTF_WAVES : 1][16];
     const uint32_t b = blockIdx.y, l = threadIdx.x & 63, lr = l & 15, row = l >> 4;
