@@ -134,18 +134,12 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
     uint32_t curL = l < nl ? T.sorted[l] : NONE;
     uint32_t QA[2] = {NONE, NONE}, QB[2] = {0, 0}, CH[4] = {0, 0, 0, 0};   // count << 5 | level, slot << 10 | node; children by composite
     auto rl = [](uint32_t v, uint32_t lane) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); };
-    // v_writelane_b32 with value and lane select both in SGPRs passes the constant-bus limit only with the lane select in
-    // M0 (this compiler has no builtin for it); M0 is handed back as it was
-    auto wl = [](uint32_t &reg, uint32_t lane, uint32_t v) {
-        uint32_t keep;
-        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\ts_mov_b32 m0, %1"
-                     : "+v"(reg), "=&s"(keep) : "s"(lane), "s"(v));
-    };
-    auto wl3 = [](uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t lane, uint32_t v0, uint32_t v1, uint32_t v2) {
-        uint32_t keep;
-        asm volatile("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
-                     "v_writelane_b32 %2, %7, m0\n\ts_mov_b32 m0, %3"
-                     : "+v"(r0), "+v"(r1), "+v"(r2), "=&s"(keep) : "s"(lane), "s"(v0), "s"(v1), "s"(v2));
+    // lane writes as compare + select (this compiler has no builtin for v_writelane_b32, and an asm statement costs more
+    // in register copies around it than the two instructions it saves)
+    auto wl = [&](uint32_t &reg, uint32_t lane, uint32_t v) { reg = l == lane ? v : reg; };
+    auto wl3 = [&](uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t lane, uint32_t v0, uint32_t v1, uint32_t v2) {
+        const bool me = l == lane;
+        r0 = me ? v0 : r0; r1 = me ? v1 : r1; r2 = me ? v2 : r2;
     };
     auto get2 = [&](const uint32_t (&R)[2], uint32_t q) -> uint32_t {
         const uint32_t v0 = rl(R[0], q & 63u), v1 = rl(R[1], q & 63u);
