@@ -502,6 +502,7 @@ def main():
     ap.add_argument("--no-overlap-pass", action="store_true",
                     help="skip the extra stage-overlap pass (profiles/collect.sh: keeps rocprofv3's per-kernel averages equal to "
                          "the timed region's)")
+    ap.add_argument("--gather-timeout", type=int, default=240, help="seconds the multi-GPU exchange leg may take before the line is printed without it")
     ap.add_argument("--with-gather", action="store_true",
                     help="N>1: include the RCCL gather of records + streams to rank 0 in the timed region")
     ap.add_argument("--sorter", type=int, default=0, help="0 bucket sorter (default), 1 general sorter only (A/B)")
@@ -607,10 +608,15 @@ def main():
             raise RuntimeError("glcCompactStreams -> %d" % rc)
         plan.synchronize()                                    # the compacted streams are complete for any stream
 
-    # the exchange under the C ABI (include/glc_exchange.h: RCCL); over gloo (one-device dry run) the same protocol in torch
-    xch = ex.RcclExchange(glc, torch, dist) if (world > 1 and not one_device) else None
+    # the exchange under the C ABI (include/glc_exchange.h: RCCL); over gloo (one-device dry run) the same protocol in
+    # torch.  The communicator is made inside the gather leg, which runs LAST and under a watchdog: whatever happens to
+    # the exchange, the line with `value` is printed.
+    xch = None
 
     def exchange():
+        nonlocal xch
+        if xch is None and world > 1 and not one_device:
+            xch = ex.RcclExchange(glc, torch, dist)
         if xch is None:
             return ex.gather_blocks(dist, torch, compact, compact_off, ex.pack_records(torch, out, nblocks, nsub), dst=0)
         g = xch.gather(compact, compact_off.data_ptr() + 8 * nblocks, xch.pack_records(out, nblocks, nsub), dst=0)
@@ -722,8 +728,12 @@ def main():
 
     # result collection (the one exchange step of the multi-GPU path): timed on its own, timed INSIDE the encode
     # (per batch on a side stream, overlapped with the next batch's encode), then checked on rank 0
-    gather_info = None
-    if world > 1:
+    def gather_leg():
+        brk = os.environ.get("GLC_BENCH_BREAK_EXCHANGE", "")             # test aid: "<rank>" fails, "hang<rank>" never returns
+        if brk == str(rank):
+            raise RuntimeError("exchange leg broken on purpose (GLC_BENCH_BREAK_EXCHANGE)")
+        if brk == "hang%d" % rank:
+            time.sleep(1e6)
         barrier()
         tg0 = time.perf_counter()
         gathered = exchange()
@@ -811,6 +821,7 @@ def main():
             if okc != tot or okd != tot:
                 raise RuntimeError("multi-GPU result check failed: %s" % gather_info)
         del gathered
+        return gather_info
 
     # decode leg (not part of `value`): every block back through the HIP decoder, then the
     # full-size property check decode(encode(x)) == x on all bytes
@@ -1012,10 +1023,6 @@ def main():
             "kernels": ktab,
             "parity": verify,
         }
-        if gather_info is not None:
-            res["gather_to_rank0"] = gather_info
-            res["value_with_gather"] = gather_info.get("value_with_gather_GBps")
-            res["gather_ms"] = gather_info["ms"]
 
     # the other configs' single-GPU figures, same run (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.main_only:
@@ -1041,8 +1048,36 @@ def main():
             res["cpu_baseline"] = cpu_baseline(sample_host, log_sample)
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(sample_host, None)
+    gather_failed = False
+    if world > 1:
+        # the gather leg last, under a watchdog: a rank that waits for a peer that is gone still lets the line out
+        import threading
+
+        def give_up():
+            if rank == 0:
+                res["gather_to_rank0"] = {"error": "the exchange leg did not finish within %d s" % args.gather_timeout}
+                res["value_with_gather"] = None
+                res["gather_ms"] = None
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.gather_timeout + (0 if rank == 0 else 10), give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            gather_info = gather_leg()
+        except Exception as e:                                 # noqa: BLE001 -- reported in the line, never fatal to `value`
+            gather_info = {"error": "%s: %s" % (type(e).__name__, e)}
+            gather_failed = True
+        dog.cancel()
+        if rank == 0:
+            res["gather_to_rank0"] = gather_info
+            res["value_with_gather"] = gather_info.get("value_with_gather_GBps")
+            res["gather_ms"] = gather_info.get("ms")
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
+    if gather_failed:
+        os._exit(0)                                            # peers may be stuck in a collective: no orderly teardown
     pool.shutdown()
     if xch is not None:
         xch.close()
