@@ -132,7 +132,7 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
     // composites are disjoint subtrees of >= 2 leaves, so at most 128 are live, and at most 127 when one is added (a
     // merge out of 128 live composites takes at least one of them) -- entry k never lands on a live entry k - 128.
     uint32_t curL = l < nl ? T.sorted[l] : NONE;
-    uint32_t QA[2] = {NONE, NONE}, QB[2] = {0, 0}, CH[4] = {0, 0, 0, 0};   // count << 5 | level, slot << 10 | node; children by composite
+    uint32_t QA[2] = {NONE, NONE}, QB[2] = {0, 0}, CH[4] = {0, 0, 0, 0};   // count << 5 | level, slot << 16 | node; children by composite
     auto rl = [](uint32_t v, uint32_t lane) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); };
     // lane writes as compare + select (this compiler has no builtin for v_writelane_b32, and an asm statement costs more
     // in register copies around it than the two instructions it saves)
@@ -162,7 +162,7 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
                 const uint32_t lA = (lx >> 9) << 5;            /* NONE >> 9 << 5 is above every real key, below NONE */ \
                 if (lA < cA) {                                 /* a leaf (both queues empty cannot happen: k < nm) */ \
                     const uint32_t slot = lx & 511u;                                                                \
-                    a = lA; b = slot * 1025u;                  /* slot << 10 | node, node = slot */                \
+                    a = lA; b = slot * 65537u;                 /* slot << 16 | node, node = slot */                \
                     lh++;                                                                                           \
                     if ((lh & 63u) == 0) {                                                                          \
                         asm volatile("" ::: "memory");         /* a real branch: taken four times per tree */      \
@@ -181,10 +181,15 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
 #undef GLC_TAKE
             const uint32_t l0 = a0 & 31u, l1 = a1 & 31u;
             const uint32_t A = (((a0 >> 5) + (a1 >> 5)) << 5) | ((l0 > l1 ? l0 : l1) + 1u);
-            const uint32_t B = (b0 & ~1023u) | (nl + k);
-            const uint32_t kids = (b0 & 1023u) | ((b1 & 1023u) << 16);
+            const uint32_t B = (b0 & 0xFFFF0000u) | (nl + k);
+            const uint32_t kids = (b0 & 0xFFFFu) | (b1 << 16);
             const uint32_t pl = k & 63u;
-            if (k > ch && tA == A && tB > B) {
+            bool reorder = false;
+            if (tA == A) {                                     // (rare: the tail composite has this count and level)
+                asm volatile("" ::: "memory");
+                reorder = k > ch && tB > B;
+            }
+            if (reorder) {
                 // composites of the same count and level at the tail with a larger slot move up by one
                 wl(CH[seg], pl, kids);
                 uint32_t q = k;
