@@ -502,6 +502,7 @@ def main():
     ap.add_argument("--no-overlap-pass", action="store_true",
                     help="skip the extra stage-overlap pass (profiles/collect.sh: keeps rocprofv3's per-kernel averages equal to "
                          "the timed region's)")
+    ap.add_argument("--strided", action="store_true", help="timed encode writes the reference's strided layout, then one glcCompactStreams pass (rounds 1-2)")
     ap.add_argument("--gather-timeout", type=int, default=240, help="seconds the multi-GPU exchange leg may take before the line is printed without it")
     ap.add_argument("--with-gather", action="store_true",
                     help="N>1: include the RCCL gather of records + streams to rank 0 in the timed region")
@@ -543,11 +544,16 @@ def main():
     d_in = gen_blocks(torch, dev, nblocks, rank, world)
     nsub = n // 4096
     stride = glc.compressed_stride_words(n)
+    # output layout of the timed encode: COMPACT (glcCompressBatchCompact: every block is packed where it ends up, the
+    # batches chained through a device-side start offset -- one contiguous array, no copy pass) unless several host
+    # threads encode on several plans (--enc-threads > 1: their batches interleave, so they write the reference's strided
+    # layout and one glcCompactStreams pass follows, as in rounds 1-2)
+    use_compact = args.enc_threads <= 1 and not args.strided
     out = dict(bwt_index=torch.empty(nblocks, dtype=torch.int32, device=dev),
                hist=torch.empty(nblocks * 256, dtype=torch.int32, device=dev),
                offsets=torch.empty(nblocks * nsub, dtype=torch.int32, device=dev),
                size=torch.empty(nblocks, dtype=torch.int32, device=dev),
-               words=torch.empty(nblocks * stride, dtype=torch.int32, device=dev))
+               words=None if use_compact else torch.empty(nblocks * stride, dtype=torch.int32, device=dev))
     compact = torch.empty(nblocks * stride, dtype=torch.int32, device=dev)
     compact_off = torch.empty(nblocks + 1, dtype=torch.int64, device=dev)
     ctx = glc.Cudpp()
@@ -585,16 +591,44 @@ def main():
         for f in [pool.submit(fn, t, nthreads) for t in range(nthreads)]:
             f.result()
 
+    def enc_batch(pl, b0, nb, words=None, block_off=None, chained=True):
+        """one batch through the encoder.  Compact layout: into `words` (default: the one array of the whole input) with
+        offsets at block_off (default: the global ones, the batch starting where the one before ended)"""
+        if use_compact:
+            rc = L.glcCompressBatchCompact(pl.handle, d_in.data_ptr() + b0 * n, out["bwt_index"].data_ptr() + 4 * b0,
+                                           out["hist"].data_ptr() + 1024 * b0, out["offsets"].data_ptr() + 4 * nsub * b0, nsub,
+                                           out["size"].data_ptr() + 4 * b0,
+                                           (compact if words is None else words).data_ptr(), (compact if words is None else words).numel(),
+                                           (compact_off.data_ptr() + 8 * b0) if block_off is None else block_off.data_ptr(),
+                                           (compact_off.data_ptr() + 8 * b0) if (chained and block_off is None and b0 > 0) else None, n, nb)
+        else:
+            rc = L.glcCompressBatch(pl.handle, d_in.data_ptr() + b0 * n, out["bwt_index"].data_ptr() + 4 * b0,
+                                    out["hist"].data_ptr() + 1024 * b0, out["offsets"].data_ptr() + 4 * nsub * b0, nsub,
+                                    out["size"].data_ptr() + 4 * b0, out["words"].data_ptr() + 4 * stride * b0, stride, n, nb)
+        if rc != 0:
+            raise RuntimeError("glcCompressBatch%s -> %d" % ("Compact" if use_compact else "", rc))
+
+    def dec_batch(pl, b0, nb, d_out_ptr):
+        if use_compact:
+            return L.glcDecompressBatchCompact(pl.handle, out["bwt_index"].data_ptr() + 4 * b0, out["hist"].data_ptr() + 1024 * b0,
+                                               out["offsets"].data_ptr() + 4 * nsub * b0, nsub, compact.data_ptr(), compact.numel(),
+                                               compact_off.data_ptr() + 8 * b0, d_out_ptr, n, nb)
+        return L.glcDecompressBatch(pl.handle, out["bwt_index"].data_ptr() + 4 * b0, out["hist"].data_ptr() + 1024 * b0,
+                                    out["offsets"].data_ptr() + 4 * nsub * b0, nsub, out["words"].data_ptr() + 4 * stride * b0,
+                                    stride, d_out_ptr, n, nb)
+
+    def words_of_block(b, size):
+        if use_compact:
+            o = int(compact_off[b].item())
+            return compact[o:o + size]
+        return out["words"][b * stride: b * stride + size]
+
     def enc_worker(t, nt):
         torch.cuda.set_device(dev)                            # the HIP device is per host thread
         pl = plans[t]
         for b0 in batches[t::nt]:
             nb = min(rows, nblocks - b0)
-            rc = L.glcCompressBatch(pl.handle, d_in.data_ptr() + b0 * n, out["bwt_index"].data_ptr() + 4 * b0,
-                                    out["hist"].data_ptr() + 1024 * b0, out["offsets"].data_ptr() + 4 * nsub * b0, nsub,
-                                    out["size"].data_ptr() + 4 * b0, out["words"].data_ptr() + 4 * stride * b0, stride, n, nb)
-            if rc != 0:
-                raise RuntimeError("glcCompressBatch -> %d" % rc)
+            enc_batch(pl, b0, nb)
             st2 = pl.last_sort_stats()
             flagged[0] += st2[0]
             flagged[1] += st2[1]
@@ -602,6 +636,8 @@ def main():
 
     def encode_all():
         run_threads(enc_worker, args.enc_threads)
+        if use_compact:
+            return                                            # (enc_worker has waited for its plan)
         rc = L.glcCompactStreams(plan.handle, out["words"].data_ptr(), stride, out["size"].data_ptr(), nblocks,
                                  compact.data_ptr(), compact_off.data_ptr())
         if rc != 0:
@@ -645,16 +681,15 @@ def main():
                 wo += sum(g["words"]); bo += sum(g["nblk"])
         for k, b0 in enumerate(batches):
             nb = min(rows, nblocks - b0)
-            rc = L.glcCompressBatch(pl.handle, d_in.data_ptr() + b0 * n, out["bwt_index"].data_ptr() + 4 * b0,
-                                    out["hist"].data_ptr() + 1024 * b0, out["offsets"].data_ptr() + 4 * nsub * b0, nsub,
-                                    out["size"].data_ptr() + 4 * b0, out["words"].data_ptr() + 4 * stride * b0, stride, n, nb)
-            if rc != 0:
-                raise RuntimeError("glcCompressBatch -> %d" % rc)
             offk = batch_off[k]
-            rc = L.glcCompactStreams(pl.handle, out["words"].data_ptr() + 4 * stride * b0, stride, out["size"].data_ptr() + 4 * b0,
-                                     nb, compact.data_ptr() + 4 * stride * b0, offk.data_ptr())
-            if rc != 0:
-                raise RuntimeError("glcCompactStreams -> %d" % rc)
+            if use_compact:                                    # the batch's streams back to back in its own piece of `compact`
+                enc_batch(pl, b0, nb, words=compact[b0 * stride:(b0 + nb) * stride], block_off=offk)
+            else:
+                enc_batch(pl, b0, nb)
+                rc = L.glcCompactStreams(pl.handle, out["words"].data_ptr() + 4 * stride * b0, stride, out["size"].data_ptr() + 4 * b0,
+                                         nb, compact.data_ptr() + 4 * stride * b0, offk.data_ptr())
+                if rc != 0:
+                    raise RuntimeError("glcCompactStreams -> %d" % rc)
             with torch.cuda.stream(st_main):
                 rec = xch.pack_records(out, nb, nsub, first_block=b0, stream=st_main.cuda_stream)
                 ev = torch.cuda.Event()
@@ -832,9 +867,7 @@ def main():
         pl = plans[t]
         for b0 in batches[t::nt]:
             nb = min(rows, nblocks - b0)
-            rc = L.glcDecompressBatch(pl.handle, out["bwt_index"].data_ptr() + 4 * b0, out["hist"].data_ptr() + 1024 * b0,
-                                      out["offsets"].data_ptr() + 4 * nsub * b0, nsub, out["words"].data_ptr() + 4 * stride * b0,
-                                      stride, d_back.data_ptr() + b0 * n, n, nb)
+            rc = dec_batch(pl, b0, nb, d_back.data_ptr() + b0 * n)
             if rc != 0:
                 raise RuntimeError("glcDecompressBatch -> %d" % rc)
         pl.synchronize()
@@ -863,9 +896,7 @@ def main():
     nrep = min(4, len(batches))
     for b0 in batches[:nrep]:
         nb = min(rows, nblocks - b0)
-        L.glcDecompressBatch(plan.handle, out["bwt_index"].data_ptr() + 4 * b0, out["hist"].data_ptr() + 1024 * b0,
-                             out["offsets"].data_ptr() + 4 * nsub * b0, nsub, out["words"].data_ptr() + 4 * stride * b0, stride,
-                             d_back1.data_ptr(), n, nb)
+        dec_batch(plan, b0, nb, d_back1.data_ptr())
     plan.synchronize()
     dec1 = sum(min(rows, nblocks - b0) for b0 in batches[:nrep]) * n / (time.perf_counter() - t0d) / 1e9
     dec_prof = plan.kernel_profiles()
@@ -898,7 +929,7 @@ def main():
                 wants = list(tp.map(O.compress, sample_host))
             okc = 0
             for b, want in zip(pick, wants):
-                got = out["words"][b * stride: b * stride + int(sizes[b])].cpu().numpy().view(np.uint32)
+                got = words_of_block(b, int(sizes[b])).cpu().numpy().view(np.uint32)
                 okc += int(int(out["bwt_index"][b].item()) == want["bwt_index"] and int(sizes[b]) == want["size"]
                            and np.array_equal(got, want["words"])
                            and np.array_equal(out["hist"][b * 256:(b + 1) * 256].cpu().numpy().view(np.uint32), want["hist"]))
@@ -989,6 +1020,10 @@ def main():
                                    + ", 1 MiB blocks, cudppCompress BWT+MTF+Huffman encode",
                        "value_is": "encode input bytes of all ranks / wall time (inputs resident in HBM; no data-path collective"
                                    + ("; RCCL gather of records + streams to rank 0 included)" if args.with_gather else ")"),
+                       "output_layout": ("compact: glcCompressBatchCompact packs every block where it ends up, one contiguous array per GPU "
+                                         "(+ per-block offsets, sizes, histograms, sub-block offsets, BWT indices); no copy pass"
+                                         if use_compact else
+                                         "strided (the reference's per-block layout, glcCompressBatch) + one glcCompactStreams copy pass into a contiguous array"),
                        "block_bytes": n, "blocks_per_gpu": nblocks, "batch_rows": rows,
                        "plans_per_gpu": nplans, "encode_host_threads": min(args.enc_threads, nplans),
                        "decode_host_threads": min(args.dec_threads, nplans),

@@ -248,11 +248,19 @@ CUDPPResult cudppDestroyPlan(CUDPPHandle planHandle)
 // --------------------------------------------------------------------------
 // batched entry points
 // --------------------------------------------------------------------------
-CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_uncompressed, int *d_bwtIndex,
-                             unsigned int *d_hist, unsigned int *d_encodeOffset, size_t offsetStride,
-                             unsigned int *d_compressedSize, unsigned int *d_compressed,
-                             size_t compressedStrideWords, size_t numElements, size_t numBlocks)
+// One body for the two output layouts.  Strided (d_blockOffsets == nullptr): block b's words at d_compressed +
+// b * compressedStrideWords, the reference's layout per block.  Compact: block b's words at d_compressed +
+// d_blockOffsets[b], the blocks back to back from *d_startOffset on -- the sizes are known before anything is packed
+// (k_huff_build), so the packer writes every block where it ends up and no copy pass follows.  In that mode the packer
+// runs once, after the host knows that no block's size can still change (the sorter's tiers are through).
+static CUDPPResult compress_batch(CUDPPHandle planHandle, const unsigned char *d_uncompressed, int *d_bwtIndex,
+                                  unsigned int *d_hist, unsigned int *d_encodeOffset, size_t offsetStride,
+                                  unsigned int *d_compressedSize, unsigned int *d_compressed,
+                                  size_t compressedStrideWords, size_t numElements, size_t numBlocks,
+                                  unsigned long long *d_blockOffsets, const unsigned long long *d_startOffset,
+                                  size_t capacityWords)
 {
+    const bool compact = d_blockOffsets != nullptr;
     CompressPlan *p = plan_from<CompressPlan>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     if (p->config.algorithm != CUDPP_COMPRESS) return CUDPP_ERROR_INVALID_PLAN;
@@ -293,10 +301,12 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
         }
         if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist, only);
         if (p->timing) (void)hipEventRecord(p->ev[2], s2);
+        // (compact layout: a block has no slot of its own to overflow -- the array's capacity is checked with the offsets)
         if (e == hipSuccess) e = huff_build(s2, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
-                                            compressedStrideWords, p->d_status, redo_flag, only);
-        if (e == hipSuccess) e = huff_pack(s2, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
-                                           d_compressed, compressedStrideWords, only);
+                                            compact ? (size_t)(HUFF_MAX_WORDS + 1) * nsub : compressedStrideWords, p->d_status,
+                                            redo_flag, only);
+        if (e == hipSuccess && !compact) e = huff_pack(s2, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride,
+                                                       d_compressed, compressedStrideWords, only);
         if (p->timing) (void)hipEventRecord(p->ev[3], s2);
     };
     // Blocks the bucket sorter has given up on (flagged up front as text-like, or after its attempt) are skipped by this
@@ -312,9 +322,35 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
         tm.mark(1);                                            // the sort stage ends here: the other tiers' time is the sort's
         after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr);
     }
+    if (e == hipSuccess && compact) {
+        e = huff_block_offsets(s2, d_compressedSize, nb, d_blockOffsets, d_startOffset, capacityWords, p->d_status);
+        if (e == hipSuccess) e = huff_pack(s2, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride, d_compressed, 0,
+                                           nullptr, d_blockOffsets, capacityWords);
+        if (p->timing) (void)hipEventRecord(p->ev[3], s2);
+    }
     tm.done();
     if (p->pipelined) { (void)hipEventRecord(p->ev_released[k], s2); p->released_valid[k] = true; p->side_busy = true; }
     return hip_result(e);
+}
+
+CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_uncompressed, int *d_bwtIndex,
+                             unsigned int *d_hist, unsigned int *d_encodeOffset, size_t offsetStride,
+                             unsigned int *d_compressedSize, unsigned int *d_compressed,
+                             size_t compressedStrideWords, size_t numElements, size_t numBlocks)
+{
+    return compress_batch(planHandle, d_uncompressed, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
+                          d_compressed, compressedStrideWords, numElements, numBlocks, nullptr, nullptr, 0);
+}
+
+CUDPPResult glcCompressBatchCompact(CUDPPHandle planHandle, const unsigned char *d_uncompressed, int *d_bwtIndex,
+                                    unsigned int *d_hist, unsigned int *d_encodeOffset, size_t offsetStride,
+                                    unsigned int *d_compressedSize, unsigned int *d_compact, size_t capacityWords,
+                                    unsigned long long *d_blockOffsets, const unsigned long long *d_startOffset,
+                                    size_t numElements, size_t numBlocks)
+{
+    if (!d_blockOffsets || !d_compact) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    return compress_batch(planHandle, d_uncompressed, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
+                          d_compact, 0, numElements, numBlocks, d_blockOffsets, d_startOffset, capacityWords);
 }
 
 // the Huffman half of cudppCompress on its own (histogram, tree + codes, bit packer, offsets: rows a5-a8)
@@ -381,10 +417,11 @@ CUDPPResult glcMtfBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsig
     return hip_result(mtf_forward(p->stream, d_in, n, n, nb, d_out, n, p->mtf, nullptr));
 }
 
-CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, const unsigned int *d_hist,
-                               const unsigned int *d_encodeOffset, size_t offsetStride,
-                               const unsigned int *d_compressed, size_t compressedStrideWords,
-                               unsigned char *d_out, size_t numElements, size_t numBlocks)
+static CUDPPResult decompress_batch(CUDPPHandle planHandle, const int *d_bwtIndex, const unsigned int *d_hist,
+                                    const unsigned int *d_encodeOffset, size_t offsetStride,
+                                    const unsigned int *d_compressed, size_t compressedStrideWords,
+                                    unsigned char *d_out, size_t numElements, size_t numBlocks,
+                                    const unsigned long long *d_blockOffsets)
 {
     CompressPlan *p = plan_from<CompressPlan>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
@@ -398,7 +435,7 @@ CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, co
     if (!p->pipelined)
         return hip_result(decode_blocks(p->stream, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compressed,
                                         compressedStrideWords, d_out, (uint32_t)numElements, (uint32_t)numBlocks,
-                                        p->dec, p->mtf, p->d_status));
+                                        p->dec, p->mtf, p->d_status, d_blockOffsets));
     // pipelined: Huffman + inverse MTF on the plan's stream (inputs keep their stream order), the inverse
     // BWT -- a memory-latency-bound walk -- on the side stream, where it overlaps stage A of the next call.
     // d_out is complete after glcPlanSynchronize / a device synchronize.
@@ -409,7 +446,7 @@ CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, co
     uint8_t *bwt = k ? p->dec.bwt2 : p->dec.bwt;
     if (p->dec_released_valid[k]) (void)hipStreamWaitEvent(st, p->ev_dec_released[k], 0);
     e = decode_stage_a(st, d_hist, d_encodeOffset, offsetStride, d_compressed, compressedStrideWords,
-                       (uint32_t)numElements, (uint32_t)numBlocks, p->dec, bwt, p->d_status);
+                       (uint32_t)numElements, (uint32_t)numBlocks, p->dec, bwt, p->d_status, d_blockOffsets);
     (void)hipEventRecord(p->ev_dec_a[k], st);
     (void)hipStreamWaitEvent(p->side, p->ev_dec_a[k], 0);
     if (e == hipSuccess) e = decode_stage_b(p->side, d_bwtIndex, bwt, d_out, (uint32_t)numElements, (uint32_t)numBlocks, p->dec, p->d_status);
@@ -417,6 +454,26 @@ CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, co
     p->dec_released_valid[k] = true;
     p->side_busy = true;
     return hip_result(e);
+}
+
+CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex, const unsigned int *d_hist,
+                               const unsigned int *d_encodeOffset, size_t offsetStride,
+                               const unsigned int *d_compressed, size_t compressedStrideWords,
+                               unsigned char *d_out, size_t numElements, size_t numBlocks)
+{
+    return decompress_batch(planHandle, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compressed,
+                            compressedStrideWords, d_out, numElements, numBlocks, nullptr);
+}
+
+CUDPPResult glcDecompressBatchCompact(CUDPPHandle planHandle, const int *d_bwtIndex, const unsigned int *d_hist,
+                                      const unsigned int *d_encodeOffset, size_t offsetStride,
+                                      const unsigned int *d_compact, size_t compactWords,
+                                      const unsigned long long *d_blockOffsets, unsigned char *d_out,
+                                      size_t numElements, size_t numBlocks)
+{
+    if (!d_blockOffsets) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    return decompress_batch(planHandle, d_bwtIndex, d_hist, d_encodeOffset, offsetStride, d_compact, compactWords, d_out,
+                            numElements, numBlocks, d_blockOffsets);
 }
 
 // --------------------------------------------------------------------------

@@ -146,12 +146,25 @@ __device__ __forceinline__ uint32_t dh_decode_span(const uint32_t *s_w, uint32_t
     return (cnt << 8) | (pos - span_bits);
 }
 
+// where block b's words are and how many belong to it.  Strided layout: slot b of comp_stride words.  Compact layout
+// (block_off, nblk + 1 entries; comp_stride = words in the whole array): [block_off[b], block_off[b + 1]) -- offsets
+// come from the stream's producer, possibly another process: a range that does not ascend or leaves the array is empty.
+__device__ __forceinline__ void dec_block_slot(const unsigned long long *block_off, uint32_t b, size_t comp_stride,
+                                               uint64_t &base, uint64_t &slot)
+{
+    if (!block_off) { base = (uint64_t)b * comp_stride; slot = comp_stride; return; }
+    const uint64_t b0 = block_off[b], b1 = block_off[b + 1];
+    const bool ok = b1 >= b0 && b1 <= comp_stride;
+    base = ok ? b0 : 0; slot = ok ? b1 - b0 : 0;
+}
+
 __global__ __launch_bounds__(DH_WAVES * 64) void k_dec_huff(const uint32_t *__restrict__ comp, size_t comp_stride,
                                                             const uint32_t *__restrict__ offsets, size_t offset_stride,
                                                             const uint32_t *__restrict__ lut,
                                                             const uint32_t *__restrict__ nodes, uint32_t n,
                                                             uint8_t *__restrict__ mtf, size_t mtf_stride,
-                                                            uint32_t *__restrict__ d_status)
+                                                            uint32_t *__restrict__ d_status,
+                                                            const unsigned long long *__restrict__ block_off)
 {
     __shared__ uint16_t s_lut[1 << DEC_LUT_BITS];
     __shared__ uint32_t s_nodes[HUFF_NODES];
@@ -171,13 +184,20 @@ __global__ __launch_bounds__(DH_WAVES * 64) void k_dec_huff(const uint32_t *__re
     const uint32_t lo = sub * HUFF_BLOCK, cnt = min((uint32_t)HUFF_BLOCK, n - lo);
     // offsets and lengths come from the stream: stay inside the block's slot whatever they say
     uint32_t off = offsets[(size_t)b * offset_stride + sub];
-    if ((size_t)off + 1 > comp_stride) { off = 0; if (d_status && l == 0) atomicOr(d_status, ST_CORRUPT); }
-    const uint32_t *w = comp + (size_t)b * comp_stride + off;
-    uint32_t nwords = w[0];
-    if (nwords > HUFF_MAX_WORDS || (size_t)off + 1 + nwords > comp_stride) {
-        nwords = (uint32_t)min((size_t)min(nwords, (uint32_t)HUFF_MAX_WORDS), comp_stride - off - 1);
-        if (d_status && l == 0) atomicOr(d_status, ST_CORRUPT);
+    uint64_t wbase, slot;
+    dec_block_slot(block_off, b, comp_stride, wbase, slot);
+    bool bad = false;
+    if ((uint64_t)off + 1 > slot) { off = 0; bad = true; }
+    const uint32_t *w = comp + wbase + off;
+    uint32_t nwords = 0;
+    if (slot > 0) {
+        nwords = w[0];
+        if (nwords > HUFF_MAX_WORDS || (uint64_t)off + 1 + nwords > slot) {
+            nwords = (uint32_t)min((uint64_t)min(nwords, (uint32_t)HUFF_MAX_WORDS), slot - off - 1);
+            bad = true;
+        }
     }
+    if (bad && d_status && l == 0) atomicOr(d_status, ST_CORRUPT);
     w++;
     const uint32_t S = max(1u, (nwords + 63) / 64), P = S | 1u;
     uint32_t *sw = s_words[wv];
@@ -226,7 +246,8 @@ __global__ __launch_bounds__(DL_NT) void k_dec_huff_lanes(const uint32_t *__rest
                                                           const uint32_t *__restrict__ lut,
                                                           const uint32_t *__restrict__ nodes, uint32_t n,
                                                           uint8_t *__restrict__ mtf, size_t mtf_stride,
-                                                          uint32_t *__restrict__ d_status)
+                                                          uint32_t *__restrict__ d_status,
+                                                          const unsigned long long *__restrict__ block_off)
 {
     __shared__ uint16_t s_lut[1 << DEC_LUT_BITS];
     __shared__ uint32_t s_nodes[HUFF_NODES];
@@ -244,13 +265,20 @@ __global__ __launch_bounds__(DL_NT) void k_dec_huff_lanes(const uint32_t *__rest
     const uint32_t lo = sub * HUFF_BLOCK, cnt = min((uint32_t)HUFF_BLOCK, n - lo);
     // offsets and lengths come from the stream: stay inside the block's slot whatever they say
     uint32_t off = offsets[(size_t)b * offset_stride + sub];
-    if ((size_t)off + 1 > comp_stride) { off = 0; if (d_status) atomicOr(d_status, ST_CORRUPT); }
-    const uint32_t *w = comp + (size_t)b * comp_stride + off;
-    uint32_t nwords = w[0];
-    if (nwords > HUFF_MAX_WORDS || (size_t)off + 1 + nwords > comp_stride) {
-        nwords = (uint32_t)min((size_t)min(nwords, (uint32_t)HUFF_MAX_WORDS), comp_stride - off - 1);
-        if (d_status) atomicOr(d_status, ST_CORRUPT);
+    uint64_t wbase, slot;
+    dec_block_slot(block_off, b, comp_stride, wbase, slot);
+    bool bad = false;
+    if ((uint64_t)off + 1 > slot) { off = 0; bad = true; }
+    const uint32_t *w = comp + wbase + off;
+    uint32_t nwords = 0;
+    if (slot > 0) {
+        nwords = w[0];
+        if (nwords > HUFF_MAX_WORDS || (uint64_t)off + 1 + nwords > slot) {
+            nwords = (uint32_t)min((uint64_t)min(nwords, (uint32_t)HUFF_MAX_WORDS), slot - off - 1);
+            bad = true;
+        }
     }
+    if (bad && d_status) atomicOr(d_status, ST_CORRUPT);
     w++;
     uint32_t *ring = s_ring + tid * DL_PITCH;
     uint32_t wi = 0, rd = 0, have = 0;                          // next word to fetch / ring read position / words in the ring
@@ -1061,7 +1089,7 @@ void decode_scratch_free(DecodeScratch &s)
 // (glcPlanSetPipelining): A is LDS/VALU work, B is a memory-latency-bound pointer chase.
 hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t *d_offsets, size_t offset_stride,
                           const uint32_t *d_comp, size_t comp_stride_words, uint32_t n, uint32_t nblk, DecodeScratch &s,
-                          uint8_t *bwt, uint32_t *d_status)
+                          uint8_t *bwt, uint32_t *d_status, const unsigned long long *d_block_off)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
@@ -1071,10 +1099,10 @@ hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t
     hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes);
     if ((uint64_t)nsub * nblk >= DL_MIN_SUBS)
         hipLaunchKernelGGL(k_dec_huff_lanes, dim3((nsub + DL_NT - 1) / DL_NT, nblk), dim3(DL_NT), 0, st, d_comp, comp_stride_words,
-                           d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
+                           d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status, d_block_off);
     else
         hipLaunchKernelGGL(k_dec_huff, dim3((nsub + DH_WAVES - 1) / DH_WAVES, nblk), dim3(DH_WAVES * 64), 0, st, d_comp, comp_stride_words,
-                           d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status);
+                           d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status, d_block_off);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_IMTF_POS, st) : -1;
     static const bool rings = getenv("GLC_IMTF_RINGS") != nullptr;   // A/B: the ring form of pass 1
@@ -1123,9 +1151,10 @@ hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t 
 
 hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist, const uint32_t *d_offsets,
                          size_t offset_stride, const uint32_t *d_comp, size_t comp_stride_words, uint8_t *d_out,
-                         uint32_t n, uint32_t nblk, DecodeScratch &s, MtfScratch & /*ms*/, uint32_t *d_status)
+                         uint32_t n, uint32_t nblk, DecodeScratch &s, MtfScratch & /*ms*/, uint32_t *d_status,
+                         const unsigned long long *d_block_off)
 {
-    GLC_TRY(decode_stage_a(st, d_hist, d_offsets, offset_stride, d_comp, comp_stride_words, n, nblk, s, s.bwt, d_status));
+    GLC_TRY(decode_stage_a(st, d_hist, d_offsets, offset_stride, d_comp, comp_stride_words, n, nblk, s, s.bwt, d_status, d_block_off));
     return decode_stage_b(st, d_bwt_index, s.bwt, d_out, n, nblk, s, d_status);
 }
 

@@ -240,9 +240,14 @@ hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s,
                       size_t capacity_words, uint32_t *d_status, const uint32_t *redo_flag = nullptr,
                       const uint32_t *only = nullptr);
 // pack (reads mtf bytes, writes the stream)
+//   d_block_off (compact layout): block b is written at d_compressed + d_block_off[b]; capacity_words bounds the array
 hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
                      HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride,
-                     uint32_t *d_compressed, size_t comp_stride_words, const uint32_t *only = nullptr);
+                     uint32_t *d_compressed, size_t comp_stride_words, const uint32_t *only = nullptr,
+                     const unsigned long long *d_block_off = nullptr, size_t capacity_words = 0);
+// d_off[b] = *d_start (0 if null) + sizes of the blocks before b; d_off[nblk] = the end; past capacity_words -> ST_CAPACITY
+hipError_t huff_block_offsets(hipStream_t st, const uint32_t *d_sizes, uint32_t nblk, unsigned long long *d_off,
+                              const unsigned long long *d_start, size_t capacity_words, uint32_t *d_status);
 
 hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride, const uint32_t *d_sizes,
                            uint32_t nblk, uint32_t *d_out, unsigned long long *d_off);
@@ -275,14 +280,16 @@ hipError_t tile_hist_scan9(hipStream_t st, uint32_t *tile_hist, uint32_t count, 
                            uint32_t max_tiles, uint32_t nblk, uint32_t tile_elems);
 hipError_t decode_scratch_alloc(DecodeScratch &s, uint32_t nmax, uint32_t rows);
 void       decode_scratch_free(DecodeScratch &s);
+// d_block_off (compact layout, nblk + 1 entries): block b's words are d_comp[d_block_off[b] .. d_block_off[b + 1])
 hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t *d_offsets, size_t offset_stride,
                           const uint32_t *d_comp, size_t comp_stride_words, uint32_t n, uint32_t nblk, DecodeScratch &s,
-                          uint8_t *bwt, uint32_t *d_status);
+                          uint8_t *bwt, uint32_t *d_status, const unsigned long long *d_block_off = nullptr);
 hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t *bwt, uint8_t *d_out, uint32_t n,
                           uint32_t nblk, DecodeScratch &s, uint32_t *d_status);
 hipError_t decode_blocks(hipStream_t st, const int *d_bwt_index, const uint32_t *d_hist,
                          const uint32_t *d_offsets, size_t offset_stride, const uint32_t *d_comp,
                          size_t comp_stride_words, uint8_t *d_out, uint32_t n, uint32_t nblk,
-                         DecodeScratch &s, MtfScratch &ms, uint32_t *d_status);
+                         DecodeScratch &s, MtfScratch &ms, uint32_t *d_status,
+                         const unsigned long long *d_block_off = nullptr);
 
 } // namespace glc

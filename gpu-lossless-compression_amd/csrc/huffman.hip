@@ -174,8 +174,11 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
                                                    const uint32_t *__restrict__ lens,
                                                    const uint32_t *__restrict__ d_offsets, size_t offset_stride,
                                                    uint32_t *__restrict__ d_comp, size_t comp_stride,
-                                                   uint64_t capacity_words, const uint32_t *__restrict__ only)
+                                                   uint64_t capacity_words, const uint32_t *__restrict__ only,
+                                                   const unsigned long long *__restrict__ block_off)
 {
+    // block_off (compact layout): block b's words start at d_comp + block_off[b] and capacity_words bounds the whole
+    // array; otherwise at d_comp + b * comp_stride with capacity_words per block
     constexpr int SPT = HUFF_BLOCK / 256;                     // 16 symbols per thread
     constexpr int MAXW = HUFF_BLOCK * 28 / 32 + 16;            // code length <= 28 for <= 2^20+1 total count
     __shared__ uint32_t s_code[257], s_len[257];
@@ -229,8 +232,9 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
 
     const uint32_t nwords = (total + 31) / 32;
     const uint32_t off = d_offsets[(size_t)b * offset_stride + sub];
-    if ((uint64_t)off + 1 + nwords > capacity_words) return;             // flagged by k_huff_build
-    uint32_t *dst = d_comp + (size_t)b * comp_stride + off;
+    const uint64_t base = block_off ? block_off[b] : 0ull;
+    if (base + off + 1 + nwords > capacity_words) return;                // flagged by k_huff_build / k_compact_offsets
+    uint32_t *dst = d_comp + (block_off ? (size_t)base : (size_t)b * comp_stride) + off;
     if (tid == 0) dst[0] = nwords;
     for (uint32_t i = tid; i < nwords; i += 256) dst[1 + i] = s_words[i];
 }
@@ -240,11 +244,15 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
 // layout to out[off[b] .. off[b]+size[b]); off has nblk+1 entries (last = total).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_compact_offsets(const uint32_t *__restrict__ sizes, uint32_t nblk,
-                                                          unsigned long long *__restrict__ off)
+                                                          unsigned long long *__restrict__ off,
+                                                          const unsigned long long *__restrict__ start,
+                                                          unsigned long long capacity, uint32_t *__restrict__ d_status)
 {
+    // start (optional): device word offset the first block begins at (the end of the batch before); capacity
+    // (with d_status): the array's size in words -- streams that would pass it are reported and not written
     __shared__ uint32_t s_tmp[20];
     __shared__ unsigned long long s_run;
-    if (threadIdx.x == 0) s_run = 0;
+    if (threadIdx.x == 0) s_run = start ? *start : 0ull;
     __syncthreads();
     for (uint32_t base = 0; base < nblk; base += 1024) {
         const uint32_t i = base + threadIdx.x;
@@ -257,7 +265,10 @@ __global__ __launch_bounds__(1024) void k_compact_offsets(const uint32_t *__rest
         if (threadIdx.x == 0) s_run = run + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) off[nblk] = s_run;
+    if (threadIdx.x == 0) {
+        off[nblk] = s_run;
+        if (d_status && s_run > capacity) atomicOr(d_status, ST_CAPACITY);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_compact_copy(const uint32_t *__restrict__ comp, size_t stride,
@@ -275,7 +286,8 @@ __global__ __launch_bounds__(256) void k_compact_copy(const uint32_t *__restrict
 hipError_t compact_streams(hipStream_t st, const uint32_t *d_comp, size_t stride, const uint32_t *d_sizes,
                            uint32_t nblk, uint32_t *d_out, unsigned long long *d_off)
 {
-    hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, d_sizes, nblk, d_off);
+    hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, d_sizes, nblk, d_off, (const unsigned long long *)nullptr,
+                       0ull, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_compact_copy, dim3(32, nblk), dim3(256), 0, st, d_comp, stride, d_sizes, d_off, d_out);
     return hipGetLastError();
 }
@@ -377,14 +389,24 @@ hipError_t huff_build(hipStream_t st, uint32_t n, uint32_t nblk, HuffScratch &s,
     return hipGetLastError();
 }
 
+hipError_t huff_block_offsets(hipStream_t st, const uint32_t *d_sizes, uint32_t nblk, unsigned long long *d_off,
+                              const unsigned long long *d_start, size_t capacity_words, uint32_t *d_status)
+{
+    hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, st, d_sizes, nblk, d_off, d_start,
+                       (unsigned long long)capacity_words, d_status);
+    return hipGetLastError();
+}
+
 hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint32_t n, uint32_t nblk,
                      HuffScratch &s, const uint32_t *d_offsets, size_t offset_stride, uint32_t *d_compressed,
-                     size_t comp_stride_words, const uint32_t *only)
+                     size_t comp_stride_words, const uint32_t *only, const unsigned long long *d_block_off,
+                     size_t capacity_words)
 {
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const int pi = s.prof ? s.prof->begin(PROF_HUFF_PACK, st) : -1;
     hipLaunchKernelGGL(k_huff_pack, dim3(nsub, nblk), dim3(256), 0, st, mtf, mtf_stride, n, s.codes, s.lens,
-                       d_offsets, offset_stride, d_compressed, comp_stride_words, (uint64_t)comp_stride_words, only);
+                       d_offsets, offset_stride, d_compressed, comp_stride_words,
+                       (uint64_t)(d_block_off ? capacity_words : comp_stride_words), only, d_block_off);
     if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
     return hipGetLastError();
 }

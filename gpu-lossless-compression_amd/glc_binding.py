@@ -39,6 +39,7 @@ CUDPP_SYMBOLS = [
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
     "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcPlanKernelProfileLost",
+    "glcCompressBatchCompact", "glcDecompressBatchCompact",
 ]
 CULZSS_SYMBOLS = [
     "compression_kernel_wrapper", "aftercompression_wrapper", "decompression_kernel_wrapper",
@@ -93,6 +94,8 @@ def lib():
     L.glcBwtBatch.argtypes = [sz, vp, vp, vp, sz, sz]
     L.glcMtfBatch.argtypes = [sz, vp, vp, sz, sz]
     L.glcDecompressBatch.argtypes = [sz, vp, vp, vp, sz, vp, sz, vp, sz, sz]
+    L.glcCompressBatchCompact.argtypes = [sz, vp, vp, vp, vp, sz, vp, vp, sz, vp, vp, sz, sz]
+    L.glcDecompressBatchCompact.argtypes = [sz, vp, vp, vp, sz, vp, sz, vp, vp, sz, sz]
     L.glcPlanSetStream.argtypes = [sz, vp]
     L.glcPlanSynchronize.argtypes = [sz]
     L.glcPlanSetPipelining.argtypes = [sz, C.c_int]
@@ -357,6 +360,46 @@ def compress_batch_into(plan, d_in, n, nblk, out):
                                 out["hist"].data_ptr(), out["offsets"].data_ptr(), out["nsub"],
                                 out["size"].data_ptr(), out["words"].data_ptr(), out["stride"], n, nblk)
     _chk("glcCompressBatch", rc)
+
+
+def compress_batch_compact(plan, d_in, n, nblk, words=None, block_off=None, start=None, meta=None, first=0):
+    """glcCompressBatchCompact.  words: int32 cuda tensor that receives the streams back to back (default: room for the
+    worst case); block_off: int64 tensor of >= first + nblk + 1 entries; start: data_ptr of a device u64 the first block
+    begins at (None = 0); meta: dict with bwt_index / hist / offsets / size tensors for >= first + nblk blocks (default:
+    new ones); first: index of this batch's first block in those arrays.  Returns the dict (+ words, block_off)."""
+    import torch
+    dev = d_in.device
+    nsub = (n + HUFF_BLOCK - 1) // HUFF_BLOCK
+    if meta is None:
+        meta = dict(bwt_index=torch.empty(first + nblk, dtype=torch.int32, device=dev),
+                    hist=torch.empty((first + nblk) * 256, dtype=torch.int32, device=dev),
+                    offsets=torch.empty((first + nblk) * nsub, dtype=torch.int32, device=dev),
+                    size=torch.empty(first + nblk, dtype=torch.int32, device=dev), nsub=nsub)
+    if words is None:
+        words = torch.empty(nblk * compressed_stride_words(n), dtype=torch.int32, device=dev)
+    if block_off is None:
+        block_off = torch.empty(first + nblk + 1, dtype=torch.int64, device=dev)
+    rc = lib().glcCompressBatchCompact(plan.handle, d_in.data_ptr(), meta["bwt_index"].data_ptr() + 4 * first,
+                                       meta["hist"].data_ptr() + 1024 * first, meta["offsets"].data_ptr() + 4 * nsub * first, nsub,
+                                       meta["size"].data_ptr() + 4 * first, words.data_ptr(), words.numel(),
+                                       block_off.data_ptr() + 8 * first, start, n, nblk)
+    _chk("glcCompressBatchCompact", rc)
+    out = dict(meta)
+    out.update(words=words, block_off=block_off, nsub=nsub)
+    return out
+
+
+def decompress_batch_compact(plan, comp, n, nblk, first=0, d_out=None):
+    """glcDecompressBatchCompact on the dict compress_batch_compact returns (blocks first .. first + nblk)"""
+    import torch
+    nsub = comp["nsub"]
+    if d_out is None:
+        d_out = torch.empty(nblk * n, dtype=torch.uint8, device=comp["words"].device)
+    rc = lib().glcDecompressBatchCompact(plan.handle, comp["bwt_index"].data_ptr() + 4 * first, comp["hist"].data_ptr() + 1024 * first,
+                                         comp["offsets"].data_ptr() + 4 * nsub * first, nsub, comp["words"].data_ptr(),
+                                         comp["words"].numel(), comp["block_off"].data_ptr() + 8 * first, d_out.data_ptr(), n, nblk)
+    _chk("glcDecompressBatchCompact", rc)
+    return d_out
 
 
 def decompress_batch(plan, comp, n, nblk):

@@ -160,6 +160,20 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
                              unsigned int *d_compressed, size_t compressedStrideWords,
                              size_t numElements, size_t numBlocks);
 
+/* The same encode with the COMPACT output layout: block b's words are written at d_compact + d_blockOffsets[b], the
+ * blocks back to back (d_blockOffsets: numBlocks + 1 entries, the last one = the end; d_compressedSize[b] =
+ * d_blockOffsets[b + 1] - d_blockOffsets[b]).  The first block starts at *d_startOffset (a DEVICE value, read in
+ * stream order; NULL = 0): pass the previous batch's d_blockOffsets + numBlocks and a sequence of batches fills one
+ * contiguous array with no host involvement -- the layout glcCompactStreams produces from the strided one, without
+ * the copy pass.  capacityWords = size of the d_compact array; streams that would pass it are not written and
+ * glcPlanSynchronize reports CUDPP_ERROR_UNKNOWN.  Everything else as glcCompressBatch. */
+CUDPPResult glcCompressBatchCompact(CUDPPHandle planHandle, const unsigned char *d_uncompressed,
+                                    int *d_bwtIndex, unsigned int *d_hist, unsigned int *d_encodeOffset,
+                                    size_t offsetStride, unsigned int *d_compressedSize,
+                                    unsigned int *d_compact, size_t capacityWords,
+                                    unsigned long long *d_blockOffsets, const unsigned long long *d_startOffset,
+                                    size_t numElements, size_t numBlocks);
+
 CUDPPResult glcBwtBatch(CUDPPHandle planHandle, const unsigned char *d_in, unsigned char *d_out,
                         int *d_index, size_t numElements, size_t numBlocks);
 
@@ -174,6 +188,15 @@ CUDPPResult glcDecompressBatch(CUDPPHandle planHandle, const int *d_bwtIndex,
                                size_t offsetStride, const unsigned int *d_compressed,
                                size_t compressedStrideWords, unsigned char *d_out,
                                size_t numElements, size_t numBlocks);
+
+/* glcDecompressBatch reading the compact layout: block b's words are d_compact[d_blockOffsets[b] ..
+ * d_blockOffsets[b + 1]) (numBlocks + 1 entries; absolute word offsets into d_compact, which holds compactWords
+ * words).  A range that does not ascend or leaves the array is treated as empty and reported. */
+CUDPPResult glcDecompressBatchCompact(CUDPPHandle planHandle, const int *d_bwtIndex,
+                                      const unsigned int *d_hist, const unsigned int *d_encodeOffset,
+                                      size_t offsetStride, const unsigned int *d_compact, size_t compactWords,
+                                      const unsigned long long *d_blockOffsets, unsigned char *d_out,
+                                      size_t numElements, size_t numBlocks);
 
 /* Run a plan's work on `hipStream` (a hipStream_t cast to void*; NULL = the
  * default stream, which is what the reference uses). */
