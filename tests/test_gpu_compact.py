@@ -19,7 +19,8 @@ def _blocks(n, kinds):
 
 @pytest.mark.parametrize("n,kinds", [(1 << 18, ["zipf", "float", "zipf", "zipf", "float"]),
                                      (1 << 16, ["zipf", "text", "zipf", "zeros", "float", "text", "zipf"]),   # blocks that leave the bucket sorter
-                                     (40961, ["zipf", "float", "zipf"]), (1 << 20, ["zipf", "float"])])
+                                     (40961, ["zipf", "float", "zipf"]), (1 << 20, ["zipf", "float"]),
+                                     (1, ["zipf"]), (7, ["zeros", "zipf", "float"]), (4097, ["zipf", "zeros"]), (4096, ["float"])])
 def test_compact_equals_strided_then_compacted(glc, cuda, n, kinds):
     import torch
     L = glc.lib()
