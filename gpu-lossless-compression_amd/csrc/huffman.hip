@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
     // array; otherwise at d_comp + b * comp_stride with capacity_words per block
     constexpr int SPT = HUFF_BLOCK / 256;                     // 16 symbols per thread
     constexpr int MAXW = HUFF_BLOCK * 28 / 32 + 16;            // code length <= 28 for <= 2^20+1 total count
-    __shared__ uint32_t s_code[257], s_len[257];
+    __shared__ uint2 s_cl[257];                                // {code, length}: one 8-byte LDS read per symbol
     __shared__ uint32_t s_words[MAXW];
     __shared__ uint32_t s_tmp[8];
     const uint32_t b = blockIdx.y, sub = blockIdx.x, tid = threadIdx.x;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
     const uint32_t lo = sub * HUFF_BLOCK;
     if (lo >= n) return;
     const uint32_t cntb = min((uint32_t)HUFF_BLOCK, n - lo);
-    for (uint32_t i = tid; i < 257; i += 256) { s_code[i] = codes[(size_t)b * 257 + i]; s_len[i] = lens[(size_t)b * 257 + i]; }
+    for (uint32_t i = tid; i < 257; i += 256) s_cl[i] = make_uint2(codes[(size_t)b * 257 + i], lens[(size_t)b * 257 + i]);
     for (uint32_t i = tid; i < MAXW; i += 256) s_words[i] = 0;
     __syncthreads();
 
@@ -205,29 +205,35 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
 #pragma unroll
         for (int j = 0; j < SPT; j++) sym[j] = (i0 + j < cntb) ? src[i0 + j] : 0;
     }
+    uint2 cl[SPT];                                             // read once, used by the bit count and by the merge
     uint32_t mybits = 0;
 #pragma unroll
-    for (int j = 0; j < SPT; j++) if (i0 + j < cntb) mybits += s_len[sym[j]];
+    for (int j = 0; j < SPT; j++) {
+        cl[j] = s_cl[sym[j]];
+        if (i0 + j >= cntb) cl[j] = make_uint2(0u, 0u);
+        mybits += cl[j].y;
+    }
     uint32_t total = 0;
     const uint32_t start = block_excl_add<256>(mybits, s_tmp, &total);
 
-    // shift-merge: pending bits live in the low `na` bits of acc
-    uint32_t wi = start >> 5, na = start & 31;
-    uint64_t acc = 0;
+    // merge, branch-free: `hi` is the word being filled (MSB first), `fill` its used bits.  A code of ln <= 28 bits goes
+    // in as the 64-bit value code << (64 - fill - ln): its upper half lands in `hi`, its lower half is the start of the
+    // next word, which becomes `hi` when the word is full.  (Pending bits kept right-aligned in a 64-bit accumulator
+    // needed a variable-length mask and a branch per symbol: ~25 VALU per symbol against ~12.)
+    uint32_t wi = start >> 5, fill = start & 31, hi = 0;
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
-        if (i0 + j < cntb) {
-            const uint32_t ln = s_len[sym[j]];
-            acc = (acc << ln) | s_code[sym[j]];
-            na += ln;
-            if (na >= 32) {
-                na -= 32;
-                atomicOr(&s_words[wi++], (uint32_t)(acc >> na));
-                acc &= (1ull << na) - 1ull;
-            }
-        }
+        const uint32_t ln = cl[j].y;                           // 0 (and code 0) past the end of the block: a no-op
+        const uint64_t V = (uint64_t)cl[j].x << ((64u - fill - ln) & 63u);
+        hi |= (uint32_t)(V >> 32);
+        const uint32_t nf = fill + ln;
+        const bool full = nf >= 32;
+        if (full) atomicOr(&s_words[wi], hi);
+        wi += full ? 1u : 0u;
+        hi = full ? (uint32_t)V : hi;
+        fill = nf & 31u;
     }
-    if (na > 0 && mybits > 0) atomicOr(&s_words[wi], (uint32_t)(acc << (32 - na)));
+    if (fill > 0 && mybits > 0) atomicOr(&s_words[wi], hi);
     __syncthreads();
 
     const uint32_t nwords = (total + 31) / 32;
