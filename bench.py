@@ -963,6 +963,9 @@ def main():
                 n64 = per_launch_units / 64.0
                 ktab[name]["valu_issue_frac"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["slow_class_cycles_per_inst"] / simd_cycles, 3)
                 ktab[name]["valu_issue_frac_if_all_fast_class"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["fast_class_cycles_per_inst"] / simd_cycles, 3)
+                if ktab[name]["valu_issue_frac"] > 1.0:
+                    ktab[name]["valu_issue_note"] = ("above 1 at 4 cycles per instruction: a good part of this kernel's instructions are of the "
+                                                     "2-cycle class (plain add / logic / mov); the truth lies between the two figures")
                 ktab[name]["salu_issue_frac"] = round(n64 * pk.get("SQ_INSTS_SALU", 0.0) / (simd_cycles / 4), 3)
                 ktab[name]["instructions_per_64_bytes"] = {"valu": pk["SQ_INSTS_VALU"], "salu": pk.get("SQ_INSTS_SALU"), "lds": pk.get("SQ_INSTS_LDS")}
         # decoder: per-kernel table of the one-plan pass (stages back to back) and its dominant kernel
