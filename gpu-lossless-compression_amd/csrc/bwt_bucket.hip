@@ -73,22 +73,26 @@ constexpr uint32_t FSH_SLICE = 32768;
 // takes it.  A wrong guess costs time, never correctness (the other way round, the attempt flags the block as before).
 constexpr uint32_t FSH_SLOTS = 2048, FS_DUP_FLAG = 48;
 
+#ifndef GLC_FSH_COPIES
+#define GLC_FSH_COPIES 16
+#endif
+constexpr int FSH_COPIES = GLC_FSH_COPIES;             // LDS copies of the histogram (same-symbol atomics of a wave spread over them)
 __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                  uint32_t *__restrict__ hist, uint32_t *__restrict__ dup)
 {
-    __shared__ uint32_t s_h[8 * 257];
+    __shared__ uint32_t s_h[FSH_COPIES * 257];
     __shared__ uint32_t s_fp[FSH_SLOTS];
     __shared__ uint32_t s_dup;
     const uint32_t b = blockIdx.y, tid = threadIdx.x;
     const uint32_t lo = blockIdx.x * FSH_SLICE;
     if (lo >= n) return;
     const uint32_t hi = min(n, lo + FSH_SLICE);
-    for (uint32_t i = tid; i < 8 * 257; i += 256) s_h[i] = 0;
+    for (uint32_t i = tid; i < FSH_COPIES * 257; i += 256) s_h[i] = 0;
     for (uint32_t i = tid; i < FSH_SLOTS; i += 256) s_fp[i] = 0;
     if (tid == 0) s_dup = 0;
     __syncthreads();
     const uint8_t *T = text + (size_t)b * stride;
-    uint32_t *H = s_h + (tid & 7) * 257;
+    uint32_t *H = s_h + (tid & (FSH_COPIES - 1)) * 257;
     uint32_t done = lo;
     if ((reinterpret_cast<uintptr_t>(T + lo) & 15) == 0) {
         const uint32_t nvec = (hi - lo) / 16;                       // <= 2048 = 8 per thread
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ tex
     __syncthreads();
     uint32_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) c += s_h[k * 257 + tid];
+    for (int k = 0; k < FSH_COPIES; k++) c += s_h[k * 257 + tid];
     if (c) atomicAdd(&hist[(size_t)b * 256 + tid], c);
     if (tid == 0 && s_dup) atomicAdd(&dup[b], s_dup);
 }
