@@ -35,14 +35,20 @@
  *     size, CRC, head / tail bytes, full bytes for the small buffers
  *     (tests/golden/make_lzss_gold.py, ref_lzss_gold.npz).  The decoder
  *     restatement reads those reference-packed bytes back to the input.
- *   - CULZSS match search (EncodeKernel / FindMatch, gpu_compress.cu:104-350)
- *     and DecodeKernel (gpu_decompress.cu:120-244) are CUDA only: no CPU twin
- *     and no test in the reference.  Restated lock-step from the cited lines;
- *     "parity unpinned" by reference-produced vectors for those two kernels.
- *     What they have: the survey's INDEPENDENT restatement KAT on pg1661.txt
- *     (candidates CRC 799b54ef, 569 823 packed bytes CRC 15c4edd7; SURVEY.md
- *     App. C; tests/test_cpu_oracle.py::test_survey_kat_on_pg1661), and the
- *     decoder reading bytes written by the reference's packer.
+ *   - CULZSS match search (FindMatch, gpu_compress.cu:104-168): pinned
+ *     against the reference's own FindMatch, whose body is plain C and is
+ *     compiled from the reference's lines by oracle/mk_ref_findmatch.sh; it
+ *     is called once per byte position on the rings as EncodeKernel fills
+ *     them (tests/golden/make_findmatch_gold.py), 24 inputs, candidate bytes
+ *     / CRCs in tests/golden/ref_findmatch_gold.npz; orc_lzss_candidates
+ *     reproduces every byte.  What stays restated is the data movement of
+ *     EncodeKernel around those calls (gpu_compress.cu:182-350: ring slots,
+ *     emit rule, last-chunk clamp) and DecodeKernel
+ *     (gpu_decompress.cu:120-244), both CUDA only; the decoder restatement
+ *     reads bytes written by the reference's packer back to the input, and
+ *     the survey's INDEPENDENT restatement KAT on pg1661.txt (candidates CRC
+ *     799b54ef, 569 823 packed bytes CRC 15c4edd7; SURVEY.md App. C;
+ *     tests/test_cpu_oracle.py::test_survey_kat_on_pg1661) agrees.
  */
 #include <stdint.h>
 #include <stdlib.h>

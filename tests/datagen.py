@@ -161,3 +161,27 @@ def lzss_gold_inputs():
     for k in (1, 2, 3, 4):
         c["log_%dpkt" % k] = log_bytes(4096 * k, seed=40 + k)
     return c
+
+
+def findmatch_gold_inputs():
+    """inputs of tests/golden/ref_findmatch_gold.npz (CULZSS row a11, the match search): the buffers of
+    lzss_gold_inputs() plus packets aimed at FindMatch's corners -- runs of 128 and more (length clamp to 127), a
+    4-symbol alphabet (many equally long runs: the first one found must win), all spaces (matches against the ring's
+    initial fill), periods 1 / 2 / 5, a run that starts inside the last 128-byte chunk (shortened scan + clamp),
+    and the '^' fill meeting '^' data.  Shared by tests/golden/make_findmatch_gold.py and the tests."""
+    c = dict(lzss_gold_inputs())
+    rng = np.random.default_rng(4242)
+    c["sym4_16k"] = rng.integers(0, 4, 16384, dtype=np.uint8) + 65
+    c["spaces_8k"] = np.full(8192, 0x20, dtype=np.uint8)
+    c["runs_ge128_8k"] = np.repeat(rng.integers(0, 256, 40, dtype=np.uint8), rng.integers(100, 400, 40))[:8192].copy()
+    c["period1_2_5_12k"] = np.concatenate([np.full(4096, 7, dtype=np.uint8), np.tile(np.array([8, 9], dtype=np.uint8), 2048),
+                                           np.tile(np.array([1, 2, 3, 4, 5], dtype=np.uint8), 820)[:4096]])
+    last = log_bytes(4096, seed=77).copy()
+    last[3968 + 40:] = last[3968 - 60:3968 - 60 + 88]                  # a repeat that begins 40 bytes into the last chunk
+    c["repeat_inside_last_chunk"] = last
+    car = text_bytes(4096, seed=8).copy()
+    car[3900:3968] = ord("^")                                             # '^' data just ahead of the '^'-filled slot
+    car[4000:] = ord("^")
+    c["caret_data_4k"] = car
+    c["random_64k"] = rng.integers(0, 256, 65536, dtype=np.uint8)
+    return c

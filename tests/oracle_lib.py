@@ -386,3 +386,27 @@ def ref_aftercomp_lib():
         L.aftercompression_wrapper.restype = C.c_int
         _aftercomp = L
     return _aftercomp
+
+
+FINDMATCH_SO = os.path.join(os.path.dirname(SAGOLD_SO), "libfindmatch.so")
+_findmatch = None
+
+
+class _EncodedString(C.Structure):          # gpu_compress.h:75-79
+    _fields_ = [("offset", C.c_int), ("length", C.c_int)]
+
+
+def have_ref_findmatch():
+    return os.path.exists(FINDMATCH_SO)
+
+
+def ref_findmatch_lib():
+    """oracle/_ref/libfindmatch.so: the reference's own FindMatch (cuda-lzss-cluster/gpu_compress.cu:104-168),
+    built by oracle/mk_ref_findmatch.sh from the reference's lines."""
+    global _findmatch
+    if _findmatch is None:
+        L = C.CDLL(FINDMATCH_SO)
+        L.ref_FindMatch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ref_FindMatch.restype = _EncodedString
+        _findmatch = L
+    return _findmatch

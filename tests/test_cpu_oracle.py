@@ -4,6 +4,7 @@ properties on the oracle, and checks the C-ABI library without touching a GPU.""
 import ctypes as C
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -394,3 +395,38 @@ def test_survey_kat_on_pg1661():
         m = ctypes.c_int(-1)
         assert O.ref_aftercomp_lib().aftercompression_wrapper(buf.ctypes.data, x.size, cand.ctypes.data, ctypes.byref(m)) == 1
         assert m.value == 569823 and np.array_equal(buf[: m.value], packed)
+
+
+# ------------------------------------------------ CULZSS match search vs the reference's own FindMatch (row a11) ----
+FM_GOLD = np.load(os.path.join(GOLD, "ref_findmatch_gold.npz"))
+_FM_INPUTS = None
+
+
+@pytest.mark.parametrize("name", [str(s) for s in FM_GOLD["names"]])
+def test_oracle_lzss_candidates_vs_reference_findmatch(name):
+    """orc_lzss_candidates == the candidate stream the reference's own FindMatch (gpu_compress.cu:104-168, compiled
+    from the reference's lines by oracle/mk_ref_findmatch.sh) produced inside EncodeKernel's ring choreography
+    (tests/golden/make_findmatch_gold.py): CRC-32 for every input, every byte for inputs up to 64 KiB."""
+    global _FM_INPUTS
+    import zlib
+    if _FM_INPUTS is None:
+        _FM_INPUTS = datagen.findmatch_gold_inputs()
+    x = _FM_INPUTS[name]
+    assert x.size == int(FM_GOLD[name + "/n"]) and (zlib.crc32(x.tobytes()) & 0xFFFFFFFF) == int(FM_GOLD[name + "/in_crc"]), "input of %s drifted" % name
+    cand = O.lzss_candidates(x)
+    assert (zlib.crc32(cand.tobytes()) & 0xFFFFFFFF) == int(FM_GOLD[name + "/cand_crc"]), name
+    if name + "/cand" in FM_GOLD:
+        assert np.array_equal(cand, FM_GOLD[name + "/cand"]), name
+    assert int(np.count_nonzero(cand[0::2] > 1)) == int(FM_GOLD[name + "/matches"])
+
+
+@pytest.mark.skipif(not O.have_ref_findmatch(), reason="oracle/_ref/libfindmatch.so not built (needs /root/reference)")
+def test_reference_findmatch_live_on_fresh_packets():
+    """the reference's FindMatch, run HERE on packets that are not in the fixture, against the oracle"""
+    sys.path.insert(0, GOLD)
+    import make_findmatch_gold as M
+    rng = np.random.default_rng(20260929)
+    for x in (datagen.log_bytes(8192, seed=123), datagen.text_bytes(4096, seed=321),
+              rng.integers(0, 3, 4096, dtype=np.uint8), np.repeat(rng.integers(0, 256, 64, dtype=np.uint8), 64)):
+        assert np.array_equal(M.ref_candidates(x), O.lzss_candidates(x))
+

@@ -9,8 +9,11 @@
 a13: the HIP token walk + packer (k_lzss_pack_wave / k_lzss_pack / layout / gather) on the same candidates must
      give exactly those bytes;
 a14: the HIP decoder (k_lzss_decode) must read bytes THE REFERENCE packed back to the input;
-a11: the HIP match kernel's candidate stream is compared with the CRC the fixture keeps of the stream the reference's
-     packer was fed (that stream is the oracle's: EncodeKernel has no CPU twin in the reference).
+a11: the HIP match kernel's candidate stream (k_lzss_match) against
+  tests/golden/ref_findmatch_gold.npz   the candidate streams the reference's own FindMatch
+                                   (gpu_compress.cu:104-168, compiled from the reference's lines by
+                                   oracle/mk_ref_findmatch.sh) produced inside EncodeKernel's ring choreography
+                                   (tests/golden/make_findmatch_gold.py): 24 inputs, CRC-32 each, every byte up to 64 KiB.
 Checksums are zlib's CRC-32."""
 import ctypes as C
 import os
@@ -127,3 +130,58 @@ def test_decoder_reads_reference_packed_bytes(glc, cuda, inputs, name):
     L.deleteCPUmem(buf)
     L.deleteGPUStreams()
     assert np.array_equal(back, x), name
+
+
+# ------------------------------------------------ a11: the match kernel against the reference's FindMatch ----
+FM = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_findmatch_gold.npz"))
+FM_NAMES = [str(s) for s in FM["names"]]
+
+
+@pytest.fixture(scope="module")
+def fm_inputs():
+    return datagen.findmatch_gold_inputs()
+
+
+@pytest.mark.parametrize("name", FM_NAMES)
+def test_match_kernel_equals_reference_findmatch(glc, cuda, fm_inputs, name):
+    """input -> k_lzss_match (through glcLzssEncodeDevice) == the bytes the reference's own FindMatch produced"""
+    import torch
+    L = glc.lib()
+    x = fm_inputs[name]
+    n = x.size
+    assert n == int(FM[name + "/n"]) and _crc(x) == int(FM[name + "/in_crc"]), name + ": input drifted"
+    d_in = torch.from_numpy(x.copy()).cuda()
+    d_cand = torch.full((2 * n,), 0xEE, dtype=torch.uint8, device=cuda)
+    d_packed = torch.zeros(L.glcLzssPackStride(n), dtype=torch.uint8, device=cuda)
+    d_size = torch.full((1,), -7, dtype=torch.int32, device=cuda)
+    d_work = torch.zeros(L.glcLzssWorkBytes(n, 1), dtype=torch.uint8, device=cuda)
+    assert L.glcLzssEncodeDevice(d_in.data_ptr(), n, 1, d_cand.data_ptr(), d_packed.data_ptr(), d_size.data_ptr(),
+                                 d_work.data_ptr(), None) == 1
+    torch.cuda.synchronize()
+    cand = d_cand.cpu().numpy()
+    if name + "/cand" in FM:
+        want = FM[name + "/cand"]
+        bad = np.flatnonzero(cand != want)
+        assert bad.size == 0, "%s: %d candidate bytes differ from the reference FindMatch, first at position %d" % (name, bad.size, int(bad[0]) // 2)
+    assert _crc(cand) == int(FM[name + "/cand_crc"]), name + ": candidate stream"
+
+
+def test_match_kernel_batch_of_reference_buffers(glc, cuda, fm_inputs):
+    """the 1 MiB fixture inputs as ONE batched launch (buffers side by side): every buffer's candidates == the reference's"""
+    import torch
+    L = glc.lib()
+    names = [s for s in FM_NAMES if int(FM[s + "/n"]) == 1 << 20]
+    n, nb = 1 << 20, len(names)
+    d_in = torch.from_numpy(np.concatenate([fm_inputs[s] for s in names])).cuda()
+    d_cand = torch.zeros(2 * n * nb, dtype=torch.uint8, device=cuda)
+    stride = L.glcLzssPackStride(n)
+    d_packed = torch.zeros(stride * nb, dtype=torch.uint8, device=cuda)
+    d_size = torch.zeros(nb, dtype=torch.int32, device=cuda)
+    d_work = torch.zeros(L.glcLzssWorkBytes(n, nb), dtype=torch.uint8, device=cuda)
+    assert L.glcLzssEncodeDevice(d_in.data_ptr(), n, nb, d_cand.data_ptr(), d_packed.data_ptr(), d_size.data_ptr(),
+                                 d_work.data_ptr(), None) == 1
+    torch.cuda.synchronize()
+    cand = d_cand.cpu().numpy()
+    for i, s in enumerate(names):
+        assert _crc(cand[2 * n * i: 2 * n * (i + 1)]) == int(FM[s + "/cand_crc"]), s
+
