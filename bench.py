@@ -670,9 +670,8 @@ def main():
 
         def collect(item):
             nonlocal wo, bo
-            k, b0, nb, ev, rec, offk = item
-            side.wait_event(ev)
-            g = xch.gather(compact[b0 * stride:], offk.data_ptr() + 8 * nb, rec, dst=0, stream=side.cuda_stream,
+            k, b0, nb, ticket, rec, offk = item
+            g = xch.gather(compact[b0 * stride:], offk.data_ptr() + 8 * nb, rec, dst=0, stream=side.cuda_stream, ticket=ticket,
                            out_words=root_words[wo:] if root_words is not None else None,
                            out_records=root_records.view(-1)[bo * R:] if root_records is not None else None)
             if g is not None:
@@ -696,7 +695,9 @@ def main():
                 ev.record(st_main)
             if prev is not None:
                 collect(prev)                                      # host waits for batch k - 1's counts; the GPU has batch k queued
-            prev = (k, b0, nb, ev, rec, offk)
+            side.wait_event(ev)
+            ticket = xch.gather_begin(offk.data_ptr() + 8 * nb, rec, stream=side.cuda_stream)   # enqueued, no host wait
+            prev = (k, b0, nb, ticket, rec, offk)
             keep.append(rec)
         collect(prev)
         pl.synchronize()

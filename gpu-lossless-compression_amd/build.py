@@ -2,6 +2,7 @@
 gfx950 with hipcc.  No torch dependency: the library's boundary is plain pointers and sizes.
 Sources are compiled to objects in parallel (build/ is git-ignored), an object is reused while it is newer than its
 source and every header; the link step pulls in librccl for the multi-GPU exchange (csrc/exchange.cpp)."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -11,9 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INC = os.path.join(os.path.dirname(HERE), "include")
 # A/B builds: GLC_CXXFLAGS adds compiler flags (e.g. -DGLC_IMD_POS=512), GLC_LIB_OUT names the library; such a build
-# keeps its objects apart.  tests / bench pick a library with GLC_LIB (glc_binding.py).
+# keeps its objects apart, in a directory named after a hash of ITS flags: two variants never share (and so never
+# silently reuse) each other's objects.  tests / bench pick a library with GLC_LIB (glc_binding.py).
 _VARIANT = bool(os.environ.get("GLC_CXXFLAGS") or os.environ.get("GLC_LIB_OUT"))
-OBJ = os.path.join(HERE, "build_variant" if _VARIANT else "build")
+_TAG = hashlib.sha1(" ".join(os.environ.get("GLC_CXXFLAGS", "").split()).encode()).hexdigest()[:10]
+OBJ = os.path.join(HERE, "build_variant", _TAG) if _VARIANT else os.path.join(HERE, "build")
 LIB = os.environ.get("GLC_LIB_OUT") or os.path.join(HERE, "libglc_amd.so")
 SOURCES = ["cudpp_api.cpp", "bwt_sa.hip", "bwt_bucket.hip", "mtf.hip", "huffman.hip", "decode.hip", "culzss.hip",
            "culzss_api.cpp", "hd_decode.hip", "probe.hip", "exchange.cpp"]

@@ -57,14 +57,26 @@ constexpr uint32_t EMIT_SEGS    = 4;                     // segments per wave in
 //    node entry: leaf -> DEC_FLAG | symbol ; composite -> left | right << 16
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dec_prepare(const uint32_t *__restrict__ d_hist, uint32_t *__restrict__ lut,
-                                                     uint32_t *__restrict__ nodes)
+                                                     uint32_t *__restrict__ nodes, uint32_t n, uint32_t *__restrict__ d_status)
 {
     __shared__ uint32_t s_hist[257];
+    __shared__ uint32_t s_sum[4];
     __shared__ HuffTreeLds T;
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    s_hist[tid] = d_hist[(size_t)b * 256 + tid];
+    // The histogram is stream data (possibly from another process).  huff_tree_build keys its leaves as
+    // count << 9 | slot in 32 bits, i.e. it relies on count < 2^23: a histogram of n symbols has every count <= n and
+    // the counts add up to n.  Anything else is reported, and the counts are clamped to n (<= 2^20) so that the tree
+    // that is built anyway is structurally valid and nothing downstream indexes with garbage.
+    uint32_t c = d_hist[(size_t)b * 256 + tid];
+    const bool over = c > n;
+    if (over) c = n;
+    s_hist[tid] = c;
     if (tid == 0) s_hist[256] = 1;
+    uint32_t sum = c;
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     __syncthreads();
+    if (d_status && (over || (tid == 0 && s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3] != n))) atomicOr(d_status, ST_CORRUPT);
     huff_tree_build<256>(T, s_hist, tid);
     __syncthreads();
     const int head = T.head, used = 2 * T.nl - 1;
@@ -1096,7 +1108,7 @@ hipError_t decode_stage_a(hipStream_t st, const uint32_t *d_hist, const uint32_t
     const uint32_t nchunks = (n + IMTF_CHUNK - 1) / IMTF_CHUNK;
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_DEC_HUFF, st) : -1;
-    hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes);
+    hipLaunchKernelGGL(k_dec_prepare, dim3(nblk), dim3(256), 0, st, d_hist, s.lut, s.nodes, n, d_status);
     if ((uint64_t)nsub * nblk >= DL_MIN_SUBS)
         hipLaunchKernelGGL(k_dec_huff_lanes, dim3((nsub + DL_NT - 1) / DL_NT, nblk), dim3(DL_NT), 0, st, d_comp, comp_stride_words,
                            d_offsets, offset_stride, s.lut, s.nodes, n, s.mtf, (size_t)s.nmax, d_status, d_block_off);

@@ -16,14 +16,39 @@ struct glcComm_st {
     ncclComm_t comm = nullptr;
     bool owned = false;
     int nranks = 0, rank = 0;
-    unsigned long long *d_counts = nullptr;      // [2 + 2 * nranks]: mine, then everybody's
-    unsigned long long *h_counts = nullptr;      // pinned [2 * nranks]
+    // GLC_COUNT_SLOTS count exchanges may be in flight (one per batch of a pipelined encode): a slot = device
+    // [2 + 2 * nranks] (mine, then everybody's), pinned host [2 * nranks], an event behind the copy to the host
+    unsigned long long *d_counts = nullptr;
+    unsigned long long *h_counts = nullptr;
+    hipEvent_t done[GLC_COUNT_SLOTS] = {};
+    bool busy[GLC_COUNT_SLOTS] = {};
+    unsigned next = 0;
+    size_t slot_words() const { return 2 + 2 * (size_t)nranks; }
 };
 
 namespace {
 
 #define GLC_NCCL(x) do { if ((x) != ncclSuccess) return CUDPP_ERROR_UNKNOWN; } while (0)
 #define GLC_HIP(x) do { if ((x) != hipSuccess) return CUDPP_ERROR_UNKNOWN; } while (0)
+
+// A group of point-to-point operations that is ALWAYS closed: the first error is remembered, later operations are
+// skipped, ncclGroupEnd runs in any case (a group left open on this thread would swallow every later RCCL call and
+// hang the peers), and end() returns what happened.
+struct P2PGroup {
+    ncclResult_t err;
+    bool open;
+    P2PGroup() : err(ncclGroupStart()), open(err == ncclSuccess) {}
+    void send(const void *p, size_t n, int peer, ncclComm_t comm, hipStream_t st)
+    { if (open && err == ncclSuccess) err = ncclSend(p, n, ncclUint32, peer, comm, st); }
+    void recv(void *p, size_t n, int peer, ncclComm_t comm, hipStream_t st)
+    { if (open && err == ncclSuccess) err = ncclRecv(p, n, ncclUint32, peer, comm, st); }
+    CUDPPResult end()
+    {
+        if (open) { const ncclResult_t e = ncclGroupEnd(); open = false; if (err == ncclSuccess) err = e; }
+        return err == ncclSuccess ? CUDPP_SUCCESS : CUDPP_ERROR_UNKNOWN;
+    }
+    ~P2PGroup() { if (open) (void)ncclGroupEnd(); }
+};
 
 __global__ void k_pack_records(const int *__restrict__ idx, const unsigned int *__restrict__ hist,
                                const unsigned int *__restrict__ off, size_t off_stride,
@@ -62,8 +87,9 @@ CUDPPResult finish_init(glcComm_st *c)
 {
     GLC_NCCL(ncclCommCount(c->comm, &c->nranks));
     GLC_NCCL(ncclCommUserRank(c->comm, &c->rank));
-    GLC_HIP(hipMalloc((void **)&c->d_counts, sizeof(unsigned long long) * (2 + 2 * (size_t)c->nranks)));
-    GLC_HIP(hipHostMalloc((void **)&c->h_counts, sizeof(unsigned long long) * 2 * (size_t)c->nranks, hipHostMallocDefault));
+    GLC_HIP(hipMalloc((void **)&c->d_counts, sizeof(unsigned long long) * c->slot_words() * GLC_COUNT_SLOTS));
+    GLC_HIP(hipHostMalloc((void **)&c->h_counts, sizeof(unsigned long long) * 2 * (size_t)c->nranks * GLC_COUNT_SLOTS, hipHostMallocDefault));
+    for (int i = 0; i < GLC_COUNT_SLOTS; i++) GLC_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
     return CUDPP_SUCCESS;
 }
 
@@ -113,6 +139,7 @@ CUDPPResult glcCommDestroy(glcComm_t c)
     if (!c) return CUDPP_ERROR_INVALID_HANDLE;
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
+    for (int i = 0; i < GLC_COUNT_SLOTS; i++) if (c->done[i]) (void)hipEventDestroy(c->done[i]);
     if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
     delete c;
     return CUDPP_SUCCESS;
@@ -150,19 +177,55 @@ CUDPPResult glcUnpackRecords(const unsigned int *d_records, size_t nsub, size_t 
     return hipGetLastError() == hipSuccess ? CUDPP_SUCCESS : CUDPP_ERROR_UNKNOWN;
 }
 
+CUDPPResult glcGatherCountsBegin(glcComm_t c, unsigned long long numBlocks, unsigned long long numWords,
+                                 const unsigned long long *d_numWords, int *ticket, void *hipStream)
+{
+    if (!c) return CUDPP_ERROR_INVALID_HANDLE;
+    if (!ticket) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    const unsigned slot = c->next % GLC_COUNT_SLOTS;
+    if (c->busy[slot]) return CUDPP_ERROR_INSUFFICIENT_RESOURCES;      // GLC_COUNT_SLOTS exchanges begun and not ended
+    hipStream_t st = (hipStream_t)hipStream;
+    unsigned long long *d = c->d_counts + slot * c->slot_words();
+    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, st, d, numBlocks, numWords, d_numWords);
+    GLC_HIP(hipGetLastError());
+    GLC_NCCL(ncclAllGather(d, d + 2, 2, ncclUint64, c->comm, st));
+    GLC_HIP(hipMemcpyAsync(c->h_counts + slot * 2 * (size_t)c->nranks, d + 2, sizeof(unsigned long long) * 2 * (size_t)c->nranks,
+                           hipMemcpyDeviceToHost, st));
+    GLC_HIP(hipEventRecord(c->done[slot], st));
+    c->busy[slot] = true;
+    c->next++;
+    *ticket = (int)slot;
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcGatherCountsReady(glcComm_t c, int ticket, int *ready)
+{
+    if (!c) return CUDPP_ERROR_INVALID_HANDLE;
+    if (ticket < 0 || ticket >= GLC_COUNT_SLOTS || !c->busy[ticket] || !ready) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    const hipError_t e = hipEventQuery(c->done[ticket]);
+    if (e != hipSuccess && e != hipErrorNotReady) return CUDPP_ERROR_UNKNOWN;
+    *ready = e == hipSuccess;
+    return CUDPP_SUCCESS;
+}
+
+CUDPPResult glcGatherCountsEnd(glcComm_t c, int ticket, unsigned long long *h_counts)
+{
+    if (!c) return CUDPP_ERROR_INVALID_HANDLE;
+    if (ticket < 0 || ticket >= GLC_COUNT_SLOTS || !c->busy[ticket] || !h_counts) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    c->busy[ticket] = false;
+    GLC_HIP(hipEventSynchronize(c->done[ticket]));                   // waits for THIS exchange only, not for the stream
+    memcpy(h_counts, c->h_counts + (size_t)ticket * 2 * (size_t)c->nranks, sizeof(unsigned long long) * 2 * (size_t)c->nranks);
+    return CUDPP_SUCCESS;
+}
+
 CUDPPResult glcGatherCounts(glcComm_t c, unsigned long long numBlocks, unsigned long long numWords,
                             const unsigned long long *d_numWords, unsigned long long *h_counts, void *hipStream)
 {
     if (!c) return CUDPP_ERROR_INVALID_HANDLE;
     if (!h_counts) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
-    hipStream_t st = (hipStream_t)hipStream;
-    hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, st, c->d_counts, numBlocks, numWords, d_numWords);
-    GLC_NCCL(ncclAllGather(c->d_counts, c->d_counts + 2, 2, ncclUint64, c->comm, st));
-    GLC_HIP(hipMemcpyAsync(c->h_counts, c->d_counts + 2, sizeof(unsigned long long) * 2 * (size_t)c->nranks,
-                           hipMemcpyDeviceToHost, st));
-    GLC_HIP(hipStreamSynchronize(st));
-    memcpy(h_counts, c->h_counts, sizeof(unsigned long long) * 2 * (size_t)c->nranks);
-    return CUDPP_SUCCESS;
+    int ticket = -1;
+    const CUDPPResult r = glcGatherCountsBegin(c, numBlocks, numWords, d_numWords, &ticket, hipStream);
+    return r != CUDPP_SUCCESS ? r : glcGatherCountsEnd(c, ticket, h_counts);
 }
 
 CUDPPResult glcGatherStreams(glcComm_t c, int root, const unsigned int *d_words, const unsigned int *d_records,
@@ -175,24 +238,26 @@ CUDPPResult glcGatherStreams(glcComm_t c, int root, const unsigned int *d_words,
     const unsigned long long myb = h_counts[2 * c->rank], myw = h_counts[2 * c->rank + 1];
     if ((myb && !d_records) || (myw && !d_words)) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     if (c->rank != root) {
-        GLC_NCCL(ncclGroupStart());
-        if (myb) GLC_NCCL(ncclSend(d_records, (size_t)myb * recordWords, ncclUint32, root, c->comm, st));
-        if (myw) GLC_NCCL(ncclSend(d_words, (size_t)myw, ncclUint32, root, c->comm, st));
-        GLC_NCCL(ncclGroupEnd());
-        return CUDPP_SUCCESS;
+        P2PGroup g;
+        if (myb) g.send(d_records, (size_t)myb * recordWords, root, c->comm, st);
+        if (myw) g.send(d_words, (size_t)myw, root, c->comm, st);
+        return g.end();
     }
     if (!d_allWords || !d_allRecords) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     unsigned long long wo = 0, bo = 0;
-    GLC_NCCL(ncclGroupStart());
-    for (int r = 0; r < c->nranks; r++) {
-        const unsigned long long nb = h_counts[2 * r], nw = h_counts[2 * r + 1];
-        if (r != root) {
-            if (nb) GLC_NCCL(ncclRecv(d_allRecords + bo * recordWords, (size_t)nb * recordWords, ncclUint32, r, c->comm, st));
-            if (nw) GLC_NCCL(ncclRecv(d_allWords + wo, (size_t)nw, ncclUint32, r, c->comm, st));
+    {
+        P2PGroup g;
+        for (int r = 0; r < c->nranks; r++) {
+            const unsigned long long nb = h_counts[2 * r], nw = h_counts[2 * r + 1];
+            if (r != root) {
+                if (nb) g.recv(d_allRecords + bo * recordWords, (size_t)nb * recordWords, r, c->comm, st);
+                if (nw) g.recv(d_allWords + wo, (size_t)nw, r, c->comm, st);
+            }
+            wo += nw; bo += nb;
         }
-        wo += nw; bo += nb;
+        const CUDPPResult gr = g.end();
+        if (gr != CUDPP_SUCCESS) return gr;
     }
-    GLC_NCCL(ncclGroupEnd());
     wo = 0; bo = 0;
     for (int r = 0; r < root; r++) { bo += h_counts[2 * r]; wo += h_counts[2 * r + 1]; }
     if (myb && d_allRecords + bo * recordWords != d_records)
@@ -212,24 +277,26 @@ CUDPPResult glcScatterStreams(glcComm_t c, int root, const unsigned int *d_allWo
     const unsigned long long myb = h_counts[2 * c->rank], myw = h_counts[2 * c->rank + 1];
     if ((myb && !d_records) || (myw && !d_words)) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     if (c->rank != root) {
-        GLC_NCCL(ncclGroupStart());
-        if (myb) GLC_NCCL(ncclRecv(d_records, (size_t)myb * recordWords, ncclUint32, root, c->comm, st));
-        if (myw) GLC_NCCL(ncclRecv(d_words, (size_t)myw, ncclUint32, root, c->comm, st));
-        GLC_NCCL(ncclGroupEnd());
-        return CUDPP_SUCCESS;
+        P2PGroup g;
+        if (myb) g.recv(d_records, (size_t)myb * recordWords, root, c->comm, st);
+        if (myw) g.recv(d_words, (size_t)myw, root, c->comm, st);
+        return g.end();
     }
     if (!d_allWords || !d_allRecords) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     unsigned long long wo = 0, bo = 0, mywo = 0, mybo = 0;
-    GLC_NCCL(ncclGroupStart());
-    for (int r = 0; r < c->nranks; r++) {
-        const unsigned long long nb = h_counts[2 * r], nw = h_counts[2 * r + 1];
-        if (r != root) {
-            if (nb) GLC_NCCL(ncclSend(d_allRecords + bo * recordWords, (size_t)nb * recordWords, ncclUint32, r, c->comm, st));
-            if (nw) GLC_NCCL(ncclSend(d_allWords + wo, (size_t)nw, ncclUint32, r, c->comm, st));
-        } else { mywo = wo; mybo = bo; }
-        wo += nw; bo += nb;
+    {
+        P2PGroup g;
+        for (int r = 0; r < c->nranks; r++) {
+            const unsigned long long nb = h_counts[2 * r], nw = h_counts[2 * r + 1];
+            if (r != root) {
+                if (nb) g.send(d_allRecords + bo * recordWords, (size_t)nb * recordWords, r, c->comm, st);
+                if (nw) g.send(d_allWords + wo, (size_t)nw, r, c->comm, st);
+            } else { mywo = wo; mybo = bo; }
+            wo += nw; bo += nb;
+        }
+        const CUDPPResult gr = g.end();
+        if (gr != CUDPP_SUCCESS) return gr;
     }
-    GLC_NCCL(ncclGroupEnd());
     if (myb && d_records != d_allRecords + mybo * recordWords)
         GLC_HIP(hipMemcpyAsync(d_records, d_allRecords + mybo * recordWords, (size_t)myb * recordWords * 4, hipMemcpyDeviceToDevice, st));
     if (myw && d_words != d_allWords + mywo)

@@ -195,14 +195,23 @@ class RcclExchange:
                                         rec.data_ptr(), stream), "glcPackRecords")
         return rec
 
-    def gather(self, compact, nwords_dev, records, dst=0, stream=None, out_words=None, out_records=None):
+    def gather_begin(self, nwords_dev, records, stream=None):
+        """first half of gather(): ENQUEUES the count exchange of a batch (glcGatherCountsBegin: all-gather + copy to pinned
+        memory + event) and returns a ticket; the host does not wait."""
+        t = C.c_int(-1)
+        self._chk(self.L.glcGatherCountsBegin(self.comm, int(records.shape[0]), 0, nwords_dev, C.byref(t), stream), "glcGatherCountsBegin")
+        return t.value
+
+    def gather(self, compact, nwords_dev, records, dst=0, stream=None, out_words=None, out_records=None, ticket=None):
         """compact: int32 tensor holding this rank's streams back to back from its start; nwords_dev: device pointer to
         their word count (the last offset glcCompactStreams wrote); records: int32 [nblk, R].  On dst returns the
         gather_blocks dict (buffers / records are views of two rank-ordered arrays), None elsewhere.  Waits once (the
-        counts); the transfers are only enqueued on `stream`."""
+        counts -- for the exchange a gather_begin ticket names, if one is given); the transfers are only enqueued on `stream`."""
         torch = self.torch
         nblk, R = int(records.shape[0]), int(records.shape[1])
-        self._chk(self.L.glcGatherCounts(self.comm, nblk, 0, nwords_dev, self.counts, stream), "glcGatherCounts")
+        if ticket is None:
+            ticket = self.gather_begin(nwords_dev, records, stream)
+        self._chk(self.L.glcGatherCountsEnd(self.comm, ticket, self.counts), "glcGatherCountsEnd")
         nblks = [int(self.counts[2 * r]) for r in range(self.world)]
         words = [int(self.counts[2 * r + 1]) for r in range(self.world)]
         allw = allr = None

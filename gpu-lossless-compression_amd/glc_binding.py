@@ -51,7 +51,8 @@ CULZSS_SYMBOLS = [
     "culzss_compress_file", "culzss_decompress_file", "glcLzssEnableProfile", "glcLzssKernelProfile",
 ]
 EXCHANGE_SYMBOLS = ["glcCommGetUniqueId", "glcCommInitRank", "glcCommAdopt", "glcCommDestroy", "glcCommInfo", "glcPackRecords",
-                    "glcUnpackRecords", "glcGatherCounts", "glcGatherStreams", "glcScatterStreams"]
+                    "glcUnpackRecords", "glcGatherCounts", "glcGatherCountsBegin", "glcGatherCountsReady", "glcGatherCountsEnd",
+                    "glcGatherStreams", "glcScatterStreams"]
 HD_SYMBOLS = ["glcHdBuildTable", "glcHdEncodeHost", "glcHdWorkBytes", "glcHdDecodeDevice", "glcHdDecodeDeviceTable", "glcHdDecodeDeviceTableOnDevice", "glcHdEnableProfile",
               "glcHdKernelProfile"]
 
@@ -191,6 +192,9 @@ def lib():
         L.glcPackRecords.argtypes = [vp, vp, vp, sz, vp, sz, sz, vp, vp]
         L.glcUnpackRecords.argtypes = [vp, sz, sz, vp, vp, vp, sz, vp, vp]
         L.glcGatherCounts.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, vp, ullp, vp]
+        L.glcGatherCountsBegin.argtypes = [vp, C.c_ulonglong, C.c_ulonglong, vp, C.POINTER(C.c_int), vp]
+        L.glcGatherCountsReady.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+        L.glcGatherCountsEnd.argtypes = [vp, C.c_int, ullp]
         L.glcGatherStreams.argtypes = [vp, C.c_int, vp, vp, sz, ullp, vp, vp, vp]
         L.glcScatterStreams.argtypes = [vp, C.c_int, vp, vp, sz, ullp, vp, vp, vp]
         for name in EXCHANGE_SYMBOLS:

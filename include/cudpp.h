@@ -165,7 +165,12 @@ CUDPPResult glcCompressBatch(CUDPPHandle planHandle, const unsigned char *d_unco
  * d_blockOffsets[b + 1] - d_blockOffsets[b]).  The first block starts at *d_startOffset (a DEVICE value, read in
  * stream order; NULL = 0): pass the previous batch's d_blockOffsets + numBlocks and a sequence of batches fills one
  * contiguous array with no host involvement -- the layout glcCompactStreams produces from the strided one, without
- * the copy pass.  capacityWords = size of the d_compact array; streams that would pass it are not written and
+ * the copy pass.  ORDERING: the start offset is read by work queued on THIS plan (its stream, or its internal stream
+ * when stage pipelining is on), so chaining is ordered only between batches that go through the SAME plan; a batch
+ * whose start offset was written by ANOTHER plan (or host thread) must be queued after glcPlanSynchronize of that
+ * plan (or after an event the caller records behind it once it has been synchronised).  With glcPlanSetPipelining on,
+ * d_blockOffsets, d_compressedSize and d_compact are complete only after glcPlanSynchronize, as for every output of a
+ * pipelined plan.  capacityWords = size of the d_compact array; streams that would pass it are not written and
  * glcPlanSynchronize reports CUDPP_ERROR_UNKNOWN.  Everything else as glcCompressBatch. */
 CUDPPResult glcCompressBatchCompact(CUDPPHandle planHandle, const unsigned char *d_uncompressed,
                                     int *d_bwtIndex, unsigned int *d_hist, unsigned int *d_encodeOffset,

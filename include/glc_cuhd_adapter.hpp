@@ -11,8 +11,12 @@
 //     cuhd::CUHDGPUDecoder::decode(in, n_units, out, n_sym, table, aux, 11, 4, 128);      // reference
 //     glc::cuhd::CUHDGPUDecoder::decode(in, n_units, out, n_sym, table, aux, 11, 4, 128); // here
 //
-// Differences, deliberate: `aux` (the reference's synchronisation scratch, cuhd_gpu_decoder_memory.h) may be any type --
-// a null pointer of `DecoderMemory` below makes the adapter allocate and cache its own work buffer; the subsequence
+// Differences, deliberate: `aux` (the reference's synchronisation scratch, cuhd_gpu_decoder_memory.h) may be any type.
+// A `std::shared_ptr<glc::cuhd::DecoderMemory>` IS the work buffer of the decode (one per decoder object, as the
+// reference holds its CUHDGPUDecoderMemory; the caller then owns the rule "one decode in flight per DecoderMemory").
+// Any other type (or a null pointer) makes the adapter keep its own work buffers, ONE PER (calling thread, stream):
+// two decodes enqueued from one thread on different streams never share scratch, and decodes on the same stream are
+// ordered by the stream.  A buffer that has to grow waits for its stream before the old allocation is freed.  The subsequence
 // size and threads-per-block hints are accepted and ignored (the span functions of hd_decode.hip need no
 // self-synchronisation rounds, so there is nothing to tune and no device->host flag copy per round,
 // cuhd_gpu_decoder.cu:459-495); codewords longer than 11 bits are refused, as the reference's table format does.
@@ -20,6 +24,8 @@
 #include <cstddef>
 #include <memory>
 #include <stdexcept>
+#include <type_traits>
+#include <unordered_map>
 #include <hip/hip_runtime.h>
 #include "glc_hd.h"
 
@@ -32,11 +38,15 @@ class DecoderMemory {
     DecoderMemory(const DecoderMemory &) = delete;
     DecoderMemory &operator=(const DecoderMemory &) = delete;
     ~DecoderMemory() { if (ptr_) (void)hipFree(ptr_); }
-    void *reserve(std::size_t units)
+    // `stream`: where the decodes that used this buffer were enqueued; waited for before a smaller buffer is released
+    void *reserve(std::size_t units, hipStream_t stream = nullptr)
     {
         const std::size_t need = glcHdWorkBytes(units);
         if (need > bytes_) {
-            if (ptr_) (void)hipFree(ptr_);
+            if (ptr_) {
+                if (hipStreamSynchronize(stream) != hipSuccess) throw std::runtime_error("glc::cuhd::DecoderMemory: hipStreamSynchronize failed");
+                (void)hipFree(ptr_);
+            }
             ptr_ = nullptr; bytes_ = 0;
             if (hipMalloc(&ptr_, need) != hipSuccess) throw std::runtime_error("glc::cuhd::DecoderMemory: hipMalloc failed");
             bytes_ = need;
@@ -52,14 +62,20 @@ class CUHDGPUDecoder {
   public:
     template <class InputBuffer, class OutputBuffer, class Codetable, class Aux>
     static void decode(std::shared_ptr<InputBuffer> input, std::size_t input_size, std::shared_ptr<OutputBuffer> output,
-                       std::size_t output_size, std::shared_ptr<Codetable> table, std::shared_ptr<Aux> /*aux*/,
+                       std::size_t output_size, std::shared_ptr<Codetable> table, std::shared_ptr<Aux> aux,
                        std::size_t max_codeword_length, std::size_t /*preferred_subsequence_size*/,
                        std::size_t /*threads_per_block*/, hipStream_t stream = nullptr)
     {
         if (!input || !output || !table) throw std::invalid_argument("glc::cuhd::CUHDGPUDecoder::decode: null buffer");
         if (max_codeword_length > GLC_HD_MAX_LEN) throw std::invalid_argument("glc::cuhd::CUHDGPUDecoder::decode: codewords longer than 11 bits");
-        static thread_local DecoderMemory work;                // one per calling thread, grown on demand
-        void *w = work.reserve(input_size);
+        void *w = nullptr;
+        if constexpr (std::is_same<Aux, DecoderMemory>::value) {
+            if (aux) w = aux->reserve(input_size, stream);     // the caller's decoder memory, as in the reference
+        }
+        if (!w) {
+            static thread_local std::unordered_map<hipStream_t, DecoderMemory> work;   // one per (thread, stream)
+            w = work[stream].reserve(input_size, stream);
+        }
         const int ok = glcHdDecodeDeviceTableOnDevice(reinterpret_cast<const unsigned int *>(input->get()), input_size,
                                                       reinterpret_cast<const unsigned char *>(table->get()),
                                                       reinterpret_cast<unsigned char *>(output->get()), output_size, w, stream);

@@ -9,7 +9,8 @@
  * Result collection on a root rank, and its mirror for decoding:
  *
  *   glcGatherCounts    all-gather of {blocks, words} of every rank (16 bytes each; one ncclAllGather), read back
- *                      to the host -- the only host wait of the exchange;
+ *                      to the host -- the only host wait of the exchange, and glcGatherCountsBegin / ...End move
+ *                      it behind the queueing of the next batch;
  *   glcGatherStreams   gather-v of the per-block RECORDS and of the compacted word streams with grouped
  *                      point-to-point operations: ONE ncclGroup of ncclRecv on the root, one of ncclSend on every
  *                      other rank -- exact lengths, no padding to the largest rank, and on xGMI (point-to-point
@@ -38,6 +39,7 @@ extern "C" {
 typedef struct glcComm_st *glcComm_t;
 #define GLC_UNIQUE_ID_BYTES 128        /* = NCCL_UNIQUE_ID_BYTES */
 #define GLC_RECORD_FIXED_WORDS 258     /* compressedSize, bwtIndex, hist[256]; encodeOffset[nsub] follows */
+#define GLC_COUNT_SLOTS 4              /* count exchanges that may be begun and not yet ended, per communicator */
 
 /* Communicator.  Rank 0 calls glcCommGetUniqueId and hands the 128 bytes to the other ranks by whatever means the
  * application has (MPI, a socket, torch.distributed); every rank then calls glcCommInitRank with the GPU it
@@ -59,9 +61,20 @@ CUDPPResult glcUnpackRecords(const unsigned int *d_records, size_t nsub, size_t 
 
 /* h_counts[2 r] = blocks, h_counts[2 r + 1] = words of rank r (host array of 2 * nranks entries).  d_numWords: a
  * device word count (e.g. the last entry of glcCompactStreams' offsets) or NULL with the count in numWords.
- * Waits for the stream: the counts size the point-to-point operations that follow. */
+ * Waits for the exchange (not for the rest of the stream): the counts size the point-to-point operations that
+ * follow.  = glcGatherCountsBegin + glcGatherCountsEnd. */
 CUDPPResult glcGatherCounts(glcComm_t comm, unsigned long long numBlocks, unsigned long long numWords,
                             const unsigned long long *d_numWords, unsigned long long *h_counts, void *hipStream);
+
+/* The same in two halves, so that the encoding thread never waits: Begin ENQUEUES the count exchange of a batch on
+ * the stream (set counts, ncclAllGather, copy to pinned host memory, an event) and returns a ticket; the caller goes on
+ * queueing the next batch; End waits for that ticket's event only and hands out the counts (Ready polls instead).
+ * Up to GLC_COUNT_SLOTS tickets may be outstanding per communicator (Begin returns
+ * CUDPP_ERROR_INSUFFICIENT_RESOURCES beyond that); every rank must Begin its exchanges in the same order. */
+CUDPPResult glcGatherCountsBegin(glcComm_t comm, unsigned long long numBlocks, unsigned long long numWords,
+                                 const unsigned long long *d_numWords, int *ticket, void *hipStream);
+CUDPPResult glcGatherCountsReady(glcComm_t comm, int ticket, int *ready);
+CUDPPResult glcGatherCountsEnd(glcComm_t comm, int ticket, unsigned long long *h_counts);
 
 /* Every rank: d_words (its compacted streams, h_counts[2 rank + 1] words) and d_records (h_counts[2 rank] records).
  * Root only: d_allWords / d_allRecords receive the ranks' data back to back in rank order (rank r's words start at

@@ -50,7 +50,25 @@ int main(int argc, char **argv)
     if (hipDeviceSynchronize() != hipSuccess) { printf("device error\n"); return 1; }
     std::vector<uint8_t> got(nsym);
     (void)hipMemcpy(got.data(), out->get(), nsym, hipMemcpyDeviceToHost);
-    const bool ok = memcmp(got.data(), want.data(), nsym) == 0;
+    bool ok = memcmp(got.data(), want.data(), nsym) == 0;
+    // two decodes in flight from ONE thread on two streams (each gets its own scratch), and one with the caller's own
+    // DecoderMemory as `aux`, the way the reference passes its CUHDGPUDecoderMemory
+    hipStream_t st[2];
+    std::shared_ptr<DeviceBuffer<uint8_t>> outs[3];
+    for (int i = 0; i < 3; i++) { outs[i] = std::make_shared<DeviceBuffer<uint8_t>>(nsym); (void)hipMemset(outs[i]->get(), 0, nsym); }
+    for (int i = 0; i < 2; i++) if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) { printf("stream\n"); return 1; }
+    (void)hipDeviceSynchronize();
+    for (int rep = 0; rep < 4; rep++)
+        for (int i = 0; i < 2; i++)
+            glc::cuhd::CUHDGPUDecoder::decode(in, nunits, outs[i], nsym, tab, aux, 11, 4, 128, st[i]);
+    auto mine = std::make_shared<glc::cuhd::DecoderMemory>();
+    glc::cuhd::CUHDGPUDecoder::decode(in, nunits, outs[2], nsym, tab, mine, 11, 4, 128);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("device error\n"); return 1; }
+    for (int i = 0; i < 3; i++) {
+        (void)hipMemcpy(got.data(), outs[i]->get(), nsym, hipMemcpyDeviceToHost);
+        ok = ok && memcmp(got.data(), want.data(), nsym) == 0;
+    }
+    for (int i = 0; i < 2; i++) (void)hipStreamDestroy(st[i]);
     printf("units=%zu symbols=%zu decoded_equals_original=%d\n", nunits, nsym, ok ? 1 : 0);
     return ok ? 0 : 1;
 }

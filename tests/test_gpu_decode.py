@@ -126,9 +126,13 @@ def test_corrupt_stream_is_reported_not_followed(glc, cuda):
     with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=1) as plan:
         comp = glc.compress_batch(plan, torch.from_numpy(x).cuda(), n, 1)
         plan.synchronize()
-        for what in ("index", "offset", "length"):
+        for what in ("index", "offset", "length", "hist_wrap", "hist_sum"):
             bad = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in comp.items()}
-            if what == "index":
+            if what == "hist_wrap":
+                bad["hist"][5] = 1 << 23                           # would wrap the tree builder's count << 9 | slot key
+            elif what == "hist_sum":
+                bad["hist"][7] += 3                                # counts that do not add up to n
+            elif what == "index":
                 bad["bwt_index"][0] = n + 12345
             elif what == "offset":
                 bad["offsets"][3] = 0x7FFFFFF0

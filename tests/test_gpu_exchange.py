@@ -94,3 +94,40 @@ def test_expand_streams_refuses_offsets_that_do_not_ascend(glc, cuda):
         s = sizes.cpu().numpy()
         assert s[0] == 400 and s[1] == 0, s
         assert torch.equal(strided[:400], words[:400]) and int(strided[stride].item()) == -1
+
+
+def test_count_exchange_tickets(glc, cuda):
+    """glcGatherCountsBegin / Ready / End: the count exchange of a batch is enqueued without a host wait; up to
+    GLC_COUNT_SLOTS tickets outstanding, each ended on its own event, in any order"""
+    import torch
+    ex = _dist_mod()
+    L = glc.lib()
+    xch = ex.RcclExchange(glc, torch, None)
+    side = torch.cuda.Stream(cuda)
+    nw = torch.tensor([111, 222, 333, 444, 555], dtype=torch.int64, device=cuda)
+    torch.cuda.synchronize()
+    tickets = []
+    for i in range(4):
+        t = C.c_int(-1)
+        assert L.glcGatherCountsBegin(xch.comm, 10 + i, 0, nw.data_ptr() + 8 * i, C.byref(t), side.cuda_stream) == 0
+        tickets.append(t.value)
+    t = C.c_int(-1)
+    assert L.glcGatherCountsBegin(xch.comm, 1, 1, None, C.byref(t), side.cuda_stream) == glc.CUDPP_ERROR_INSUFFICIENT_RESOURCES
+    assert sorted(tickets) == [0, 1, 2, 3]
+    cnt = (C.c_ulonglong * 2)()
+    for i in (2, 0, 3, 1):
+        assert L.glcGatherCountsEnd(xch.comm, tickets[i], cnt) == 0
+        assert (cnt[0], cnt[1]) == (10 + i, 111 * (i + 1))
+        assert L.glcGatherCountsEnd(xch.comm, tickets[i], cnt) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION   # ended already
+    # a host count instead of a device one, polled
+    assert L.glcGatherCountsBegin(xch.comm, 7, 99, None, C.byref(t), side.cuda_stream) == 0
+    ready = C.c_int(0)
+    for _ in range(100000):
+        assert L.glcGatherCountsReady(xch.comm, t.value, C.byref(ready)) == 0
+        if ready.value:
+            break
+    assert ready.value == 1
+    assert L.glcGatherCountsEnd(xch.comm, t.value, cnt) == 0 and (cnt[0], cnt[1]) == (7, 99)
+    assert L.glcGatherCountsReady(xch.comm, 9, C.byref(ready)) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
+    xch.close()
+
