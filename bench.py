@@ -38,6 +38,7 @@ PKG = os.path.join(ROOT, "gpu-lossless-compression_amd")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MiB = 1 << 20
+_GLC = None                     # the ctypes binding (set in main / by tools that import this file before they generate data)
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -58,6 +59,53 @@ ALG_BYTES = {"k_fs_part": 9.0, "k_fs_sort": 9.0, "k_fs_hist": 1.0, "k_mtf_encode
              "k_rs_onesweep<8,false>": 16.0}
 
 
+def load_census():
+    """profiles/isa_census.json (tools/isa_census.py): static share of the 2-cycle VALU class per kernel"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "isa_census.json")))["kernels"]
+    except Exception:
+        return {}
+
+
+def issue_fractions(name, pmc_per64, census, issue, per_launch_units, avg_ms):
+    """instruction-issue and LDS fractions of a launch: wave64 instruction counts per 64 input bytes from the committed PMC
+    passes; VALU cycles per instruction by class (2.1 for plain add / sub / logic / shift right / mov, 4.0 for the rest:
+    tools/probes/valu_rate_probe), the class shares from the static census of the kernel's ISA; the scalar unit issues one
+    instruction per cycle per CU; LDS busy = SQ_LDS_IDX_ACTIVE cycles / CU cycles where the PMC summary has it"""
+    pk, fast, nfast = None, 0.0, 0.0
+    for key in name.split("+"):
+        q = pmc_per64.get(key)
+        if q:
+            pk = q if pk is None else {c: pk.get(c, 0) + q.get(c, 0) for c in set(pk) | set(q) if isinstance(q.get(c, 0), (int, float))}
+            cz = census.get(key) or next((v for k2, v in census.items() if k2.split("<")[0] == key), None)
+            f = cz["valu_fast_frac"] if cz and cz.get("valu_fast_frac") is not None else 0.0
+            fast += f * q.get("SQ_INSTS_VALU", 0.0)
+            nfast += q.get("SQ_INSTS_VALU", 0.0)
+    if not pk or avg_ms <= 0 or not pk.get("SQ_INSTS_VALU"):
+        return {}
+    f = fast / nfast if nfast else 0.0
+    cu_cycles = 256 * issue["clock_GHz"] * 1e9 * (avg_ms * 1e-3)
+    n64 = per_launch_units / 64.0
+    cyc = f * issue["fast_class_cycles_per_inst"] + (1.0 - f) * issue["slow_class_cycles_per_inst"]
+    out = {"valu_issue_frac": round(n64 * pk["SQ_INSTS_VALU"] * cyc / (4 * cu_cycles), 3), "valu_fast_class_share": round(f, 3),
+           "salu_issue_frac": round(n64 * pk.get("SQ_INSTS_SALU", 0.0) / cu_cycles, 3),
+           "instructions_per_64_bytes": {"valu": round(pk["SQ_INSTS_VALU"], 1), "salu": round(pk.get("SQ_INSTS_SALU", 0), 1),
+                                         "lds": round(pk.get("SQ_INSTS_LDS", 0), 1)}}
+    if pk.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_busy_frac"] = round(n64 * pk["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 3)
+    return out
+
+
+def bound_of(e):
+    """what holds a kernel, from the evidence in its table entry: the busiest unit, 'latency' when none is busy"""
+    cand = {"hbm": e.get("hbm_busy_frac") or 0.0, "valu-issue": e.get("valu_issue_frac") or 0.0,
+            "salu-issue": e.get("salu_issue_frac") or 0.0, "lds": e.get("lds_busy_frac") or 0.0}
+    if not any(cand.values()):
+        return None
+    top = max(cand, key=cand.get)
+    return top if cand[top] >= 0.6 else "latency (busiest unit: %s %.2f)" % (top, cand[top])
+
+
 def _load(name, path):
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
@@ -66,10 +114,11 @@ def _load(name, path):
     return mod
 
 
-def kernel_table(getter, alg_bytes, pmc_per64, issue, traffic_tab=None, blocks_in_traffic=256.0, unit_bytes=float(MiB)):
+def kernel_table(getter, alg_bytes, pmc_per64, issue, traffic_tab=None, blocks_in_traffic=256.0, unit_bytes=float(MiB), census=None, rho=None):
     """getter(i) -> (name, ms, launches, units) or None past the last slot.  Per kernel: average launch time (hipEvent pairs on
-    the launch stream), algorithmic bytes per launch and the HBM fraction they give, instruction-issue fractions where
-    the committed PMC summary has the kernel, HBM traffic per launch where profiles/pmc_traffic.json has it."""
+    the launch stream), SURVEY.md 8(d)'s fraction ((1 + rho) algorithmic bytes per unit where rho is given), the kernel's own
+    design traffic and the HBM fraction it gives, issue / LDS fractions where the committed PMC summary has the kernel, HBM
+    traffic per launch where profiles/pmc_traffic.json has it, and the bound those figures name."""
     tab, i = {}, 0
     while True:
         r = getter(i)
@@ -83,25 +132,20 @@ def kernel_table(getter, alg_bytes, pmc_per64, issue, traffic_tab=None, blocks_i
         per_launch = units / launches
         ab = alg_bytes.get(name)
         ach = per_launch * ab / (avg * 1e-3) / 1e9 if (ab and avg > 0) else None
-        e = {"avg_launch_ms": round(avg, 4), "launches": int(launches), "alg_bytes_per_input_byte": ab,
-             "algorithmic_bytes_per_launch": round(per_launch * ab, 1) if ab else None,
-             "achieved_GBps": round(ach, 1) if ach else None, "hbm_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
-        pk = None
-        for key in name.split("+"):
-            if key in pmc_per64:
-                q = pmc_per64[key]
-                pk = q if pk is None else {c: pk.get(c, 0) + q.get(c, 0) for c in set(pk) | set(q) if isinstance(q.get(c, 0), (int, float))}
-        if pk and avg > 0 and pk.get("SQ_INSTS_VALU"):
-            simd_cycles = 1024 * issue["clock_GHz"] * 1e9 * (avg * 1e-3)
-            n64 = per_launch / 64.0
-            e["valu_issue_frac"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["slow_class_cycles_per_inst"] / simd_cycles, 3)
-            e["salu_issue_frac"] = round(n64 * pk.get("SQ_INSTS_SALU", 0.0) / (simd_cycles / 4), 3)
-            e["instructions_per_64_bytes"] = {"valu": round(pk["SQ_INSTS_VALU"], 1), "salu": round(pk.get("SQ_INSTS_SALU", 0), 1),
-                                              "lds": round(pk.get("SQ_INSTS_LDS", 0), 1)}
+        e = {"avg_launch_ms": round(avg, 4), "launches": int(launches), "input_bytes_per_launch": int(per_launch),
+             "design_bytes_per_input_byte": round(ab, 3) if ab else None,
+             "design_GBps": round(ach, 1) if ach else None, "kernel_design_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
+        if rho is not None and avg > 0:
+            e["frac_8d"] = round(per_launch * (1.0 + rho) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         if traffic_tab:
             t = sum(traffic_tab.get(key, 0) for key in name.split("+"))
-            if t:
-                e["traffic"] = int(round(t * (per_launch / unit_bytes) / blocks_in_traffic))
+            if t and avg > 0:
+                tb = t * (per_launch / unit_bytes) / blocks_in_traffic
+                e["traffic"] = int(round(tb))
+                e["hbm_busy_frac"] = round(tb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3)
+        if pmc_per64:
+            e.update(issue_fractions(name, pmc_per64, census or {}, issue, per_launch, avg))
+        e["bound"] = bound_of(e)
         tab[name] = e
     return tab
 
@@ -112,9 +156,11 @@ def roofline_of(tab, note):
         return None
     dom = max(tab, key=lambda k: tab[k]["avg_launch_ms"] * tab[k]["launches"])
     d = tab[dom]
-    return {"kernel": "glc::" + dom, "bound": "hbm", "achieved": d.get("achieved_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": d.get("hbm_frac"), "traffic": d.get("traffic"), "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
-            "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"), "valu_issue_frac": d.get("valu_issue_frac"),
+    frac = d.get("frac_8d") if d.get("frac_8d") is not None else d.get("kernel_design_frac")
+    return {"kernel": "glc::" + dom, "bound": d.get("bound"), "achieved": round(frac * HBM_PEAK_GBPS, 1) if frac else None,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac, "traffic": d.get("traffic"), "avg_launch_ms": d["avg_launch_ms"],
+            "launches": d["launches"], "kernel_design_frac": d.get("kernel_design_frac"), "hbm_busy_frac": d.get("hbm_busy_frac"),
+            "valu_issue_frac": d.get("valu_issue_frac"), "salu_issue_frac": d.get("salu_issue_frac"), "lds_busy_frac": d.get("lds_busy_frac"),
             "timing": "hipEvent pairs on the launch stream around every launch", "note": note}
 
 
@@ -127,17 +173,85 @@ def load_traffic():
 
 
 def zipf_blocks_on_device(torch, dev, nblocks, first_global_block, stride_blocks, seed=0x5EED0002):
-    """Zipf(1.0) bytes over 256 symbols, identity symbol permutation.  Block g of the global stream is generated
-    from seed+g so any rank / any N produces the same bytes."""
+    """configs[1] as SURVEY.md 8(d) defines it: Zipf(1.0) bytes over 256 symbols, identity symbol permutation, from a
+    counter-based Philox4x32-10 stream (key = seed, counter = byte index / 4): global block g is bytes [g MiB, (g + 1) MiB)
+    of that stream whatever the rank or N, reproducible on the host (tests/datagen.zipf_philox_bytes) and on the
+    device (glcGenZipfPhilox, csrc/probe.hip)."""
+    import numpy as np
+    import datagen
+    L = (_GLC or sys.modules.get("glc_binding") or _load("glc_binding", os.path.join(PKG, "glc_binding.py"))).lib()
     out = torch.empty(nblocks * MiB, dtype=torch.uint8, device=dev)
-    p = 1.0 / torch.arange(1, 257, dtype=torch.float64)
-    cdf = torch.cumsum(p / p.sum(), 0).to(torch.float32).to(dev)
+    thr = torch.from_numpy(datagen.zipf_thresholds().view(np.int32)).to(dev)
+    if stride_blocks == 1:
+        ok = L.glcGenZipfPhilox(out.data_ptr(), nblocks * MiB, first_global_block * MiB, seed, thr.data_ptr(), None)
+        assert ok == 1
+    else:
+        for i in range(nblocks):
+            assert L.glcGenZipfPhilox(out.data_ptr() + i * MiB, MiB, (first_global_block + i * stride_blocks) * MiB, seed,
+                                      thr.data_ptr(), None) == 1
+    torch.cuda.synchronize(dev)
+    return out
+
+
+def log_buffers_on_device(torch, dev, nbuf, seed=0x5EED0003, chunk=64):
+    """configs[2] as SURVEY.md 8(d) defines it: `nbuf` DISTINCT 1 MiB buffers of log-style ASCII lines
+    `YYYY-MM-DDThh:mm:ss.mmmZ host-HH svc-NAME[PID]: LEVEL message k=K v=V` (the line shape of tests/datagen.log_bytes),
+    every buffer from its own seed, built on the device with vectorised torch ops: a [lines, 96] matrix of left-aligned
+    fields with 0 for "no character", flattened and squeezed.  4096 buffers take a few seconds."""
+    W, LINES = 96, 16384                                      # shortest line 66 bytes: 16384 lines always fill 1 MiB
+
+    def table(words):
+        t = torch.zeros((len(words), max(len(w) for w in words)), dtype=torch.uint8)
+        for i, w in enumerate(words):
+            t[i, :len(w)] = torch.tensor(list(w), dtype=torch.uint8)
+        return t.to(dev)
+    svcs = table([b"auth", b"db", b"cache", b"api", b"queue", b"sched"])
+    levels = table([b"INFO", b"WARN", b"DEBUG", b"ERROR"])
+    msgs = table([b"request completed", b"connection reset by peer", b"cache miss for key", b"retrying operation",
+                  b"user login ok", b"slow query detected", b"heartbeat", b"flushed buffers"])
+    pow10 = torch.tensor([1, 10, 100, 1000, 10000, 100000], dtype=torch.int64, device=dev)
+    out = torch.empty(nbuf * MiB, dtype=torch.uint8, device=dev)
     gen = torch.Generator(device=dev)
-    for i in range(nblocks):
-        g = first_global_block + i * stride_blocks
-        gen.manual_seed(seed + g)
-        u = torch.rand(MiB, generator=gen, device=dev)
-        out[i * MiB:(i + 1) * MiB] = torch.searchsorted(cdf, u).clamp_(max=255).to(torch.uint8)
+
+    def fixed(x, ndig):                                       # zero-padded decimal, ndig columns
+        cols = [((x // int(10 ** (ndig - 1 - j))) % 10 + 48) for j in range(ndig)]
+        return torch.stack(cols, dim=-1).to(torch.uint8)
+
+    def var(x, maxdig):                                       # decimal without leading zeros, left-aligned, 0 = no character
+        nd = torch.ones_like(x)
+        for d in range(1, maxdig):
+            nd += (x >= int(10 ** d)).to(x.dtype)
+        cols = []
+        for j in range(maxdig):
+            e = (nd - 1 - j).clamp(min=0)
+            cols.append(torch.where(j < nd, (x // pow10[e]) % 10 + 48, torch.zeros_like(x)))
+        return torch.stack(cols, dim=-1).to(torch.uint8)
+    for b0 in range(0, nbuf, chunk):
+        nb = min(chunk, nbuf - b0)
+        gen.manual_seed(seed + b0)
+        r = torch.randint(0, 1 << 30, (nb, LINES, 8), generator=gen, device=dev, dtype=torch.int64)
+        t = torch.cumsum(r[..., 0] % 997, dim=1)
+        M = torch.zeros((nb, LINES, W), dtype=torch.uint8, device=dev)
+
+        def put(col, text):
+            M[..., col:col + len(text)] = torch.tensor(list(text), dtype=torch.uint8, device=dev)
+        put(0, b"2026-09-"); M[..., 8:10] = fixed(1 + (t // 86400000) % 28, 2)
+        put(10, b"T"); M[..., 11:13] = fixed((t // 3600000) % 24, 2)
+        put(13, b":"); M[..., 14:16] = fixed((t // 60000) % 60, 2)
+        put(16, b":"); M[..., 17:19] = fixed((t // 1000) % 60, 2)
+        put(19, b"."); M[..., 20:23] = fixed(t % 1000, 3)
+        put(23, b"Z host-"); M[..., 30:32] = fixed(r[..., 1] % 16, 2)
+        put(32, b" svc-"); M[..., 37:42] = svcs[r[..., 2] % 6]
+        put(42, b"["); M[..., 43:48] = var(r[..., 3] % 32768, 5)
+        put(48, b"]: "); M[..., 51:56] = levels[r[..., 4] % 4]
+        put(56, b" "); M[..., 57:81] = msgs[r[..., 5] % 8]
+        put(81, b" k="); M[..., 84:87] = var(r[..., 6] % 1000, 3)
+        put(87, b" v="); M[..., 90:95] = var(r[..., 7] % 100000, 5)
+        put(95, b"\n")
+        for i in range(nb):
+            flat = M[i].reshape(-1)
+            out[(b0 + i) * MiB:(b0 + i + 1) * MiB] = flat[flat != 0][:MiB]
+        del M, r, t
     return out
 
 
@@ -149,6 +263,60 @@ def float_blocks_on_device(torch, dev, nblocks, first_global_block, stride_block
         g = first_global_block + i * stride_blocks
         gen.manual_seed(seed + g)
         out[i * MiB:(i + 1) * MiB] = torch.randn(MiB // 4, generator=gen, device=dev, dtype=torch.float32).view(torch.uint8)
+    return out
+
+
+def text_blocks_on_device(torch, dev, nblocks, seed=0x5EED0001, chunk_blocks=32):
+    """configs[0]-style text, `nblocks` DISTINCT 1 MiB blocks: the order-1 word model of tests/datagen.text_bytes (same
+    4096-word vocabulary, w -> (31 w + 7) mod 4096 with probability 0.35, the same tag / full-stop / space frequencies),
+    vectorised on the device (the loop of datagen.text_bytes makes ~1 MB/s)."""
+    import numpy as np
+    import datagen
+    datagen.text_bytes(16)                                    # builds the vocabulary
+    words = datagen._WORDS
+    nw = len(words)
+    wl = torch.tensor([len(w) for w in words], dtype=torch.int64, device=dev)
+    wo = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(wl, 0)])
+    wb = torch.from_numpy(np.frombuffer(b"".join(words), dtype=np.uint8).copy()).to(dev)
+    zp = 1.0 / torch.arange(1, nw + 1, dtype=torch.float64)
+    cdf = torch.cumsum(zp / zp.sum(), 0).to(torch.float32).to(dev)
+    pre_t = torch.tensor([0, 0, 2, 1], dtype=torch.int64, device=dev)
+    post_t = torch.tensor([1, 2, 2, 1], dtype=torch.int64, device=dev)
+    out = torch.empty(nblocks * MiB, dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    for b0 in range(0, nblocks, chunk_blocks):
+        nb = min(chunk_blocks, nblocks - b0)
+        nbytes = nb * MiB
+        gen.manual_seed(seed + b0)
+        m = int(nbytes / 5.5) + 4096
+        picks = torch.searchsorted(cdf, torch.rand(m, generator=gen, device=dev)).clamp_(max=nw - 1)
+        mix = torch.rand(m, generator=gen, device=dev)
+        dep = mix < 0.35
+        dep[0] = False
+        idx = torch.arange(m, device=dev)
+        last = torch.cummax(torch.where(~dep, idx, torch.zeros_like(idx)), 0).values
+        d = idx - last
+        w = picks[last]
+        for step in range(1, int(d.max().item()) + 1):
+            w = torch.where(d >= step, (w * 31 + 7) % nw, w)
+        kind = torch.where(mix > 0.985, 3, torch.where(mix > 0.97, 2, torch.where(mix > 0.93, 1, 0)))
+        pre, post, lw = pre_t[kind], post_t[kind], wl[w]
+        off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(pre + lw + post, 0)])
+        total = int(off[-1].item())
+        assert total >= nbytes
+        buf = torch.zeros(total + 8, dtype=torch.uint8, device=dev)
+        rep = torch.repeat_interleave(torch.arange(m, device=dev), lw)
+        wstart = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(lw, 0)])[:-1]
+        within = torch.arange(rep.numel(), device=dev) - wstart[rep]
+        buf[off[:-1][rep] + pre[rep] + within] = wb[wo[w][rep] + within]
+        s0, e0 = off[:-1], off[:-1] + pre + lw
+        k0, k1, k2, k3 = kind == 0, kind == 1, kind == 2, kind == 3
+        buf[e0[k0]] = 32
+        buf[e0[k1]] = 46; buf[e0[k1] + 1] = 32
+        buf[s0[k2]] = 60; buf[s0[k2] + 1] = 47; buf[e0[k2]] = 62; buf[e0[k2] + 1] = 10
+        buf[s0[k3]] = 60; buf[e0[k3]] = 62
+        out[b0 * MiB:(b0 + nb) * MiB] = buf[:nbytes]
+        del buf, rep, within
     return out
 
 
@@ -230,7 +398,7 @@ def cpu_baseline(sample_blocks, log_sample):
     return res
 
 
-def leg_single_call(torch, glc, dev, d_block, iters=20):
+def leg_single_call(torch, glc, dev, d_block, iters=20, what="Zipf"):
     """the reference API as its own test drives it: cudppCompress on one 1 MiB block with a rows=1 plan, outputs read
     back afterwards (test_compress.cpp:744-779) -- here the wait is glcPlanSynchronize"""
     L = glc.lib()
@@ -261,25 +429,23 @@ def leg_single_call(torch, glc, dev, d_block, iters=20):
         plan.synchronize()
         assert rc == 0
     med = statistics.median(ts)
-    return {"api": "cudppCompress (reference entry point), plan rows=1, one 1 MiB Zipf block, glcPlanSynchronize after each call",
+    return {"api": "cudppCompress (reference entry point), plan rows=1, one 1 MiB %s block, glcPlanSynchronize after each call" % what,
             "ms_per_call_median": round(med * 1e3, 4), "GBps": round(n / med / 1e9, 4),
             "ms_host_in_call": round(t_call * 1e3, 4), "calls": iters,
             "host_syncs_per_call": "1 inside (flagged-block count of the bucket sorter) + the caller's wait"}
 
 
-def leg_text_like(torch, glc, dev, rows=256, distinct=8, iters=3):
-    """configs[0]-style data through the same entry point: order-1 word-model text and log lines (tests/datagen.py),
-    `distinct` different 1 MiB blocks tiled to a batch of `rows`.  These blocks leave the bucket sorter (their
-    order-0 code is lumpy) for the sample sorter; the figure includes the bucket sorter's wasted attempt and the
-    MTF + Huffman pass queued behind it speculatively and redone."""
-    import numpy as np
-    import datagen
+def leg_text_like(torch, glc, dev, rows=256, iters=3):
+    """configs[0]-style data through the same entry point: order-1 word-model text and log lines, `rows` DISTINCT 1 MiB
+    blocks per batch (generated on the device: text_blocks_on_device / log_buffers_on_device).  These blocks leave the
+    bucket sorter (their order-0 code is lumpy) for the sample sorter; the figure includes whatever the bucket sorter
+    spends before it hands them over.  Also: ONE text block through the reference entry point (config 1 as named)."""
     n = MiB
     out_res = {}
+    L = glc.lib()
     with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
-        for name, gen in (("text", datagen.text_bytes), ("log", datagen.log_bytes)):
-            x = gen(n * distinct).reshape(distinct, n)
-            d_in = torch.from_numpy(np.tile(x, (rows // distinct, 1))).to(dev).contiguous().view(-1)
+        for name, gen in (("text", text_blocks_on_device), ("log", log_buffers_on_device)):
+            d_in = gen(torch, dev, rows)
             out = glc.compress_batch(plan, d_in, n, rows)
             plan.synchronize()
             ts = []
@@ -295,11 +461,14 @@ def leg_text_like(torch, glc, dev, rows=256, distinct=8, iters=3):
             ok = bool(torch.equal(back, d_in))
             words = int(out["size"].sum().item())
             out_res[name] = {"GBps": round(n * rows / min(ts) / 1e9, 2), "ms_per_batch": round(min(ts) * 1e3, 3),
-                             "ratio": round(n * rows / (4.0 * words), 3), "blocks": rows,
+                             "ratio": round(n * rows / (4.0 * words), 3), "blocks": rows, "distinct_blocks": rows,
                              "blocks_left_by_bucket_sorter": f1, "blocks_left_by_sample_sorter": f2, "round_trip_ok": ok}
+            if name == "text":
+                one = d_in[:n].clone()
             del d_in, out, back
-    out_res["note"] = ("cudppCompress path (glcCompressBatch, one plan, %d blocks per call) on %d distinct synthetic 1 MiB blocks "
-                       "tiled; best of %d calls incl. the host wait" % (rows, distinct, iters))
+    out_res["single_call_text"] = leg_single_call(torch, glc, dev, one, what="text")
+    out_res["note"] = ("cudppCompress path (glcCompressBatch, one plan, %d distinct synthetic 1 MiB blocks per call); best of %d calls "
+                       "incl. the host wait" % (rows, iters))
     return out_res
 
 
@@ -310,11 +479,12 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
     import oracle_lib as O
     L = glc.lib()
     nbuf = max(1, int(gib * 1024))
-    uniq = min(64, nbuf)
-    host = np.concatenate([datagen.log_bytes(MiB, seed=0x5EED0003 + i) for i in range(uniq)])
-    d_u = torch.from_numpy(host).to(dev)
-    d_in = d_u.repeat((nbuf + uniq - 1) // uniq)[: nbuf * MiB].contiguous()
-    del d_u
+    d_in = log_buffers_on_device(torch, dev, nbuf)             # nbuf DISTINCT buffers, each from its own seed
+    uniq = nbuf
+    pick = sorted(set([0, nbuf // 2, nbuf - 1]))
+    host = {b: d_in[b * MiB:(b + 1) * MiB].cpu().numpy() for b in pick}
+    nwrapbuf = min(8, nbuf)
+    host_first = d_in[:nwrapbuf * MiB].cpu().numpy()
     stride = L.glcLzssPackStride(MiB)
     d_packed = torch.empty(nbuf * stride, dtype=torch.uint8, device=dev)
     d_sizes = torch.empty(nbuf, dtype=torch.int32, device=dev)
@@ -358,10 +528,10 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
     sizes = d_sizes.cpu().numpy().astype(np.int64)
     raw = int((sizes == 0).sum())
     comp_bytes = int(sizes.sum()) + raw * MiB
-    ok, pick = 0, [0, uniq // 2, uniq - 1]
+    ok = 0
     t0 = time.perf_counter()
     for b in pick:
-        blk = host[b * MiB:(b + 1) * MiB]
+        blk = host[b]
         want = O.lzss_pack(O.lzss_candidates(blk), MiB)
         ok += int(want is not None and np.array_equal(d_packed[b * stride: b * stride + int(sizes[b])].cpu().numpy(), want))
     cpu_s = (time.perf_counter() - t0) / len(pick)
@@ -370,7 +540,8 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
     total = nbuf * MiB
     rho = comp_bytes / total
     ktab = kernel_table(lz_get, {"k_lzss_match": 3.0, "k_lzss_pack_wave+k_lzss_pack": 2.0 + rho,
-                                 "k_lzss_layout+k_lzss_gather": 2.0 * rho, "k_lzss_decode": 1.0 + rho}, pmc_per64, issue)
+                                 "k_lzss_layout+k_lzss_gather": 2.0 * rho, "k_lzss_decode": 1.0 + rho}, pmc_per64, issue,
+                        census=load_census(), rho=rho)
     L.glcLzssEnableProfile(0)
     # the reference's wrapper ABI as culzss.c drives it (host pointers: H2D of the buffer, kernels, D2H of the 2 B/B
     # candidate stream, packing, D2H of the packed bytes): PCIe inclusive, never `value`
@@ -382,15 +553,15 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
     for i in range(nwrap + 4):
         if i == 4:
             tw0 = time.perf_counter()
-        ctypes.memmove(buf, host[(i % uniq) * MiB:].ctypes.data, MiB)
+        ctypes.memmove(buf, host_first[(i % nwrapbuf) * MiB:].ctypes.data, MiB)
         L.compression_kernel_wrapper(buf, MiB, bufout, 0, 0, 128, 0, i % 4, in_d, out_d)
         L.onestream_finish_GPU(i % 4)
         L.aftercompression_wrapper(buf, MiB, bufout, ctypes.byref(nn))
     wrap_s = (time.perf_counter() - tw0) / nwrap
     L.deleteCPUmem(buf); L.deleteCPUmem(bufout); L.deleteGPUmem(in_d); L.deleteGPUmem(out_d)
     L.deleteGPUStreams()
-    return {"workload": "configs[2]: %g GiB log-style ASCII (%d MiB unique, tiled), 1 MiB buffers, 4096-B packets, 128-B window, "
-                        "device resident (glcLzssEncodeDevice / glcLzssDecodeDevice)" % (gib, uniq),
+    return {"workload": "configs[2]: %g GiB log-style ASCII, %d DISTINCT 1 MiB buffers (each from its own seed, generated on the device), "
+                        "4096-B packets, 128-B window, device resident (glcLzssEncodeDevice / glcLzssDecodeDevice)" % (gib, uniq),
             "encode_GBps": round(total / ms_enc / 1e6, 3), "decode_GBps": round(total / ms_dec / 1e6, 3),
             "encode_ms": round(ms_enc, 3), "decode_ms": round(ms_dec, 3), "timing": "median of %d, hipEvents on the launch stream" % iters,
             "encode_with_pcie_staging_GBps": round(MiB / wrap_s / 1e9, 4),
@@ -415,7 +586,7 @@ def leg_culzss(torch, glc, dev, gib, iters=3):
             "roundtrip": "decode(encode(x)) == x on all %d buffers" % nbuf,
             "parity": "%d/%d sampled buffers byte-exact vs oracle" % (ok, len(pick)),
             "cpu_port": {"value": round(MiB / cpu_s / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
-                         "sample": "3 x 1 MiB buffers through the oracle's lock-step EncodeKernel emulation + aftercomp"}}, host[:8 * MiB]
+                         "sample": "%d x 1 MiB buffers through the oracle's lock-step EncodeKernel emulation + aftercomp" % len(pick)}}, host_first
 
 
 def leg_hd(torch, glc, dev, mib, iters=5):
@@ -456,7 +627,7 @@ def leg_hd(torch, glc, dev, mib, iters=5):
             return None
         return nm.value.decode(), o3[0], o3[1], o3[2]
     rho_hd = units.size * 4.0 / n
-    hd_tab = kernel_table(hd_get, {"k_hd_span_functions": rho_hd, "k_hd_walk x3": None, "k_hd_emit": rho_hd + 1.0}, {}, {})
+    hd_tab = kernel_table(hd_get, {"k_hd_span_functions": rho_hd, "k_hd_walk x3": None, "k_hd_emit": rho_hd + 1.0}, {}, {}, rho=rho_hd)
     L.glcHdEnableProfile(0)
     ns = min(n, 16 << 20)
     su = glc.hd_encode_host(data[:ns], lens, codes)
@@ -476,6 +647,75 @@ def leg_hd(torch, glc, dev, mib, iters=5):
                          "sample": "%d MiB bit-serial oracle decode" % (ns >> 20)}}
 
 
+def compact_line(res, details_path):
+    """the ONE line the driver keeps (it retains the last 8 KB of output): every headline figure, `roofline` and `cpu_baseline`
+    as the contract asks; the per-kernel tables and every leg's sub-figures go to the details file"""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+    line = pick(res, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "dtype", "data"])
+    line["vs_baseline"] = res.get("vs_baseline")
+    cfg = res.get("config", {})
+    line["config"] = pick(cfg, ["workload", "block_bytes", "blocks_per_gpu", "batch_rows", "output_layout", "stage_pipelining", "parallelism",
+                                "blocks_left_by_bucket_sorter", "blocks_left_by_sample_sorter"])
+    if "output_layout" in line["config"]:
+        line["config"]["output_layout"] = line["config"]["output_layout"].split(":")[0]
+    line.update(pick(res, ["compression_ratio", "per_rank_GBps", "value_no_stage_overlap_GBps", "decode_GBps", "decode_one_plan_GBps",
+                           "frac_of_hbm_read_roofline", "frac_of_hbm_roofline_algorithmic_1_plus_rho", "encode_hbm_bytes_per_input_byte",
+                           "stream_read_ceiling_GBps", "parity", "roundtrip", "value_with_gather", "gather_ms", "rccl_ranks_seen"]))
+    rf = res.get("roofline") or {}
+    line["roofline"] = pick(rf, ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                                 "launches", "kernel_design_frac", "hbm_busy_frac", "valu_issue_frac", "salu_issue_frac", "lds_busy_frac", "timing"])
+    line["roofline"]["traffic"] = rf.get("traffic")
+    kt = res.get("kernels") or {}
+    line["kernel_ms_per_launch"] = {k: v["avg_launch_ms"] for k, v in kt.items()}
+    dec = res.get("decode") or {}
+    if dec.get("roofline"):
+        line["decode_roofline"] = pick(dec["roofline"], ["kernel", "bound", "frac", "kernel_design_frac", "traffic", "avg_launch_ms", "hbm_busy_frac"])
+    sc = res.get("single_call") or {}
+    tl = res.get("text_like") or {}
+    line["single_call"] = {"zipf_ms": sc.get("ms_per_call_median"), "zipf_host_ms_in_call": sc.get("ms_host_in_call"),
+                           "text_ms": (tl.get("single_call_text") or {}).get("ms_per_call_median"), "host_syncs_in_call": sc.get("host_syncs_per_call")}
+    if tl:
+        line["text_like"] = {k: pick(tl[k], ["GBps", "ratio", "distinct_blocks", "blocks_left_by_sample_sorter", "round_trip_ok"]) for k in ("text", "log") if k in tl}
+    cz = res.get("culzss") or {}
+    if cz:
+        line["culzss"] = pick(cz, ["encode_GBps", "decode_GBps", "encode_with_pcie_staging_GBps", "compression_ratio", "parity", "roundtrip"])
+        line["culzss"]["workload"] = cz.get("workload", "").split(",")[0] + ", " + cz.get("workload", "").split(",")[1].strip() if cz.get("workload") else None
+        if cz.get("roofline"):
+            line["culzss"]["roofline"] = pick(cz["roofline"], ["kernel", "bound", "frac", "kernel_design_frac", "avg_launch_ms", "valu_issue_frac"])
+    hd = res.get("hd_decode") or {}
+    if hd:
+        line["hd_decode"] = pick(hd, ["decode_GBps", "ratio", "decoded_equals_original"])
+    cb = res.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = pick(cb, ["value", "unit", "cores", "kind", "sample"])
+        ac = cb.get("all_cores") or {}
+        line["cpu_baseline"]["all_cores"] = pick(ac, ["cores", "oracle_port_encode_GBps", "libbz2_9_encode_GBps", "libbz2_9_decode_GBps"])
+        if cb.get("serial_lzss_config3"):
+            line["cpu_baseline"]["serial_lzss_config3"] = pick(cb["serial_lzss_config3"], ["kind", "encode_GBps", "decode_GBps"])
+    if res.get("gather_to_rank0"):
+        line["gather_to_rank0"] = pick(res["gather_to_rank0"], ["error", "backend", "gathered_equals_single_process_streams", "root_decodes_gathered_blocks",
+                                                                "per_batch_gather_equals_one_shot", "value_with_gather_GBps", "ms"])
+    line["details"] = details_path
+    return line
+
+
+def emit(res, args):
+    path = args.details
+    if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        path = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    shown = None
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(res, f)
+            shown = os.path.relpath(path, ROOT)
+        except OSError:
+            shown = None
+    print(json.dumps(compact_line(res, shown)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -493,15 +733,18 @@ def main():
     ap.add_argument("--main-only", action="store_true", help="skip the single_call / culzss / hd_decode / ceiling legs")
     ap.add_argument("--culzss-gib", type=float, default=4.0)
     ap.add_argument("--hd-mib", type=int, default=1024)
-    ap.add_argument("--enc-pipeline", action="store_true",
-                    help="stage pipelining in the timed encode leg (glcPlanSetPipelining: the VALU-bound MTF + Huffman stages of "
-                         "batch i overlap the suffix sort of batch i+1: +6-8 %% throughput).  Off by default so that the "
-                         "launch times under `roofline` / `kernels` are each kernel's own; the overlapped figure is measured "
-                         "in an extra pass and reported as `value_stage_overlap_GBps`")
+    ap.add_argument("--enc-pipeline", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--no-enc-pipeline", action="store_true",
+                    help="timed encode leg without stage pipelining (glcPlanSetPipelining: the MTF + Huffman stages of batch i "
+                         "overlap the suffix sort of batch i + 1).  It is a library feature and on by default; the launch times "
+                         "under `roofline` / `kernels` come from a separate pass WITHOUT overlap, so that each is the kernel's own")
     ap.add_argument("--no-dec-pipeline", action="store_true", help="decode leg: no stage pipelining")
     ap.add_argument("--no-overlap-pass", action="store_true",
-                    help="skip the extra stage-overlap pass (profiles/collect.sh: keeps rocprofv3's per-kernel averages equal to "
-                         "the timed region's)")
+                    help="no stage overlap anywhere and no separate profile pass: the timed region itself is profiled "
+                         "(profiles/collect.sh, tools/exp/pmc_insts.sh: keeps rocprofv3's per-kernel averages equal to the bench's)")
+    ap.add_argument("--details", default=None,
+                    help="file for the full result (per-kernel tables, every leg's sub-figures); default gpurun_out/bench_full.json "
+                         "when that directory exists, else no file")
     ap.add_argument("--strided", action="store_true", help="timed encode writes the reference's strided layout, then one glcCompactStreams pass (rounds 1-2)")
     ap.add_argument("--gather-timeout", type=int, default=240, help="seconds the multi-GPU exchange leg may take before the line is printed without it")
     ap.add_argument("--with-gather", action="store_true",
@@ -532,7 +775,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    glc = _load("glc_binding", os.path.join(PKG, "glc_binding.py"))
+    global _GLC
+    glc = _GLC = _load("glc_binding", os.path.join(PKG, "glc_binding.py"))
     L = glc.lib()                                         # fails loudly if the HIP library is missing
     ex = _load("glc_dist", os.path.join(PKG, "dist_gather.py"))
 
@@ -573,7 +817,7 @@ def main():
         pl = glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows)
         st_ = torch.cuda.current_stream(dev) if nplans == 1 else torch.cuda.Stream(dev)
         pl.set_stream(st_.cuda_stream)
-        pl.set_pipelining(bool(args.enc_pipeline))
+        pl.set_pipelining(False)
         pl.set_sorter(args.sorter)
         plans.append(pl)
         streams.append(st_)
@@ -716,11 +960,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # the timed region runs the encoder as a caller would: stage overlap across batches on (glcPlanSetPipelining), no
+    # per-launch events.  The per-kernel launch times of `roofline` / `kernels` come from ONE more pass without overlap
+    # and with the library's hipEvent pairs around every launch (each time is then the kernel's own).
+    use_pipe = not args.no_enc_pipeline and not args.no_overlap_pass
+    profile_in_timed = args.no_overlap_pass or not use_pipe
+    for pl in plans:
+        pl.set_pipelining(use_pipe)
     for _ in range(args.warmup):
         step()
     for pl in plans:
         pl.synchronize()
-        pl.enable_timing(3)
+        pl.enable_timing(3 if profile_in_timed else 0)
     flagged[0] = flagged[1] = 0
     barrier()
     step_s = []
@@ -731,6 +982,23 @@ def main():
         step_s.append(time.perf_counter() - ts)
     barrier()
     t1 = time.perf_counter()
+    no_overlap_gbps = None
+    if not profile_in_timed:
+        for pl in plans:
+            pl.synchronize()
+            pl.set_pipelining(False)
+        encode_all()                                          # (first call after the switch: not timed)
+        for pl in plans:
+            pl.synchronize()
+            pl.enable_timing(3)
+        barrier()
+        ts = time.perf_counter()
+        encode_all()
+        barrier()
+        tno = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tno, op=dist.ReduceOp.MAX)
+        no_overlap_gbps = float(nblocks) * n * world / float(tno.item()) / 1e9
     kernels = {}
     for pl in plans:
         pl.synchronize()
@@ -741,26 +1009,8 @@ def main():
     stage_ms = plan.last_timing()
     for pl in plans:
         pl.enable_timing(0)
-    # the same encode with stage overlap across batches (a library feature; not `value`): 2 passes, best of them
+        pl.set_pipelining(False)
     overlap_gbps = None
-    if not args.enc_pipeline and not args.no_overlap_pass:
-        for pl in plans:
-            pl.set_pipelining(True)
-        encode_all()
-        best = None
-        for _ in range(2):
-            barrier()
-            ts = time.perf_counter()
-            encode_all()
-            barrier()
-            dt = time.perf_counter() - ts
-            best = dt if best is None or dt < best else best
-        tov = torch.tensor([best], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tov, op=dist.ReduceOp.MAX)
-        overlap_gbps = float(nblocks) * n * world / float(tov.item()) / 1e9
-        for pl in plans:
-            pl.set_pipelining(False)
 
     # result collection (the one exchange step of the multi-GPU path): timed on its own, timed INSIDE the encode
     # (per batch on a side stream, overlapped with the next batch's encode), then checked on rank 0
@@ -908,9 +1158,14 @@ def main():
         dist.all_reduce(dec_elapsed, op=dist.ReduceOp.MAX)
     decode_gbps = float(nblocks) * n * world / float(dec_elapsed.item()) / 1e9
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    my_elapsed = t1 - t0
+    elapsed = torch.tensor([my_elapsed], dtype=torch.float64, device=dev)
+    per_rank_gbps = [float(nblocks) * n * args.steps / my_elapsed / 1e9]
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        allv = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allv, torch.tensor([per_rank_gbps[0]], dtype=torch.float64, device=dev))
+        per_rank_gbps = [float(v.item()) for v in allv]
     elapsed = float(elapsed.item())
     total_bytes = float(nblocks) * n * world * args.steps
     value = total_bytes / elapsed / 1e9
@@ -943,6 +1198,8 @@ def main():
         rho = 1.0 / ratio
         ktab = {}
         pmc_per64, issue, valu_src = load_pmc_insts()
+        census = load_census()
+        ttab_all, tblocks_all, tcollected_all = load_traffic()
         for name, k in kernels.items():
             avg = k["ms"] / max(1, k["launches"])
             per_launch_units = k["units"] / max(1, k["launches"])
@@ -950,25 +1207,20 @@ def main():
             if name == "k_huff_pack":
                 ab = 1.0 + rho
             ach = per_launch_units * ab / (avg * 1e-3) / 1e9 if (ab and avg > 0) else None
-            ktab[name] = {"avg_launch_ms": round(avg, 4), "launches": k["launches"], "alg_bytes_per_input_byte": ab,
-                          "achieved_GBps": round(ach, 1) if ach else None,
-                          "hbm_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
-            pk = pmc_per64.get(name)
-            if pk and avg > 0 and pk.get("SQ_INSTS_VALU"):
-                # instruction issue, not HBM, bounds the big kernels: wave64 instructions per 64 input bytes from the
-                # committed PMC passes; issue rates from tools/probes/valu_rate_probe.hip (profiles/*_valu_rate.md): a SIMD
-                # takes 4 cycles per instruction of the "slow" class (DPP, compares, carries, shifts left, min/max,
-                # multiplies, bit-field ops: most of what these kernels execute), ~2.1 for plain add/sub/logic/mov; the
-                # scalar unit issues one instruction per cycle per CU
-                simd_cycles = 1024 * issue["clock_GHz"] * 1e9 * (avg * 1e-3)
-                n64 = per_launch_units / 64.0
-                ktab[name]["valu_issue_frac"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["slow_class_cycles_per_inst"] / simd_cycles, 3)
-                ktab[name]["valu_issue_frac_if_all_fast_class"] = round(n64 * pk["SQ_INSTS_VALU"] * issue["fast_class_cycles_per_inst"] / simd_cycles, 3)
-                if ktab[name]["valu_issue_frac"] > 1.0:
-                    ktab[name]["valu_issue_note"] = ("above 1 at 4 cycles per instruction: a good part of this kernel's instructions are of the "
-                                                     "2-cycle class (plain add / logic / mov); the truth lies between the two figures")
-                ktab[name]["salu_issue_frac"] = round(n64 * pk.get("SQ_INSTS_SALU", 0.0) / (simd_cycles / 4), 3)
-                ktab[name]["instructions_per_64_bytes"] = {"valu": pk["SQ_INSTS_VALU"], "salu": pk.get("SQ_INSTS_SALU"), "lds": pk.get("SQ_INSTS_LDS")}
+            e = {"avg_launch_ms": round(avg, 4), "launches": k["launches"], "input_bytes_per_launch": int(per_launch_units),
+                 # the bytes an encoder cannot avoid are 1 read + rho written per input byte
+                 "frac_8d": round(per_launch_units * (1.0 + rho) / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if avg > 0 else None,
+                 # the kernel's OWN design traffic (e.g. 8-byte suffix words in and out of HBM): what its formulation asks of HBM
+                 "design_bytes_per_input_byte": ab, "design_GBps": round(ach, 1) if ach else None,
+                 "kernel_design_frac": round(ach / HBM_PEAK_GBPS, 4) if ach else None}
+            t = sum(ttab_all.get(key, 0) for key in name.split("+"))
+            if t and avg > 0:
+                tb = t * (per_launch_units / float(n)) / tblocks_all          # counted per launch of tblocks_all blocks, scaled
+                e["traffic"] = int(round(tb))
+                e["hbm_busy_frac"] = round(tb / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3)
+            e.update(issue_fractions(name, pmc_per64, census, issue, per_launch_units, avg))
+            e["bound"] = bound_of(e)
+            ktab[name] = e
         # decoder: per-kernel table of the one-plan pass (stages back to back) and its dominant kernel
         dec_names = [k for k in dec_prof if k.startswith(("k_dec", "k_imtf", "k_ibwt"))]
         dec_alg = {"k_dec_prepare+k_dec_huff": rho + 1.0, "k_imtf_pos": 2.0, "k_imtf_scan+k_imtf_apply": 2.0,
@@ -981,37 +1233,19 @@ def main():
             return dec_names[i], k["ms"], k["launches"], k["units"]
         dec_pmc = dict(pmc_per64)
         dec_pmc["k_dec_huff"] = pmc_per64.get("k_dec_huff_lanes", {})
-        ttab, tblocks, tcollected = load_traffic()
-        ttab = dict(ttab)
+        ttab = dict(ttab_all)
         ttab.setdefault("k_dec_huff", 0)
-        dtab = kernel_table(dec_get, dec_alg, dec_pmc, issue, traffic_tab=ttab, blocks_in_traffic=tblocks)
+        dtab = kernel_table(dec_get, dec_alg, dec_pmc, issue, traffic_tab=ttab, blocks_in_traffic=tblocks_all, census=census, rho=rho)
         decode_block = {"one_plan_GBps": round(dec1, 4), "pipelined_plans_GBps": round(decode_gbps, 4),
                         "hbm_frac_algorithmic_rho_plus_1": round((1 + rho) * dec1 / HBM_PEAK_GBPS, 6),
-                        "roofline": roofline_of(dtab, "one plan, stages back to back; algorithmic bytes of the walk = one 4-byte LF entry read + 1 byte "
-                                                      "emitted per symbol; `traffic` (profiles/pmc_traffic.json, offline rocprofv3 --pmc passes, scaled to this "
-                                                      "run's launch size) is ~80 B per symbol: every step is a dependent scattered 4-byte read that brings a "
-                                                      "64-byte sector past L2, so the launch moves ~6 TB/s -- the streaming ceiling measured in this run -- "
-                                                      "for 5 useful bytes per step; with tables that fit L2 (n = 2^17) it is no faster: see DESIGN.md section 5"),
-                        "traffic_source": "profiles/pmc_traffic.json (%s)" % tcollected,
+                        "roofline": roofline_of(dtab, "one plan, stages back to back; frac = (rho + 1) x decoded bytes of a launch / its time / 8 TB/s (SURVEY.md 8(d)); "
+                                                      "kernel_design_frac counts the kernel's own design traffic"),
+                        "traffic_source": "profiles/pmc_traffic.json (%s)" % tcollected_all,
                         "kernels": dtab}
         dom = max(kernels, key=lambda kname: kernels[kname]["ms"]) if kernels else None
         d = ktab.get(dom, {})
-        traffic, tsrc = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and dom:
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
-                tsrc = "profiles/pmc_traffic.json (offline rocprofv3 --pmc passes, %s)" % tj.get("collected", "see file")
-                if traffic is not None:
-                    # the counters were collected on launches of `blocks_per_launch` blocks; these kernels move a
-                    # fixed number of bytes per block, so a launch over more blocks scales with the block count
-                    per = float(tj.get("blocks_per_launch", 256))
-                    mine = kernels[dom]["units"] / max(1, kernels[dom]["launches"]) / float(n)
-                    traffic = int(round(traffic * mine / per))
-                    tsrc += "; counted per launch of %d blocks, scaled to this run's %d" % (int(per), int(round(mine)))
-            except Exception:
-                traffic = None
+        enc_traffic = sum(ttab_all.get(k2, 0) for k2 in ("k_fs_hist", "k_fs_part", "k_fs_sort", "k_fs_ties", "k_mtf_chunk_lists", "k_mtf_scan_lists",
+                                                       "k_mtf_encode", "k_huff_build", "k_huff_pack")) / (tblocks_all * float(n)) if ttab_all else None
         res = {
             "metric": "encode+decode GB/s (input bytes) per GPU and whole-node; compression ratio parity",
             "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1019,7 +1253,7 @@ def main():
             "ms_per_step_median_rank0": round(statistics.median(step_s) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("configs[1]: %g GiB/GPU Zipf(1.0) bytes" if kind == "zipf" else
+            "config": {"workload": ("configs[1]: %g GiB/GPU Zipf(1.0) bytes (Philox4x32-10, key 0x5eed0002, counter = byte index / 4)" if kind == "zipf" else
                                     "configs[3]: %g GiB/GPU random-float32-as-bytes, blocks round-robin over the GPUs") % args.gib
                                    + ", 1 MiB blocks, cudppCompress BWT+MTF+Huffman encode",
                        "value_is": "encode input bytes of all ranks / wall time (inputs resident in HBM; no data-path collective"
@@ -1035,30 +1269,37 @@ def main():
                                          1: "general sorter only", 2: "general sorter, prefix doubling only",
                                          3: "bucket sorter, then general sorter", 4: "sample sorter first"}[args.sorter],
                        "blocks_left_by_bucket_sorter": flagged[0], "blocks_left_by_sample_sorter": flagged[1],
-                       "stage_pipelining": {"encode": bool(args.enc_pipeline), "decode": not args.no_dec_pipeline},
+                       "stage_pipelining": {"encode": bool(use_pipe), "decode": not args.no_dec_pipeline},
                        "parallelism": "blocks round-robin over %d GPU(s), no data-path collective" % world},
+            "per_rank_GBps": [round(v, 3) for v in per_rank_gbps],
             "compression_ratio": round(ratio, 4),
-            "value_stage_overlap_GBps": round(overlap_gbps, 4) if overlap_gbps else None,
+            "value_no_stage_overlap_GBps": round(no_overlap_gbps, 4) if no_overlap_gbps else (round(value, 4) if not use_pipe else None),
             "decode_GBps": round(decode_gbps, 4),
             "decode_one_plan_GBps": round(dec1, 4),
             "decode": decode_block,
             "roundtrip": "decode(encode(x)) == x on all %d blocks per GPU" % nblocks,
             "frac_of_hbm_read_roofline": round(value / world / HBM_PEAK_GBPS, 6),
             "frac_of_hbm_roofline_algorithmic_1_plus_rho": round((1 + rho) * value / world / HBM_PEAK_GBPS, 6),
+            "encode_hbm_bytes_per_input_byte": round(enc_traffic, 2) if enc_traffic else None,
             "stage_ms_last_batch": {"bwt": round(stage_ms[0], 3), "mtf": round(stage_ms[1], 3),
                                     "huffman": round(stage_ms[2], 3), "total": round(stage_ms[3], 3)},
-            "roofline": {"kernel": "glc::" + dom if dom else None, "bound": "hbm", "achieved": d.get("achieved_GBps"),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d.get("hbm_frac"), "traffic": traffic,
-                         "traffic_source": tsrc, "avg_launch_ms": d.get("avg_launch_ms"), "launches": d.get("launches"),
-                         "algorithmic_bytes_per_launch": (round(kernels[dom]["units"] / max(1, kernels[dom]["launches"])
-                                                                * d["alg_bytes_per_input_byte"], 1)
-                                                          if dom and d.get("alg_bytes_per_input_byte") else None),
-                         "timing": "hipEvent pairs on the launch stream around every launch inside the timed region",
-                         "valu_issue_frac": d.get("valu_issue_frac"), "salu_issue_frac": d.get("salu_issue_frac"),
+            "roofline": {"kernel": "glc::" + dom if dom else None, "bound": d.get("bound"),
+                         # algorithmic bytes = (1 read + rho written) per input byte x the input bytes of one launch
+                         "achieved": round(d["frac_8d"] * HBM_PEAK_GBPS, 1) if d.get("frac_8d") else None,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d.get("frac_8d"), "traffic": d.get("traffic"),
+                         "algorithmic_bytes_per_launch": int(round(d["input_bytes_per_launch"] * (1.0 + rho))) if d else None,
+                         "avg_launch_ms": d.get("avg_launch_ms"), "launches": d.get("launches"),
+                         "kernel_design_frac": d.get("kernel_design_frac"), "kernel_design_bytes_per_input_byte": d.get("design_bytes_per_input_byte"),
+                         "hbm_busy_frac": d.get("hbm_busy_frac"), "valu_issue_frac": d.get("valu_issue_frac"),
+                         "salu_issue_frac": d.get("salu_issue_frac"), "lds_busy_frac": d.get("lds_busy_frac"),
+                         "traffic_source": "profiles/pmc_traffic.json (%s), scaled to this run's launch size" % tcollected_all,
                          "valu_source": valu_src,
-                         "note": "dominant = largest summed launch time of the encode pipeline; the per-kernel table is under `kernels`; "
-                                 "`valu_issue_frac` = wave64 VALU instructions (PMC) x 4 cycles / SIMD cycles of the launch: the share of the VALU issue slots "
-                                 "at the 4-cycle rate tools/probes/valu_rate_probe measures for these kernels' instruction mix (the bound that actually holds them)"},
+                         "timing": ("hipEvent pairs on the launch stream around every launch" +
+                                    (" inside the timed region" if profile_in_timed else
+                                     " of one more pass of the same encode WITHOUT stage overlap (each time is the kernel's own)")),
+                         "note": "dominant = largest summed launch time of the encode pipeline; frac follows SURVEY.md 8(d) (1 + rho algorithmic bytes per "
+                                 "input byte); bound = the busiest of {HBM traffic / 8 TB/s, VALU issue (per-class cycles: static census x PMC count), "
+                                 "scalar issue, LDS busy}, 'latency' when none reaches 0.6"},
             "kernels": ktab,
             "parity": verify,
         }
@@ -1097,7 +1338,7 @@ def main():
                 res["gather_to_rank0"] = {"error": "the exchange leg did not finish within %d s" % args.gather_timeout}
                 res["value_with_gather"] = None
                 res["gather_ms"] = None
-                print(json.dumps(res), flush=True)
+                emit(res, args)
             os._exit(0)
 
         dog = threading.Timer(args.gather_timeout + (0 if rank == 0 else 10), give_up)
@@ -1110,11 +1351,17 @@ def main():
             gather_failed = True
         dog.cancel()
         if rank == 0:
+            if xch is not None:
+                import ctypes
+                nr, rk = ctypes.c_int(-1), ctypes.c_int(-1)
+                if L.glcCommInfo(xch.comm, ctypes.byref(nr), ctypes.byref(rk)) == 0:
+                    gather_info["rccl_ranks_seen"] = nr.value   # ranks of the RCCL communicator the C ABI made (glcCommInfo)
             res["gather_to_rank0"] = gather_info
+            res["rccl_ranks_seen"] = gather_info.get("rccl_ranks_seen")
             res["value_with_gather"] = gather_info.get("value_with_gather_GBps")
             res["gather_ms"] = gather_info.get("ms")
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res, args)
     if gather_failed:
         os._exit(0)                                            # peers may be stuck in a collective: no orderly teardown
     pool.shutdown()

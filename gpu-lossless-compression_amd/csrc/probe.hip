@@ -1,5 +1,7 @@
-// probe.hip -- measurement aid: a trivial streaming-read kernel whose launch time gives the
-// read ceiling of THIS box in the same run as the pipeline numbers it is quoted beside.
+// probe.hip -- measurement aids: a trivial streaming-read kernel whose launch time gives the
+// read ceiling of THIS box in the same run as the pipeline numbers it is quoted beside, and the generator of the
+// config-2 workload (Zipf bytes from a counter-based Philox4x32-10 stream: any byte range is reproducible on the host,
+// tests/datagen.py zipf_philox_bytes, and on the device).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -19,9 +21,65 @@ __global__ __launch_bounds__(256) void k_probe_read(const uint4 *__restrict__ p,
     if (acc == 0x9E3779B9u && sink) *sink = acc;               // keeps the loads alive; practically never true
 }
 
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter (c0..c3), key (k0, k1)
+__device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// byte i of the stream = number of thresholds thr[s] <= u (s = 0..254), u = word (i & 3) of Philox(counter = i / 4, key = seed):
+// thr[s] = floor(2^32 * P(symbol <= s)), so symbol s comes up with its Zipf probability to 2^-32
+__global__ __launch_bounds__(256) void k_gen_zipf_philox(uint4 *__restrict__ out, size_t n16, unsigned long long first_ctr,
+                                                         uint32_t seed, const uint32_t *__restrict__ thr)
+{
+    __shared__ uint32_t s_thr[256];
+    s_thr[threadIdx.x] = threadIdx.x < 255 ? thr[threadIdx.x] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long ctr = first_ctr + 4 * i + k;
+            uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+            philox4x32_10(c0, c1, c2, c3, seed, 0u);
+            const uint32_t u[4] = {c0, c1, c2, c3};
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t lo = 0;                               // symbol = #{s < 255 : thr[s] <= u}: binary search, 8 steps
+#pragma unroll
+                for (uint32_t step = 128; step >= 1; step >>= 1)
+                    if (lo + step <= 255 && s_thr[lo + step - 1] <= u[j]) lo += step;
+                word |= lo << (8 * j);
+            }
+            w[k] = word;
+        }
+        out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+// config 2 of SURVEY.md 8(d): bytes [first_byte, first_byte + bytes) of the Zipf stream of `seed` into d_out (both
+// multiples of 16; d_thr255: the 255 cumulative thresholds, device memory).  Enqueues on `stream`; returns 1 on success.
+int glcGenZipfPhilox(void *d_out, size_t bytes, unsigned long long first_byte, unsigned int seed, const unsigned int *d_thr255,
+                     void *stream)
+{
+    if (!d_out || !d_thr255 || (bytes & 15) || (first_byte & 15)) return 0;
+    if (bytes == 0) return 1;
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)(n16 / 256 < 256 * 32 ? (n16 + 255) / 256 : 256 * 32);
+    hipLaunchKernelGGL(k_gen_zipf_philox, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4 *)d_out, n16, first_byte / 4, seed, d_thr255);
+    return hipGetLastError() == hipSuccess ? 1 : 0;
+}
 
 // reads `bytes` bytes at d_buf `iters` times on `stream`; *ms = average launch duration (hipEvents on that stream).
 // Returns 1 on success.

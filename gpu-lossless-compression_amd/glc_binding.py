@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcPlanKernelProfileLost",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcPlanKernelProfileLost",
     "glcCompressBatchCompact", "glcDecompressBatchCompact",
 ]
 CULZSS_SYMBOLS = [
@@ -115,6 +115,8 @@ def lib():
         getattr(L, name).restype = C.c_int
     L.glcProbeStreamRead.argtypes = [vp, sz, C.c_int, C.POINTER(C.c_float), vp]
     L.glcProbeStreamRead.restype = C.c_int
+    L.glcGenZipfPhilox.argtypes = [vp, sz, C.c_ulonglong, C.c_uint, vp, vp]
+    L.glcGenZipfPhilox.restype = C.c_int
     # CULZSS
     if hasattr(L, "compression_kernel_wrapper"):
         L.compression_kernel_wrapper.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -279,6 +279,12 @@ CUDPPResult glcExpandStreams(CUDPPHandle planHandle, const unsigned int *d_in, c
  * d_buf `iters` times on `stream` and returns the average launch duration in *ms -- the read ceiling of this
  * box, measured in the same run as the numbers it is quoted beside.  Returns 1 on success. */
 int glcProbeStreamRead(const void *d_buf, size_t bytes, int iters, float *ms, void *stream);
+/* Measurement aid: the config-2 workload of SURVEY.md 8(d).  Bytes [first_byte, first_byte + bytes) (multiples of 16) of
+ * the Zipf(1.0) byte stream defined by a counter-based Philox4x32-10 generator: byte i = number of thresholds
+ * d_thr255[s] <= word (i & 3) of Philox(counter = i / 4, key = seed).  tests/datagen.py zipf_philox_bytes is the host
+ * twin (same bytes).  Enqueues on the stream; returns 1 on success. */
+int glcGenZipfPhilox(void *d_out, size_t bytes, unsigned long long first_byte, unsigned int seed,
+                     const unsigned int *d_thr255, void *stream);
 
 #ifdef __cplusplus
 }

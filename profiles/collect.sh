@@ -12,7 +12,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python bench.py --gib $GIB > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+timeout 900 python bench.py --gib $GIB --details $OUT/${TAG}_bench_full.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp
 rm -rf $OUT/${TAG}_prof $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o ${TAG} -- \

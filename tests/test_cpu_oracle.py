@@ -430,3 +430,23 @@ def test_reference_findmatch_live_on_fresh_packets():
               rng.integers(0, 3, 4096, dtype=np.uint8), np.repeat(rng.integers(0, 256, 64, dtype=np.uint8), 64)):
         assert np.array_equal(M.ref_candidates(x), O.lzss_candidates(x))
 
+
+# ------------------------------------------------ the config-2 generator ----
+def test_philox4x32_10_known_answers():
+    """Random123's kat_vectors for philox4x32-10: counter, key -> output"""
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kats:
+        got = datagen.philox4x32_10(*[np.array([v], dtype=np.uint64) for v in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_zipf_philox_stream_is_a_function_of_the_byte_index():
+    a = datagen.zipf_philox_bytes(0, 1 << 16)
+    b = datagen.zipf_philox_bytes(1 << 12, 1 << 12)
+    assert np.array_equal(a[1 << 12: 1 << 13], b)                    # any range, from anywhere
+    h = np.bincount(datagen.zipf_philox_bytes(5 << 20, 1 << 20), minlength=256) / float(1 << 20)
+    p = 1.0 / np.arange(1, 257); p /= p.sum()
+    assert abs(h[0] - p[0]) < 2e-3 and abs(h[1] - p[1]) < 2e-3 and abs(h[255] - p[255]) < 3e-4
+
