@@ -685,7 +685,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                                                       uint32_t nbl, const uint2 *__restrict__ tab,
                                                       const uint32_t *__restrict__ list, uint64_t *__restrict__ split,
                                                       uint16_t *__restrict__ cell, uint32_t *__restrict__ flag,
-                                                      uint32_t *__restrict__ l0_out, uint64_t *__restrict__ split8)
+                                                      uint32_t *__restrict__ l0_out, uint64_t *__restrict__ split8, uint32_t seed)
 {
     __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
     __shared__ uint2 s_tab[256];
@@ -703,8 +703,14 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         if (j < S) {
             // one sample per stride of n / S positions, at a hashed offset inside it: evenly spaced samples (every 64th
             // suffix of a 1 MiB block) would only ever see one phase of data with a period, e.g. byte 0 of every float
+            // (The offset is a full avalanche hash of j.  Round 3's `(j * 2654435761) >> 12` is a Weyl sequence: the offset
+            // advances by 55 mod 64 from one stride to the next, the samples sit on a near-lattice of 119 / 55 bytes, and log
+            // lines of ~88 bytes beat against it -- whole classes of suffixes under-sampled, a bucket of > 4032 words and the
+            // block handed to the general sorter: 2 of 256 log blocks, max LCP 51, found with distinct blocks in bench.py.)
             const uint32_t lo = (uint32_t)(((uint64_t)j * n) / S), hi = (uint32_t)(((uint64_t)(j + 1) * n) / S);
-            const uint32_t i = lo + ((j * 2654435761u) >> 12) % (hi - lo);
+            uint32_t h = (j + 1u + seed * SS_MAXS) * 0x9E3779B1u;       // (seed: a second attempt draws other samples)
+            h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+            const uint32_t i = lo + h % (hi - lo);
             w = (fs_code_at(s_tab, T, n, i) & ~FS_LOW_MASK) | ((uint64_t)i << 8);
         }
         s_s[j] = w;
@@ -1254,6 +1260,23 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
     if (deep && lane == 0) atomicOr(&flag[b], 2u);
 }
 
+// second attempt: the blocks of `list` whose ONLY trouble was a bucket past its slot (flag == 1: the samples' luck --
+// bucket populations of text-like blocks have a heavier tail than 32 samples per bucket suggest, ~1 % of log blocks end up
+// with a bucket of 4033-4200 words) are listed again, their flags and fills cleared, for a pass with other samples
+__global__ void k_ss_retry_list(uint32_t *__restrict__ flag, const uint32_t *__restrict__ list, uint32_t nflag,
+                                uint32_t *__restrict__ list2, uint32_t *__restrict__ count, uint32_t *__restrict__ fill)
+{
+    const uint32_t j = blockIdx.x;
+    if (j >= nflag) return;
+    const uint32_t b = list[j];
+    if (flag[b] != 1u) return;                                 // (uniform per workgroup)
+    __shared__ uint32_t s_at;
+    if (threadIdx.x == 0) s_at = atomicAdd(count, 1u);
+    for (uint32_t i = threadIdx.x; i < FS_MAXNB; i += blockDim.x) fill[(size_t)b * FS_MAXNB + i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { list2[s_at] = b; flag[b] = 0; }
+}
+
 // what this tier gave up on keeps its live count for the general sorter
 __global__ void k_ss_finish(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ list, uint32_t nflag,
                             uint32_t n, uint32_t *__restrict__ lcnt, uint32_t *__restrict__ nleft)
@@ -1293,16 +1316,32 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                            s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
         return hipGetLastError();
     }
-    pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
-    hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nblk), dim3(FSP_NT), 0, st, text, text_stride, n,
-                       nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.fs_flag, (const uint32_t *)nullptr,
-                       (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr);
-    if (pi >= 0) s.prof->end(pi, units, st);
-    hipLaunchKernelGGL(k_fs_scan, dim3(nblk), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.fs_flag, (const uint32_t *)nullptr);
-    pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
-    hipLaunchKernelGGL(k_fs_sort, dim3(nb, nblk), dim3(FSS_NT), 0, st, n, nbl, s.keyA, s.fs_kstride, s.fs_fill, s.fs_base,
-                       s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt);
-    if (pi >= 0) s.prof->end(pi, units, st);
+    // Sub-waves (GLC_FS_SUBWAVE = blocks per sub-wave, 0 = the whole call at once): the 8-byte suffix words of a block make
+    // one round trip through memory between k_fs_part and k_fs_sort -- 16 of the encoder's 26 bytes of HBM traffic per input
+    // byte when a call's words (8 MiB per block) are far more than the 256 MB Infinity Cache holds.  Bucketing and sorting
+    // 16 blocks at a time keeps the words of a sub-wave (128 MiB) inside that cache: the bucket sort reads what the
+    // bucketing pass has just written.
+    static const uint32_t subwave = getenv("GLC_FS_SUBWAVE") ? (uint32_t)atoi(getenv("GLC_FS_SUBWAVE")) : 0u;
+    const uint32_t step = subwave && subwave < nblk ? subwave : nblk;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += step) {
+        const uint32_t nbk = nblk - b0 < step ? nblk - b0 : step;
+        const double u = (double)n * nbk;
+        pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
+        hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nbk), dim3(FSP_NT), 0, st, text + (size_t)b0 * text_stride,
+                           text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
+                           s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0, (const uint32_t *)nullptr,
+                           (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr);
+        if (pi >= 0) s.prof->end(pi, u, st);
+        hipLaunchKernelGGL(k_fs_scan, dim3(nbk), dim3(FS_MAXNB), 0, st, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB,
+                           s.fs_flag + b0, (const uint32_t *)nullptr);
+        pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
+        hipLaunchKernelGGL(k_fs_sort, dim3(nb, nbk), dim3(FSS_NT), 0, st, n, nbl, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
+                           s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
+                           bwt_out ? bwt_out + (size_t)b0 * bwt_stride : nullptr, bwt_stride, d_index ? d_index + b0 : nullptr,
+                           sa_out ? sa_out + (size_t)b0 * s.nmax : nullptr, (size_t)s.nmax, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
+                           s.fs_wlcnt + b0);
+        if (pi >= 0) s.prof->end(pi, u, st);
+    }
     hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
@@ -1311,24 +1350,37 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 }
 
 hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nflag, SaScratch &s,
-                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out)
+                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out, uint32_t attempt)
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
-    GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
-    GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
-    hipLaunchKernelGGL(k_ss_sample, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, s.ss_list,
-                       s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB);
+    // attempt 0: the blocks k_fs_finish listed in ss_list; attempt 1: the ones k_ss_retry_list listed behind them
+    const uint32_t *list = s.ss_list + (attempt ? s.rows : 0u);
+    if (attempt == 0) {
+        GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
+        GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
+    }
+    hipLaunchKernelGGL(k_ss_sample, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, list,
+                       s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt);
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
-                       n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, s.ss_list, s.ss_split, s.ss_cell,
+                       n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, list, s.ss_split, s.ss_cell,
                        s.ss_split + (size_t)s.rows * FS_MAXNB);
-    hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, s.ss_list);
+    hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, list);
     hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.ss_flag, s.ss_list, s.ss_l0);
+                       s.fs_fill, s.ss_flag, list, s.ss_l0);
     hipLaunchKernelGGL(k_ss_windows, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.fs_base, s.ss_flag, s.ss_list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
+                       s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
                        (size_t)s.nmax);
-    hipLaunchKernelGGL(k_ss_finish, dim3((nflag + 255) / 256), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, n, s.fs_lcnt,
+    hipLaunchKernelGGL(k_ss_finish, dim3((nflag + 255) / 256), dim3(256), 0, st, s.ss_flag, list, nflag, n, s.fs_lcnt,
                        s.fs_nflag + 1);
+    return hipGetLastError();
+}
+
+// lists the blocks of the first attempt that deserve a second one (see k_ss_retry_list); their number -> s.fs_nflag[2]
+hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s)
+{
+    GLC_TRY(hipMemsetAsync(s.fs_nflag + 2, 0, 4, st));
+    hipLaunchKernelGGL(k_ss_retry_list, dim3(nflag), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, s.ss_list + s.rows,
+                       s.fs_nflag + 2, s.fs_fill);
     return hipGetLastError();
 }
 

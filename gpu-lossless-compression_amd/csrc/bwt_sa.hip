@@ -833,8 +833,8 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.fs_keep[0], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_keep[1], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_dup, (size_t)rows * 4));
-    GLC_TRY(A((void **)&s.fs_nflag, 8));
-    GLC_TRY(A((void **)&s.ss_list, (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.fs_nflag, 16));
+    GLC_TRY(A((void **)&s.ss_list, (size_t)rows * 4 * 2));
     GLC_TRY(A((void **)&s.ss_split, (size_t)rows * FS_MAXNB * 8 * 2));    // words, then the first 8 text bytes of every splitter
     GLC_TRY(A((void **)&s.ss_flag, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.ss_cell, (size_t)rows * 4098 * 2));
@@ -1089,6 +1089,7 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
     uint32_t nflag = s.h_max_cnt[4];
     s.last_flagged = nflag;
     s.last_general = 0;
+    s.last_retried = 0;
     if (nflag == 0) return hipSuccess;
     if (nflagged) *nflagged = nflag;
     if (s.sorter != 3) {
@@ -1097,7 +1098,28 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
         GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 5, s.fs_nflag + 1, 4, hipMemcpyDeviceToHost, st));
         GLC_TRY(hipEventRecord(s.ev_flag, st));
         GLC_TRY(hipEventSynchronize(s.ev_flag));
-        nflag = s.h_max_cnt[5];
+        uint32_t left = s.h_max_cnt[5];
+        if (left) {
+            // some blocks were given up on.  Those whose only trouble was a bucket past its slot get ONE more attempt with
+            // other samples (a bucket of 4033-4200 words where 4032 fit: ~1 % of log-style blocks; the general sorter
+            // costs ten times the sample sorter, and its rounds hold the host)
+            GLC_TRY(ss_retry_prepare(st, nflag, s));
+            GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.fs_nflag + 2, 4, hipMemcpyDeviceToHost, st));
+            GLC_TRY(hipEventRecord(s.ev_flag, st));
+            GLC_TRY(hipEventSynchronize(s.ev_flag));
+            const uint32_t again = s.h_max_cnt[6];
+            s.last_retried = again;
+            if (again) {
+                s.h_max_cnt[7] = left - again;                 // the others stay given up on; the second attempt adds its own
+                GLC_TRY(hipMemcpyAsync(s.fs_nflag + 1, s.h_max_cnt + 7, 4, hipMemcpyHostToDevice, st));
+                GLC_TRY(ss_build(st, text, text_stride, n, again, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa, 1));
+                GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 5, s.fs_nflag + 1, 4, hipMemcpyDeviceToHost, st));
+                GLC_TRY(hipEventRecord(s.ev_flag, st));
+                GLC_TRY(hipEventSynchronize(s.ev_flag));
+                left = s.h_max_cnt[5];
+            }
+        }
+        nflag = left;
         if (nflag == 0) return hipSuccess;
     }
     s.last_general = nflag;

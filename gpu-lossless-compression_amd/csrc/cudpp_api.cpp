@@ -613,6 +613,43 @@ CUDPPResult glcPlanLastSortStatsEx(CUDPPHandle planHandle, unsigned int *out2)
     return CUDPP_SUCCESS;
 }
 
+// out[0] = blocks of the plan's last call that the sample sorter finished only in its second attempt (other samples)
+CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    out[0] = s->last_retried;
+    return CUDPP_SUCCESS;
+}
+
+// diagnostic: the give-up flags of the plan's last sort, per block (waits for the plan's stream).  out_fs[b]: bucket sorter
+// (1 = a bucket overflowed / flagged up front as text-like, 2 = equal codes deeper than the cap, 4 = work list full);
+// out_ss[b]: sample sorter (1 = a bucket overflowed, 2 = deeper than its cap / a run no window holds)
+CUDPPResult glcPlanDebugSortFlags(CUDPPHandle planHandle, unsigned int *out_fs, unsigned int *out_ss, size_t numBlocks)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s || numBlocks > s->rows) return CUDPP_ERROR_INVALID_PLAN;
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return CUDPP_ERROR_UNKNOWN;
+    if (out_fs && hipMemcpy(out_fs, s->fs_flag, numBlocks * 4, hipMemcpyDeviceToHost) != hipSuccess) return CUDPP_ERROR_UNKNOWN;
+    if (out_ss && hipMemcpy(out_ss, s->ss_flag, numBlocks * 4, hipMemcpyDeviceToHost) != hipSuccess) return CUDPP_ERROR_UNKNOWN;
+    return CUDPP_SUCCESS;
+}
+
+// diagnostic: bucket fills of block `block` as the last bucketing pass left them (FS_MAXNB = 512 entries)
+CUDPPResult glcPlanDebugBucketFill(CUDPPHandle planHandle, size_t block, unsigned int *out512)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out512) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s || block >= s->rows) return CUDPP_ERROR_INVALID_PLAN;
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return CUDPP_ERROR_UNKNOWN;
+    return hipMemcpy(out512, s->fs_fill + block * FS_MAXNB, FS_MAXNB * 4, hipMemcpyDeviceToHost) == hipSuccess ? CUDPP_SUCCESS : CUDPP_ERROR_UNKNOWN;
+}
+
 // the event pairs are read when the plan's streams are idle: both getters wait for them first
 static void prof_collect(PlanBase *p)
 {

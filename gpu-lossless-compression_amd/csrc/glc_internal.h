@@ -148,15 +148,16 @@ struct SaScratch {
     uint32_t *fs_keep[2] = {nullptr, nullptr};   // [rows] 1 = the bucket sorter finished the block (the speculative stages' `only` mask)
     uint32_t *fs_dup = nullptr;                  // [rows] repeated 6-grams among the samples k_fs_hist looks at (text-likeness probe)
     uint32_t  parity = 0;                        // set by the caller before sa_build_begin
-    uint32_t *fs_nflag = nullptr;                // [1] number of flagged blocks
+    uint32_t *fs_nflag = nullptr;                // [4] blocks flagged by the bucket sorter; given up on by the sample sorter; listed for its second attempt
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
     uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
     uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build the bucket sorter gave up on
+    uint32_t  last_retried = 0;                  // ... the sample sorter took in a second attempt (a bucket past its slot in the first)
     uint32_t  last_general = 0;                  // ... of which the sample sorter gave up on too (general sorter)
     bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
     // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
-    uint32_t *ss_list = nullptr;                 // [rows] their block numbers
+    uint32_t *ss_list = nullptr;                 // [2 rows] their block numbers; behind them the ones that get a second attempt
     uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]
     uint32_t *ss_flag = nullptr;                 // [rows] this tier's give-up flags
     uint32_t *ss_l0 = nullptr;                   // [rows][FS_MAXNB] common prefix of a bucket's two splitters
@@ -191,7 +192,9 @@ uint32_t   fs_bucket_log2(uint32_t n);
 // second tier for the nflag blocks listed in s.ss_list: enqueues only; blocks it gives up on keep n in s.fs_lcnt
 // (the others get 0) and are counted in s.fs_nflag[1]
 hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nflag, SaScratch &s,
-                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out);
+                    uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out, uint32_t attempt = 0);
+// blocks of the first attempt whose only trouble was a bucket past its slot -> listed behind ss_list, count in s.fs_nflag[2]
+hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s);
 
 // copy SA to the cudppSuffixArray layout (out[0]=n, out[1..n]=SA)
 hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out);

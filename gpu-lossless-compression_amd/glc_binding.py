@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcPlanKernelProfileLost",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcPlanKernelProfileLost",
     "glcCompressBatchCompact", "glcDecompressBatchCompact",
 ]
 CULZSS_SYMBOLS = [
@@ -104,6 +104,9 @@ def lib():
     L.glcPlanSetSorter.argtypes = [sz, C.c_int]
     L.glcPlanLastSortStats.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanLastSortStatsEx.argtypes = [sz, C.POINTER(C.c_uint)]
+    L.glcPlanLastSortRetries.argtypes = [sz, C.POINTER(C.c_uint)]
+    L.glcPlanDebugSortFlags.argtypes = [sz, C.POINTER(C.c_uint), C.POINTER(C.c_uint), sz]
+    L.glcPlanDebugBucketFill.argtypes = [sz, sz, C.POINTER(C.c_uint)]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
     L.glcPlanLastTiming.argtypes = [sz, C.POINTER(C.c_float)]
     L.glcPlanKernelProfile.argtypes = [sz, C.POINTER(C.c_double)]
@@ -283,6 +286,12 @@ class Plan:
         a = (C.c_uint * 2)()
         _chk("glcPlanLastSortStatsEx", lib().glcPlanLastSortStatsEx(self.handle, a))
         return a[0], a[1]
+
+    def last_sort_retries(self):
+        """blocks of the last call the sample sorter finished in its second attempt (other samples)"""
+        a = (C.c_uint * 1)()
+        _chk("glcPlanLastSortRetries", lib().glcPlanLastSortRetries(self.handle, a))
+        return a[0]
 
     def enable_timing(self, mode=1):
         """0 off, 1 stage events, 3 stage events + dominant-kernel events"""

@@ -259,6 +259,14 @@ CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode);
 CUDPPResult glcPlanLastSortStats(CUDPPHandle planHandle, unsigned int *flaggedBlocks);
 /* out2[0] = the same count, out2[1] = how many of those the sample sorter gave up on too (general sorter) */
 CUDPPResult glcPlanLastSortStatsEx(CUDPPHandle planHandle, unsigned int *out2);
+/* out[0] = how many blocks of the last call the sample sorter finished in its SECOND attempt (a bucket past its slot with the
+ * first samples; other samples are drawn once before the block would go to the general sorter) */
+CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out);
+/* diagnostics (tests, tools/exp): per-block give-up flags of the last sort (bucket sorter: 1 bucket overflow / text-like, 2 deep,
+ * 4 work list full; sample sorter: 1 bucket overflow, 2 deep), numBlocks entries each, either pointer may be NULL; and the
+ * 512 bucket fills of one block as the last bucketing pass left them.  Both wait for the plan's stream. */
+CUDPPResult glcPlanDebugSortFlags(CUDPPHandle planHandle, unsigned int *out_fs, unsigned int *out_ss, size_t numBlocks);
+CUDPPResult glcPlanDebugBucketFill(CUDPPHandle planHandle, size_t block, unsigned int *out512);
 
 /* Result collection: packs the strided per-block streams of a batched compress
  * back to back.  d_outOffsets has numBlocks+1 entries (word offsets; the last is

@@ -2,6 +2,8 @@
 heavy repeated phrases, low-entropy sources -- must come out bit-exact, on this tier where its design says so
 (glcPlanLastSortStatsEx: how many blocks each tier gave up on), and on the general sorter beyond its depth cap.
 Every case is checked against the oracle and against the other sorter modes (glcPlanSetSorter)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -240,3 +242,33 @@ def test_sample_sorter_first_on_short_blocks_ending_in_zero_bytes(glc, ctx, cuda
                 plan.set_sorter(mode)
                 got, gidx = _bwt(glc, plan, torch, x)
                 assert int(gidx[0]) == widx and np.array_equal(got, want), "n %d mode %d: %r" % (n, mode, x.tolist())
+
+
+def test_bucket_past_its_slot_gets_a_second_attempt(glc, cuda):
+    """tests/golden/log_block_bucket_overflow.bin.bz2: a log-style block (max LCP 51) whose splitters, as the first sample set
+    draws them, leave one bucket with more than the 4032 words a slot holds -- ~1 % of log blocks.  It used to go to the
+    general sorter (ten times slower, host-held rounds); now the sample sorter draws other samples once.  BWT == oracle,
+    nothing left for the general sorter, and the block is alone in a batch of Zipf blocks that must not be touched."""
+    import bz2
+    import torch
+    import oracle_lib as O
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "log_block_bucket_overflow.bin.bz2")
+    blk = np.frombuffer(bz2.decompress(open(path, "rb").read()), dtype=np.uint8)
+    n = blk.size
+    assert n == 1 << 20
+    others = [datagen.zipf_bytes(n, seed=900 + i) for i in range(2)]
+    x = np.concatenate([others[0], blk, others[1]])
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_BWT, n, rows=3) as plan:
+        d_in = torch.from_numpy(x).to(cuda)
+        d_out = torch.zeros_like(d_in)
+        d_idx = torch.zeros(3, dtype=torch.int32, device=cuda)
+        assert glc.lib().glcBwtBatch(plan.handle, d_in.data_ptr(), d_out.data_ptr(), d_idx.data_ptr(), n, 3) == 0
+        plan.synchronize()
+        flagged, general = plan.last_sort_stats()
+        assert (flagged, general) == (1, 0), (flagged, general)
+        assert plan.last_sort_retries() == 1
+        got = d_out.cpu().numpy()
+        for i, b in enumerate((others[0], blk, others[1])):
+            want, idx = O.bwt(b)
+            assert np.array_equal(got[i * n:(i + 1) * n], want) and int(d_idx[i].item()) == idx, i
+

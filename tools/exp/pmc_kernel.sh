@@ -10,5 +10,5 @@ if not db: print("no db", open("/tmp/l.txt").read()[-600:])
 else:
     c=sqlite3.connect(db[0])
     q="select s.display_name, i.name, sum(e.value)/count(distinct d.id), count(distinct d.id), avg(d.end-d.start) from rocpd_pmc_event e join rocpd_kernel_dispatch d on e.event_id=d.event_id join rocpd_info_kernel_symbol s on d.kernel_id=s.id join rocpd_info_pmc i on e.pmc_id=i.id where s.display_name like '%"+sys.argv[1]+"%' group by 1,2"
-    for r in c.execute(q): print(r[0][:28], "%-24s %.4e per launch = %8.2f per 64 suffixes   (kernel avg %.1f us under the counters)" % (r[1], r[2], r[2]/ (268435456/64.0), r[4]/1e3))
+    for r in c.execute(q): print(r[0][:28], "%-24s %.4e per launch = %8.2f per 64 suffixes if a launch is 256 blocks; %d launches, sum %.4e; kernel avg %.1f us, sum %.1f us (under the counters)" % (r[1], r[2], r[2]/ (268435456/64.0), r[3], r[2]*r[3], r[4]/1e3, r[4]*r[3]/1e3))
 PY
