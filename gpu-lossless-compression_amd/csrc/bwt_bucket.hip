@@ -224,7 +224,8 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
                                                     uint64_t *__restrict__ keys, size_t kstride,
                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
                                                     const uint32_t *__restrict__ list, const uint64_t *__restrict__ split,
-                                                    const uint16_t *__restrict__ cell, const uint64_t *__restrict__ split8)
+                                                    const uint16_t *__restrict__ cell, const uint64_t *__restrict__ split8,
+                                                    uint32_t *__restrict__ zero_bucket)
 {
     __shared__ uint32_t s_cnt[FS_MAXNB], s_start[FS_MAXNB], s_gbase[FS_MAXNB];
     __shared__ uint64_t s_w[FSP_TILE];
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
             if (deep) atomicOr(&flag[b], 2u);
         } else bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
         br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
+        if (!SPLIT && j == 0 && gi == 0) zero_bucket[b] = bk;  // where the word of suffix 0 goes: k_fs_sort_bwt looks for the BWT index there only
     }
 #undef FS_BYTE
     __syncthreads();
@@ -543,6 +545,202 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
     }
     // 4. the rows
     if (O) {
+        const uint32_t end = shift + c;                        // staged bytes [shift, end)
+        for (uint32_t q = tid; 4 * q < end; q += FSS_NT) {
+            const uint32_t v = s_cp[q];
+            if (4 * q >= shift && 4 * q + 4 <= end) *reinterpret_cast<uint32_t *>(O - shift + 4 * q) = v;
+            else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++)
+                    if (4 * q + k >= shift && 4 * q + k < end) O[4 * q + k - shift] = (uint8_t)(v >> (8 * k));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_fs_sort_bwt: k_fs_sort for the BWT-only path (no suffix array asked for), on a scalar-instruction diet.  The counters
+// put k_fs_sort at 109 VALU + 93.5 SALU + 14.7 LDS instructions per suffix with the scalar pipe 0.66 busy, and nearly
+// all of the scalar work is exec-mask bookkeeping of per-item conditions, eight items per thread.  Here
+//   * the ONE partial round of a bucket (c mod 512 words) is round 0 and carries the only per-lane predicate; rounds
+//     1 .. c / 512 are full and run under a uniform branch alone (k_fs_sort: `i < c` in every round of every loop);
+//   * the rare cases of the rank step -- a bin of more than four words, another word with the same code -- are found
+//     per wave with ONE ballot and handled behind a wave-uniform branch (k_fs_sort: three nested divergent branches per
+//     item, executed or not);
+//   * the row of suffix 0 (the BWT index) is looked for in the ONE bucket k_fs_part saw it go to (zero_bucket), not in
+//     every word of every bucket.
+// Same LDS layout and access pattern (a word is ranked AT ITS POSITION of the bin-sorted array: bin bounds, neighbours and
+// the staged row of neighbouring lanes share banks -- the owner-ranked form measured in round 4 lost more to LDS bank
+// conflicts than it saved in instructions, tools/exp/attic), same work list, entry for entry.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint64_t *__restrict__ keys, size_t kstride,
+                                                        const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
+                                                        uint32_t *__restrict__ flag, uint8_t *__restrict__ bwt_out,
+                                                        size_t bwt_stride, int *__restrict__ d_index, uint4 *__restrict__ wl,
+                                                        uint32_t wl_cap, uint32_t *__restrict__ wl_count,
+                                                        const uint32_t *__restrict__ zero_bucket)
+{
+    __shared__ uint64_t s_w[FS_FILLMAX + 4];                   // + 4 sentinels behind the last word
+    __shared__ uint32_t s_cp[FS_BINS / 2 + 1];                 // bin counters, then bin starts (two 16-bit values per word), then BWT bytes
+    __shared__ uint32_t s_tmp[FSS_NT / 64 + 1];
+    __shared__ uint32_t s_deep, s_wl;
+    uint16_t *s16 = reinterpret_cast<uint16_t *>(s_cp);
+    uint8_t *s_cb = reinterpret_cast<uint8_t *>(s_cp);
+    uint32_t gx, gy;
+    xcd_order(gx, gy);
+    const uint32_t b = gy, bk = gx, tid = threadIdx.x;
+    if (tid == 0) { s_deep = flag[b]; s_wl = 0; }              // (one read: another bucket may flag the block meanwhile)
+    for (uint32_t i = tid; i < FS_BINS / 2; i += FSS_NT) s_cp[i] = 0;
+    const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
+    const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
+    const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+    const uint32_t cc = c <= FS_FILLMAX ? c : 0u;              // (a fuller bucket has flagged its block in k_fs_scan)
+    // item r of a thread: r = 0 -> word full * 512 + tid of the partial round (lanes tid < part), r >= 1 -> word
+    // (r - 1) * 512 + tid of a full round (all lanes, r <= full)
+    const uint32_t full = cc / FSS_NT, part = cc % FSS_NT;
+    const bool v0 = tid < part;
+    const uint32_t i0 = full * FSS_NT + tid;
+    uint64_t w[FSS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) w[r] = ~0ull;
+    if (v0) w[0] = K[i0];
+#pragma unroll
+    for (int r = 1; r < FSS_ITEMS; r++)
+        if ((uint32_t)r <= full) w[r] = K[(r - 1) * FSS_NT + tid];
+    if (tid < 4 && cc) s_w[cc + tid] = ~0ull;                  // what the rank step reads past the last bin compares as larger
+    __syncthreads();
+    if (s_deep || cc == 0) return;                             // flagged: the block is another sorter's
+    // 1. counting sort on the 12 bits below the bucket number (arrival order inside a bin: any order will do)
+    const uint32_t bshift = 64 - nbl - FS_BIN_BITS;
+    uint32_t rk[FSS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) rk[r] = 0;
+    {
+        auto count = [&](int r) {
+            const uint32_t bin = (uint32_t)(w[r] >> bshift) & (FS_BINS - 1), sh = 16 * (bin & 1);
+            rk[r] = (atomicAdd(&s_cp[bin >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        };
+        if (v0) count(0);
+#pragma unroll
+        for (int r = 1; r < FSS_ITEMS; r++)
+            if ((uint32_t)r <= full) count(r);
+    }
+    __syncthreads();
+    {
+        constexpr int PW = FS_BINS / 2 / FSS_NT;               // packed words per thread
+        uint32_t v[PW], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PW; k++) { v[k] = s_cp[tid * PW + k]; sum += (v[k] & 0xFFFFu) + (v[k] >> 16); }
+        uint32_t run = block_excl_add<FSS_NT>(sum, s_tmp);
+#pragma unroll
+        for (int k = 0; k < PW; k++) {
+            const uint32_t lo = run, hi = run + (v[k] & 0xFFFFu);
+            s_cp[tid * PW + k] = lo | (hi << 16);
+            run = hi + (v[k] >> 16);
+        }
+        if (tid == FSS_NT - 1) s_cp[FS_BINS / 2] = c;          // end of the last bin
+    }
+    __syncthreads();
+    {
+        auto scatter = [&](int r) { s_w[s16[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] = w[r]; };
+        if (v0) scatter(0);
+#pragma unroll
+        for (int r = 1; r < FSS_ITEMS; r++)
+            if ((uint32_t)r <= full) scatter(r);
+    }
+    __syncthreads();
+    // 2. final position = bin start + number of smaller codes in the bin (thread = the words at positions i0 / (r - 1) NT +
+    //    tid of the bin-sorted array).  The four words from the bin start are compared in straight-line code with no bounds
+    //    at all -- what lies behind the bin's end is a larger code or a sentinel; a bin of more than four, or a second word
+    //    with my code among the four, is the rare case: detected per wave, redone exactly over the whole bin.
+    const bool zb = zero_bucket[b] == bk;                       // (uniform) suffix 0 is one of this bucket's words
+    uint32_t pos[FSS_ITEMS], grp[FSS_ITEMS];                   // grp = group start << 16 | group size (0: not tied)
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) { pos[r] = 0xFFFFFFFFu; grp[r] = 0; }
+    {
+        auto rank = [&](int r, uint32_t p) {
+            const uint64_t wv = s_w[p];
+            w[r] = wv;
+            const uint32_t key = (uint32_t)(wv >> 28);         // inside a bin only the low 32 bits of the code can differ
+            const uint32_t bin = (uint32_t)(wv >> bshift) & (FS_BINS - 1);
+            const uint32_t gs = s16[bin], ge = s16[bin + 1];
+            uint32_t less = 0, eqt = 0;
+            const uint2 *B = reinterpret_cast<const uint2 *>(s_w) + gs;
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++) {
+                const uint2 wq = B[t];
+                const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
+                less += kq < key ? 1u : 0u;
+                eqt += kq == key ? 1u : 0u;
+            }
+            uint32_t at = gs + less;
+            const bool rare = (ge - gs > 4) | (eqt > 1);
+            if (__builtin_amdgcn_ballot_w64(rare) != 0) {      // (wave-uniform)
+                if (rare) {
+                    if (ge - gs > FS_MAX_GROUP) { s_deep = 1; at = 0xFFFFFFFFu; }
+                    else {
+                        uint32_t ls = 0, eq = 0, eqb = 0;
+#pragma clang loop unroll(disable)
+                        for (uint32_t q = gs; q < ge; q++) {
+                            const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[q];
+                            const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
+                            ls += kq < key; eq += kq == key; eqb += (kq == key) & (q < p);
+                        }
+                        at = gs + ls;
+                        if (eq > 1) { grp[r] = (at << 16) | eq; at += eqb; }
+                    }
+                }
+            }
+            pos[r] = at;
+        };
+        if (v0) rank(0, i0);
+#pragma unroll
+        for (int r = 1; r < FSS_ITEMS; r++)
+            if ((uint32_t)r <= full) rank(r, (r - 1) * FSS_NT + tid);
+        if (zb) {
+#pragma unroll
+            for (int r = 0; r < FSS_ITEMS; r++)
+                if (pos[r] != 0xFFFFFFFFu && ((uint32_t)w[r] & 0x0FFFFF00u) == 0 && !grp[r]) d_index[b] = (int)(R0 + pos[r]);
+        }
+    }
+    __syncthreads();                                           // s_cp (bin starts) is dead from here: it takes the BWT bytes
+    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    // rows R0 .. R0 + c of the block's BWT are staged so that aligned dwords of LDS are aligned dwords of the output
+    uint8_t *O = bwt_out + (size_t)b * bwt_stride + R0;
+    const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
+    // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) {
+        if (pos[r] != 0xFFFFFFFFu) s_cb[shift + pos[r]] = (uint8_t)w[r];      // (rows of tied groups are rewritten by k_fs_ties)
+        if (grp[r]) {
+            any = true;
+            const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu;
+            if (pos[r] == gp) reinterpret_cast<uint32_t *>(s_w)[2 * gp + 1] = atomicAdd(&s_wl, gs);   // (the codes are dead)
+        }
+    }
+    if (__syncthreads_or((int)any)) {
+        if (tid == 0) {
+            const uint32_t tot = s_wl;
+            uint32_t base = atomicAdd(&wl_count[b], tot);
+            if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
+            s_deep = base;
+        }
+        __syncthreads();
+        const uint32_t base = s_deep;
+        uint4 *WL = wl + (size_t)b * wl_cap;
+        if (base != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int r = 0; r < FSS_ITEMS; r++) {
+                if (grp[r]) {
+                    const uint32_t gp = grp[r] >> 16, gs = grp[r] & 0xFFFFu, slot0 = base + reinterpret_cast<const uint32_t *>(s_w)[2 * gp + 1];
+                    WL[slot0 + (pos[r] - gp)] = make_uint4((uint32_t)(w[r] & FS_LOW_MASK), R0 + gp, slot0, gs);
+                }
+            }
+        }
+    }
+    // 4. the rows
+    {
         const uint32_t end = shift + c;                        // staged bytes [shift, end)
         for (uint32_t q = tid; 4 * q < end; q += FSS_NT) {
             const uint32_t v = s_cp[q];
@@ -1330,16 +1528,23 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nbk), dim3(FSP_NT), 0, st, text + (size_t)b0 * text_stride,
                            text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
                            s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0, (const uint32_t *)nullptr,
-                           (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr);
+                           (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr, s.fs_zero + b0);
         if (pi >= 0) s.prof->end(pi, u, st);
         hipLaunchKernelGGL(k_fs_scan, dim3(nbk), dim3(FS_MAXNB), 0, st, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB,
                            s.fs_flag + b0, (const uint32_t *)nullptr);
         pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;
-        hipLaunchKernelGGL(k_fs_sort, dim3(nb, nbk), dim3(FSS_NT), 0, st, n, nbl, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
-                           s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
-                           bwt_out ? bwt_out + (size_t)b0 * bwt_stride : nullptr, bwt_stride, d_index ? d_index + b0 : nullptr,
-                           sa_out ? sa_out + (size_t)b0 * s.nmax : nullptr, (size_t)s.nmax, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
-                           s.fs_wlcnt + b0);
+        static const bool old_sort = getenv("GLC_FS_SORT_OLD") != nullptr;      // A/B: round 3's kernel for the BWT path too
+        if (sa_out || !bwt_out || !d_index || old_sort)                          // the suffix array itself is asked for: the kernel that writes it
+            hipLaunchKernelGGL(k_fs_sort, dim3(nb, nbk), dim3(FSS_NT), 0, st, n, nbl, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
+                               s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
+                               bwt_out ? bwt_out + (size_t)b0 * bwt_stride : nullptr, bwt_stride, d_index ? d_index + b0 : nullptr,
+                               sa_out ? sa_out + (size_t)b0 * s.nmax : nullptr, (size_t)s.nmax, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
+                               s.fs_wlcnt + b0);
+        else
+            hipLaunchKernelGGL(k_fs_sort_bwt, dim3(nb, nbk), dim3(FSS_NT), 0, st, nbl, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
+                               s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
+                               bwt_out + (size_t)b0 * bwt_stride, bwt_stride, d_index + b0, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
+                               s.fs_wlcnt + b0, s.fs_zero + b0);
         if (pi >= 0) s.prof->end(pi, u, st);
     }
     hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
@@ -1363,7 +1568,7 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                        s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt);
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
                        n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, list, s.ss_split, s.ss_cell,
-                       s.ss_split + (size_t)s.rows * FS_MAXNB);
+                       s.ss_split + (size_t)s.rows * FS_MAXNB, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, list);
     hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
                        s.fs_fill, s.ss_flag, list, s.ss_l0);

@@ -147,6 +147,7 @@ struct SaScratch {
     uint32_t *fs_redo[2] = {nullptr, nullptr};   // [rows] copies of fs_lcnt, one per call parity (read by the speculative Huffman pass)
     uint32_t *fs_keep[2] = {nullptr, nullptr};   // [rows] 1 = the bucket sorter finished the block (the speculative stages' `only` mask)
     uint32_t *fs_dup = nullptr;                  // [rows] repeated 6-grams among the samples k_fs_hist looks at (text-likeness probe)
+    uint32_t *fs_zero = nullptr;                 // [rows] bucket that holds the word of suffix 0 (k_fs_part -> k_fs_sort_bwt: the BWT index is looked for there only)
     uint32_t  parity = 0;                        // set by the caller before sa_build_begin
     uint32_t *fs_nflag = nullptr;                // [4] blocks flagged by the bucket sorter; given up on by the sample sorter; listed for its second attempt
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}

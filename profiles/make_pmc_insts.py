@@ -85,6 +85,7 @@ def main():
                 e["launches"] = k["launches"]
                 if "SQ_LDS_BANK_CONFLICT" in p and p.get("SQ_LDS_IDX_ACTIVE"):
                     e["lds_bank_conflict_frac"] = round(p["SQ_LDS_BANK_CONFLICT"] / p["SQ_LDS_IDX_ACTIVE"], 3)
+                    e["SQ_LDS_IDX_ACTIVE"] = round(p["SQ_LDS_IDX_ACTIVE"] / (UNITS / 64.0), 2)     # LDS-busy cycles (summed over CUs) per 64 input bytes
                 if "SQ_WAVE_CYCLES" in p and p.get("SQ_WAVES"):
                     e["wave_cycles_per_wave"] = round(p["SQ_WAVE_CYCLES"] / p["SQ_WAVES"] * 4)   # SQ counts in quad-cycles... see note
                 per64[short] = e
