@@ -363,6 +363,153 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     }
 }
 
+// k_fs_part for the bucket sorter's own pass (no splitters), FSP2_T consecutive tiles of a block per workgroup.  The counters
+// put k_fs_part at 0.45 of the VALU issue rate, 0.19 of the scalar one and the LDS 0.38 busy -- nothing is saturated: a
+// tile's 12.7 us are a chain  flag + table + text from memory -> codes -> scan -> 512 global atomics with return -> scatter
+// -> stores, and four workgroups per CU do not cover its waits.  The loop over tiles lets
+//   * the symbol table and the block's flag arrive once per workgroup;
+//   * the text of tile t + 1 be requested before tile t is touched (six dwords per thread in registers), so it has the
+//     whole of tile t to arrive;
+//   * the global atomic of a (tile, bucket) be ISSUED before the words are scattered in LDS and CONSUMED after (the
+//     scatter needs the tile-local ranks only), with LDS-only barriers in between so that nobody waits for it early;
+//   * the stores of tile t retire under tile t + 1 (the prefetched text is taken out of its registers before they are issued:
+//     loads and stores share one counter, in order).
+#ifndef GLC_FSP2_T
+#define GLC_FSP2_T 4
+#endif
+constexpr int FSP2_T = GLC_FSP2_T;
+#ifndef GLC_FSP2_WAVES
+#define GLC_FSP2_WAVES 5
+#endif
+
+__device__ __forceinline__ void lds_only_barrier()
+{
+    // __syncthreads() carries a workgroup-scope fence: every wave would wait for ALL its outstanding memory operations,
+    // the prefetched text and the atomic in flight included
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(GLC_FSP2_WAVES, 8))) void k_fs_part2(const uint8_t *__restrict__ text, size_t stride, uint32_t n, uint32_t nbl,
+                                                     const uint2 *__restrict__ tab, uint64_t *__restrict__ keys, size_t kstride,
+                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
+                                                     uint32_t *__restrict__ zero_bucket)
+{
+    __shared__ uint32_t s_cnt[FS_MAXNB];
+    __shared__ uint16_t s_start[FS_MAXNB], s_gbase[FS_MAXNB];
+    __shared__ uint64_t s_w[FSP_TILE];
+    __shared__ uint2 s_tab[256];
+    __shared__ uint32_t s_tmp[FSP_NT / 64 + 1];
+    __shared__ uint32_t s_flagged;
+    uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_w);         // s_txt[k] = T[base - 1 + k]: dead before the first word is bucketed
+    uint32_t bx, by;
+    xcd_order(bx, by);                                         // a block's tiles on ONE XCD, back to back
+    const uint32_t b = by, tid = threadIdx.x;
+    const uint32_t ntiles = (n + FSP_TILE - 1) / FSP_TILE, tile0 = bx * FSP2_T;
+    if (tile0 >= ntiles) return;
+    const uint8_t *T = text + (size_t)b * stride;
+    if (tid == 0) s_flagged = flag[b];                         // flagged up front as text-like, or by a tile that ran before
+    if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
+    // text of a tile as the dwords of T[base - 1 ...] (unaligned 4-byte loads: global memory takes any alignment): dword
+    // q = r NT + tid of the 4112 staged bytes.  Only for inner tiles; the first and the last tile of a block take the byte loop.
+    uint32_t stg[3] = {0, 0, 0};
+    auto inner = [&](uint32_t tile) { const uint32_t base = tile * FSP_TILE; return base > 0 && base + FSP_TILE + 16 <= n; };
+    auto request = [&](uint32_t tile) {
+        const uint8_t *D = T + (size_t)tile * FSP_TILE - 1;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint32_t q = r * FSP_NT + tid;
+            const uint32_t qq = q < (FSP_TILE + 16) / 4 ? q : 0u;   // (every load is issued: a conditional one may sink to its use)
+            uint32_t v;
+            __builtin_memcpy(&v, D + 4 * (size_t)qq, 4);
+            stg[r] = v;
+        }
+    };
+    const uint32_t tend = min(ntiles, tile0 + FSP2_T);
+    bool have = false;                                         // stg holds the text of the tile about to be processed
+    if (inner(tile0)) { request(tile0); have = true; }
+    uint64_t *K = keys + (size_t)b * kstride;
+#pragma clang loop unroll(disable)
+    for (uint32_t tile = tile0; tile < tend; tile++) {
+        const uint32_t base = tile * FSP_TILE;
+        const bool edge = base + FSP_TILE + 16 > n;
+        if (tid < FS_MAXNB) s_cnt[tid] = 0;
+        if (have) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const uint32_t q = r * FSP_NT + tid;
+                if (q < (FSP_TILE + 16) / 4) reinterpret_cast<uint32_t *>(s_txt)[q] = stg[r];
+            }
+        } else {
+            for (uint32_t k = tid; k < FSP_TILE + 16; k += FSP_NT) {
+                const int64_t g = (int64_t)base - 1 + k;
+                s_txt[k] = g < 0 ? T[n - 1] : (g < (int64_t)n ? T[g] : (uint8_t)0);
+            }
+        }
+        lds_only_barrier();                                    // (stg is in LDS: its registers take the next tile's request)
+        const bool next_inner = tile + 1 < tend && inner(tile + 1);
+        if (next_inner) request(tile + 1);                     // in flight until this tile's words are in LDS
+        if (s_flagged) return;
+        // thread = 8 consecutive suffixes gi0 .. gi0+7; byte j of its 16 staged bytes is T[gi0 - 1 + j]
+        const uint32_t k0 = tid * FSP_ITEMS, gi0 = base + k0;
+        const uint2 qa = *reinterpret_cast<const uint2 *>(s_txt + k0), qb = *reinterpret_cast<const uint2 *>(s_txt + k0 + 8);
+        const uint32_t by4[4] = {qa.x, qa.y, qb.x, qb.y};
+#define FS_BYTE(j) ((by4[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
+        uint2 e[FSP_ITEMS + 5];                                // table entries of the 13 symbols the 8 codes share
+#pragma unroll
+        for (int k = 0; k < FSP_ITEMS + 5; k++) {
+            const uint2 t = s_tab[FS_BYTE(1 + k)];
+            e[k] = (edge && gi0 + k >= n) ? make_uint2(0u, 0u) : t;
+        }
+        uint64_t w[FSP_ITEMS];
+        uint32_t br[FSP_ITEMS];                                // bucket << 16 | rank inside (tile, bucket)
+#pragma unroll
+        for (int j = 0; j < FSP_ITEMS; j++) {
+            uint32_t y = e[j + 5].x;
+#pragma unroll
+            for (int d = 4; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
+            const uint64_t X = ((uint64_t)e[j].x << 32) + (uint64_t)e[j].y * y;
+            const uint32_t gi = gi0 + j;
+            w[j] = (X & ~FS_LOW_MASK) | ((uint64_t)gi << 8) | FS_BYTE(j);
+            const uint32_t bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
+            br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
+            if (j == 0 && gi == 0) zero_bucket[b] = bk;        // where the word of suffix 0 goes: k_fs_sort_bwt looks for the BWT index there only
+        }
+#undef FS_BYTE
+        lds_only_barrier();
+        uint32_t g = 0, c = 0;
+        {
+            c = tid < FS_MAXNB ? s_cnt[tid] : 0u;
+            const uint32_t start = block_excl_add_lds<FSP_NT>(c, s_tmp);
+            if (c) g = atomicAdd(&fill[(size_t)b * FS_MAXNB + tid], c);     // issued here, looked at behind the scatter
+            if (tid < FS_MAXNB) s_start[tid] = (uint16_t)start;
+        }
+        lds_only_barrier();                                    // (the staged text and the table reads are done: s_w takes the words)
+#pragma unroll
+        for (int j = 0; j < FSP_ITEMS; j++)
+            if (gi0 + j < n) s_w[s_start[br[j] >> 16] + (br[j] & 0xFFFFu)] = w[j];
+        if (c && g + c > FS_FILLMAX) { atomicOr(&flag[b], 1u); s_flagged = 1; }
+        if (tid < FS_MAXNB) s_gbase[tid] = (uint16_t)(g < FS_CAP ? g : FS_CAP);
+        if (next_inner) {                                      // the next tile's text has arrived before this tile's stores are issued
+#pragma unroll                                                 // (loads and stores share one in-order counter)
+            for (int r = 0; r < 3; r++) asm volatile("" : "+v"(stg[r]));
+        }
+        have = next_inner;
+        lds_only_barrier();
+        const uint32_t tile_n = min((uint32_t)FSP_TILE, n - base);
+#pragma unroll
+        for (int r = 0; r < FSP_ITEMS; r++) {
+            const uint32_t p = r * FSP_NT + tid;
+            if (p < tile_n) {
+                const uint64_t ww = s_w[p];
+                const uint32_t d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
+                const uint32_t off = (uint32_t)s_gbase[d] + (p - (uint32_t)s_start[d]);
+                if (off < FS_CAP) K[(size_t)d * FS_CAP + off] = ww;
+            }
+        }
+        lds_only_barrier();                                    // s_w is free for the next tile's text
+    }
+}
+
 // rank base of every bucket (exclusive scan of the fills); a bucket past its slot flags the block
 __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict__ fill, uint32_t *__restrict__ fbase,
                                                       uint32_t *__restrict__ flag, const uint32_t *__restrict__ list)
@@ -1525,6 +1672,13 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         const uint32_t nbk = nblk - b0 < step ? nblk - b0 : step;
         const double u = (double)n * nbk;
         pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
+        static const bool old_part = getenv("GLC_FS_PART_OLD") != nullptr;      // A/B: one tile per workgroup
+        if (!old_part)
+            hipLaunchKernelGGL(k_fs_part2, dim3(((n + FSP_TILE - 1) / FSP_TILE + FSP2_T - 1) / FSP2_T, nbk), dim3(FSP_NT), 0, st,
+                               text + (size_t)b0 * text_stride, text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256,
+                               s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
+                               s.fs_zero + b0);
+        else
         hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nbk), dim3(FSP_NT), 0, st, text + (size_t)b0 * text_stride,
                            text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
                            s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0, (const uint32_t *)nullptr,

@@ -94,6 +94,22 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t x, uint32_t *s_tmp, 
     return base + inc - x;
 }
 
+// block_excl_add with ONE barrier that orders LDS only (s_waitcnt lgkmcnt(0); s_barrier): global loads / atomics a
+// software-pipelined kernel has in flight stay in flight.  The caller guarantees s_tmp is not in use when it is entered.
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_add_lds(uint32_t x, uint32_t *s_tmp)
+{
+    constexpr int NW = NT / WAVE;
+    const unsigned w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint32_t inc = wave_incl_add(x);
+    if (l == 63) s_tmp[w] = inc;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) { const uint32_t v = s_tmp[i]; if ((unsigned)i < w) base += v; }
+    return base + inc - x;
+}
+
 // Workgroup exclusive prefix max (identity 0).
 template <int NT>
 __device__ __forceinline__ uint32_t block_excl_max(uint32_t x, uint32_t *s_tmp)
