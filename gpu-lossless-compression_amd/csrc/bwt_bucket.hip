@@ -738,21 +738,28 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
     const uint32_t b = gy, bk = gx, tid = threadIdx.x;
     if (tid == 0) { s_deep = flag[b]; s_wl = 0; }              // (one read: another bucket may flag the block meanwhile)
     for (uint32_t i = tid; i < FS_BINS / 2; i += FSS_NT) s_cp[i] = 0;
+    const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+    uint64_t w[FSS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < FSS_ITEMS; r++) w[r] = ~0ull;
+    // The first FSS_SPEC full rounds are requested BEFORE the bucket's fill is known: a bucket of an i.i.d.-like block holds
+    // 2048 +- 7 % words, so words 0 .. 1535 are (nearly) always there, and fill -> words was two memory latencies in a row at
+    // the head of every workgroup's chain.  A slot has FS_CAP words whatever its fill: reading past the fill is harmless, and
+    // such a round is never looked at (r <= full guards every use).
+    constexpr int FSS_SPEC = 3;
+#pragma unroll
+    for (int r = 1; r <= FSS_SPEC; r++) w[r] = K[(r - 1) * FSS_NT + tid];
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
     const uint32_t R0 = fbase[(size_t)b * FS_MAXNB + bk];
-    const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
     const uint32_t cc = c <= FS_FILLMAX ? c : 0u;              // (a fuller bucket has flagged its block in k_fs_scan)
     // item r of a thread: r = 0 -> word full * 512 + tid of the partial round (lanes tid < part), r >= 1 -> word
     // (r - 1) * 512 + tid of a full round (all lanes, r <= full)
     const uint32_t full = cc / FSS_NT, part = cc % FSS_NT;
     const bool v0 = tid < part;
     const uint32_t i0 = full * FSS_NT + tid;
-    uint64_t w[FSS_ITEMS];
-#pragma unroll
-    for (int r = 0; r < FSS_ITEMS; r++) w[r] = ~0ull;
     if (v0) w[0] = K[i0];
 #pragma unroll
-    for (int r = 1; r < FSS_ITEMS; r++)
+    for (int r = FSS_SPEC + 1; r < FSS_ITEMS; r++)
         if ((uint32_t)r <= full) w[r] = K[(r - 1) * FSS_NT + tid];
     if (tid < 4 && cc) s_w[cc + tid] = ~0ull;                  // what the rank step reads past the last bin compares as larger
     __syncthreads();
