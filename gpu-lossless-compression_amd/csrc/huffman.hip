@@ -169,6 +169,12 @@ __global__ __launch_bounds__(HB_NT) void k_huff_build(const uint32_t *__restrict
 }
 
 // grid (sub-blocks, blocks); 256 threads x 16 symbols
+// HP_SUBS consecutive 4096-symbol sub-blocks of a block per workgroup: the {code, length} table of the block arrives once,
+// and only the words a sub-block fills are cleared (its bit total is known from the scan before anything is ORed: a Zipf
+// sub-block fills ~910 of the 3600 words the worst case needs -- clearing all of them for every 4096 symbols, plus 2 KB of
+// table per 4 KB of symbols, was most of what the kernel did).
+constexpr uint32_t HP_SUBS = 4;
+
 __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ mtf, size_t mtf_stride, uint32_t n,
                                                    const uint32_t *__restrict__ codes,
                                                    const uint32_t *__restrict__ lens,
@@ -182,67 +188,72 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
     constexpr int SPT = HUFF_BLOCK / 256;                     // 16 symbols per thread
     constexpr int MAXW = HUFF_BLOCK * 28 / 32 + 16;            // code length <= 28 for <= 2^20+1 total count
     __shared__ uint2 s_cl[257];                                // {code, length}: one 8-byte LDS read per symbol
-    __shared__ uint32_t s_words[MAXW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_words[MAXW];
     __shared__ uint32_t s_tmp[8];
-    const uint32_t b = blockIdx.y, sub = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b = blockIdx.y, tid = threadIdx.x;
     if (only && !only[b]) return;
-    const uint32_t lo = sub * HUFF_BLOCK;
-    if (lo >= n) return;
-    const uint32_t cntb = min((uint32_t)HUFF_BLOCK, n - lo);
+    if (blockIdx.x * HP_SUBS * HUFF_BLOCK >= n) return;
     for (uint32_t i = tid; i < 257; i += 256) s_cl[i] = make_uint2(codes[(size_t)b * 257 + i], lens[(size_t)b * 257 + i]);
-    for (uint32_t i = tid; i < MAXW; i += 256) s_words[i] = 0;
-    __syncthreads();
-
-    const uint8_t *src = mtf + (size_t)b * mtf_stride + lo;
-    uint8_t sym[SPT];
-    const uint32_t i0 = tid * SPT;
-    if (i0 + SPT <= cntb && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(src + i0);
-        const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int j = 0; j < SPT; j++) sym[j] = (uint8_t)(qq[j >> 2] >> (8 * (j & 3)));
-    } else {
-#pragma unroll
-        for (int j = 0; j < SPT; j++) sym[j] = (i0 + j < cntb) ? src[i0 + j] : 0;
-    }
-    uint2 cl[SPT];                                             // read once, used by the bit count and by the merge
-    uint32_t mybits = 0;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        cl[j] = s_cl[sym[j]];
-        if (i0 + j >= cntb) cl[j] = make_uint2(0u, 0u);
-        mybits += cl[j].y;
-    }
-    uint32_t total = 0;
-    const uint32_t start = block_excl_add<256>(mybits, s_tmp, &total);
-
-    // merge, branch-free: `hi` is the word being filled (MSB first), `fill` its used bits.  A code of ln <= 28 bits goes
-    // in as the 64-bit value code << (64 - fill - ln): its upper half lands in `hi`, its lower half is the start of the
-    // next word, which becomes `hi` when the word is full.  (Pending bits kept right-aligned in a 64-bit accumulator
-    // needed a variable-length mask and a branch per symbol: ~25 VALU per symbol against ~12.)
-    uint32_t wi = start >> 5, fill = start & 31, hi = 0;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        const uint32_t ln = cl[j].y;                           // 0 (and code 0) past the end of the block: a no-op
-        const uint64_t V = (uint64_t)cl[j].x << ((64u - fill - ln) & 63u);
-        hi |= (uint32_t)(V >> 32);
-        const uint32_t nf = fill + ln;
-        const bool full = nf >= 32;
-        if (full) atomicOr(&s_words[wi], hi);
-        wi += full ? 1u : 0u;
-        hi = full ? (uint32_t)V : hi;
-        fill = nf & 31u;
-    }
-    if (fill > 0 && mybits > 0) atomicOr(&s_words[wi], hi);
-    __syncthreads();
-
-    const uint32_t nwords = (total + 31) / 32;
-    const uint32_t off = d_offsets[(size_t)b * offset_stride + sub];
     const uint64_t base = block_off ? block_off[b] : 0ull;
-    if (base + off + 1 + nwords > capacity_words) return;                // flagged by k_huff_build / k_compact_offsets
-    uint32_t *dst = d_comp + (block_off ? (size_t)base : (size_t)b * comp_stride) + off;
-    if (tid == 0) dst[0] = nwords;
-    for (uint32_t i = tid; i < nwords; i += 256) dst[1 + i] = s_words[i];
+    for (uint32_t sub = blockIdx.x * HP_SUBS; sub < (blockIdx.x + 1) * HP_SUBS; sub++) {
+        const uint32_t lo = sub * HUFF_BLOCK;
+        if (lo >= n) break;
+        const uint32_t cntb = min((uint32_t)HUFF_BLOCK, n - lo);
+        __syncthreads();                                       // the table is in place / the previous sub-block's words have been read
+
+        const uint8_t *src = mtf + (size_t)b * mtf_stride + lo;
+        uint8_t sym[SPT];
+        const uint32_t i0 = tid * SPT;
+        if (i0 + SPT <= cntb && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(src + i0);
+            const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < SPT; j++) sym[j] = (uint8_t)(qq[j >> 2] >> (8 * (j & 3)));
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) sym[j] = (i0 + j < cntb) ? src[i0 + j] : 0;
+        }
+        uint2 cl[SPT];                                         // read once, used by the bit count and by the merge
+        uint32_t mybits = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            cl[j] = s_cl[sym[j]];
+            if (i0 + j >= cntb) cl[j] = make_uint2(0u, 0u);
+            mybits += cl[j].y;
+        }
+        uint32_t total = 0;
+        const uint32_t start = block_excl_add<256>(mybits, s_tmp, &total);
+        const uint32_t nwords = (total + 31) / 32;
+        for (uint32_t i = tid; 4 * i < nwords + 1; i += 256) reinterpret_cast<uint4 *>(s_words)[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+
+        // merge, branch-free: `hi` is the word being filled (MSB first), `fill` its used bits.  A code of ln <= 28 bits goes
+        // in as the 64-bit value code << (64 - fill - ln): its upper half lands in `hi`, its lower half is the start of the
+        // next word, which becomes `hi` when the word is full.  (Pending bits kept right-aligned in a 64-bit accumulator
+        // needed a variable-length mask and a branch per symbol: ~25 VALU per symbol against ~12.  Every symbol ORing its own
+        // code into the two words it spans -- no "full" test at all -- measured 0.72 against 0.71 ms per GiB: not this.)
+        uint32_t wi = start >> 5, fill = start & 31, hi = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const uint32_t ln = cl[j].y;                       // 0 (and code 0) past the end of the block: a no-op
+            const uint64_t V = (uint64_t)cl[j].x << ((64u - fill - ln) & 63u);
+            hi |= (uint32_t)(V >> 32);
+            const uint32_t nf = fill + ln;
+            const bool full = nf >= 32;
+            if (full) atomicOr(&s_words[wi], hi);
+            wi += full ? 1u : 0u;
+            hi = full ? (uint32_t)V : hi;
+            fill = nf & 31u;
+        }
+        if (fill > 0 && mybits > 0) atomicOr(&s_words[wi], hi);
+        __syncthreads();
+
+        const uint32_t off = d_offsets[(size_t)b * offset_stride + sub];
+        if (base + off + 1 + nwords > capacity_words) continue;          // flagged by k_huff_build / k_compact_offsets
+        uint32_t *dst = d_comp + (block_off ? (size_t)base : (size_t)b * comp_stride) + off;
+        if (tid == 0) dst[0] = nwords;
+        for (uint32_t i = tid; i < nwords; i += 256) dst[1 + i] = s_words[i];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -410,7 +421,7 @@ hipError_t huff_pack(hipStream_t st, const uint8_t *mtf, size_t mtf_stride, uint
 {
     const uint32_t nsub = (n + HUFF_BLOCK - 1) / HUFF_BLOCK;
     const int pi = s.prof ? s.prof->begin(PROF_HUFF_PACK, st) : -1;
-    hipLaunchKernelGGL(k_huff_pack, dim3(nsub, nblk), dim3(256), 0, st, mtf, mtf_stride, n, s.codes, s.lens,
+    hipLaunchKernelGGL(k_huff_pack, dim3((nsub + HP_SUBS - 1) / HP_SUBS, nblk), dim3(256), 0, st, mtf, mtf_stride, n, s.codes, s.lens,
                        d_offsets, offset_stride, d_compressed, comp_stride_words,
                        (uint64_t)(d_block_off ? capacity_words : comp_stride_words), only, d_block_off);
     if (pi >= 0) s.prof->end(pi, (double)n * nblk, st);
