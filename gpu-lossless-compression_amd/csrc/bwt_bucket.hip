@@ -796,7 +796,13 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
     }
     __syncthreads();
     {
-        auto scatter = [&](int r) { s_w[s16[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] = w[r]; };
+        // in LDS a word is [code bits 28..59 : 32 | the word's low dword (code bits 28..31, index, BWT byte) : 32]: the rank step
+        // compares HIGH DWORDS only -- four 4-byte reads where the whole words were four 8-byte reads and a funnel shift each
+        auto scatter = [&](int r) {
+            const uint32_t lo = (uint32_t)w[r], hi = (uint32_t)(w[r] >> 32);
+            s_w[s16[(uint32_t)(w[r] >> bshift) & (FS_BINS - 1)] + rk[r]] =
+                ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 28) << 32) | lo;
+        };
         if (v0) scatter(0);
 #pragma unroll
         for (int r = 1; r < FSS_ITEMS; r++)
@@ -815,15 +821,14 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
         auto rank = [&](int r, uint32_t p) {
             const uint64_t wv = s_w[p];
             w[r] = wv;
-            const uint32_t key = (uint32_t)(wv >> 28);         // inside a bin only the low 32 bits of the code can differ
-            const uint32_t bin = (uint32_t)(wv >> bshift) & (FS_BINS - 1);
+            const uint32_t key = (uint32_t)(wv >> 32);         // inside a bin only the low 32 bits of the code can differ
+            const uint32_t bin = (key >> (bshift - 28)) & (FS_BINS - 1);
             const uint32_t gs = s16[bin], ge = s16[bin + 1];
             uint32_t less = 0, eqt = 0;
-            const uint2 *B = reinterpret_cast<const uint2 *>(s_w) + gs;
+            const uint32_t *B = reinterpret_cast<const uint32_t *>(s_w) + 2 * gs + 1;
 #pragma unroll
             for (uint32_t t = 0; t < 4; t++) {
-                const uint2 wq = B[t];
-                const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
+                const uint32_t kq = B[2 * t];
                 less += kq < key ? 1u : 0u;
                 eqt += kq == key ? 1u : 0u;
             }
@@ -836,8 +841,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
                         uint32_t ls = 0, eq = 0, eqb = 0;
 #pragma clang loop unroll(disable)
                         for (uint32_t q = gs; q < ge; q++) {
-                            const uint2 wq = reinterpret_cast<const uint2 *>(s_w)[q];
-                            const uint32_t kq = __builtin_amdgcn_alignbit(wq.y, wq.x, 28);
+                            const uint32_t kq = reinterpret_cast<const uint32_t *>(s_w)[2 * q + 1];
                             ls += kq < key; eq += kq == key; eqb += (kq == key) & (q < p);
                         }
                         at = gs + ls;
