@@ -77,7 +77,8 @@ def issue_fractions(name, pmc_per64, census, issue, per_launch_units, avg_ms):
         q = pmc_per64.get(key)
         if q:
             pk = q if pk is None else {c: pk.get(c, 0) + q.get(c, 0) for c in set(pk) | set(q) if isinstance(q.get(c, 0), (int, float))}
-            cz = census.get(key) or next((v for k2, v in census.items() if k2.split("<")[0] == key), None)
+            ck = {"k_fs_part": "k_fs_part2", "k_fs_sort": "k_fs_sort_bwt"}.get(key, key)   # profile slot -> the kernel that fills it
+            cz = census.get(ck) or next((v for k2, v in census.items() if k2.split("<")[0] == ck), None)
             f = cz["valu_fast_frac"] if cz and cz.get("valu_fast_frac") is not None else 0.0
             fast += f * q.get("SQ_INSTS_VALU", 0.0)
             nfast += q.get("SQ_INSTS_VALU", 0.0)
