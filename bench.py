@@ -467,6 +467,35 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
             if name == "text":
                 one = d_in[:n].clone()
             del d_in, out, back
+    # the cliff, measured: blocks whose repeats are deeper than the sample sorter's cap (~500 symbols) take the general
+    # sorter (LSD radix passes + prefix doubling, host-driven rounds).  8 blocks: a 4 KiB random page repeated, all-equal
+    # bytes, a two-byte period, text with a 2000-byte phrase pasted in every 16 KiB.
+    import numpy as np
+    rng = np.random.default_rng(7)
+    deep = [np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), n // 4096), np.full(n, 65, dtype=np.uint8),
+            np.tile(np.frombuffer(b"ab", dtype=np.uint8), n // 2)]
+    t = one.cpu().numpy().copy()
+    for o in range(0, n - 2000, 16384):
+        t[o:o + 2000] = t[:2000]
+    deep.append(t)
+    d_deep = torch.from_numpy(np.concatenate(deep + deep)).to(dev)
+    nd = len(deep) * 2
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=nd) as plan:
+        outd = glc.compress_batch(plan, d_deep, n, nd)
+        plan.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        glc.compress_batch_into(plan, d_deep, n, nd, outd)
+        plan.synchronize()
+        dt = time.perf_counter() - t0
+        f1, f2 = plan.last_sort_stats()
+        back = glc.decompress_batch(plan, outd, n, nd)
+        torch.cuda.synchronize()
+        out_res["deep_repeats"] = {"GBps": round(n * nd / dt / 1e9, 3), "ms_per_block": round(dt * 1e3 / nd, 3), "blocks": nd,
+                                   "blocks_left_by_sample_sorter": f2, "round_trip_ok": bool(torch.equal(back, d_deep)),
+                                   "what": "repeats deeper than the sample sorter's ~500-symbol cap (repeated 4 KiB page, all-equal bytes, "
+                                           "two-byte period, text with a 2000-byte phrase every 16 KiB): the general sorter's cliff"}
+    del d_deep, outd, back
     out_res["single_call_text"] = leg_single_call(torch, glc, dev, one, what="text")
     out_res["note"] = ("cudppCompress path (glcCompressBatch, one plan, %d distinct synthetic 1 MiB blocks per call); best of %d calls "
                        "incl. the host wait" % (rows, iters))
@@ -679,6 +708,8 @@ def compact_line(res, details_path):
                            "text_ms": (tl.get("single_call_text") or {}).get("ms_per_call_median"), "host_syncs_in_call": sc.get("host_syncs_per_call")}
     if tl:
         line["text_like"] = {k: pick(tl[k], ["GBps", "ratio", "distinct_blocks", "blocks_left_by_sample_sorter", "round_trip_ok"]) for k in ("text", "log") if k in tl}
+        if tl.get("deep_repeats"):
+            line["text_like"]["deep_repeats"] = pick(tl["deep_repeats"], ["GBps", "ms_per_block", "blocks", "blocks_left_by_sample_sorter", "round_trip_ok"])
     cz = res.get("culzss") or {}
     if cz:
         line["culzss"] = pick(cz, ["encode_GBps", "decode_GBps", "encode_with_pcie_staging_GBps", "compression_ratio", "parity", "roundtrip"])
