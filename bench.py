@@ -468,7 +468,7 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
                 one = d_in[:n].clone()
             del d_in, out, back
     # the cliff, measured: blocks whose repeats are deeper than the sample sorter's cap (~500 symbols) take the general
-    # sorter (LSD radix passes + prefix doubling, host-driven rounds).  8 blocks: a 4 KiB random page repeated, all-equal
+    # sorter (LSD radix passes + prefix doubling, host-driven rounds).  64 blocks, 16 of each: a 4 KiB random page repeated, all-equal
     # bytes, a two-byte period, text with a 2000-byte phrase pasted in every 16 KiB.
     import numpy as np
     rng = np.random.default_rng(7)
@@ -478,8 +478,8 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
     for o in range(0, n - 2000, 16384):
         t[o:o + 2000] = t[:2000]
     deep.append(t)
-    d_deep = torch.from_numpy(np.concatenate(deep + deep)).to(dev)
-    nd = len(deep) * 2
+    d_deep = torch.from_numpy(np.concatenate(deep * 16)).to(dev)
+    nd = len(deep) * 16
     with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=nd) as plan:
         outd = glc.compress_batch(plan, d_deep, n, nd)
         plan.synchronize()
