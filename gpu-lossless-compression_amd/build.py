@@ -32,9 +32,19 @@ def _header_mtime():
     return max(m, os.path.getmtime(os.path.abspath(__file__)))
 
 
+def have_rccl():
+    """the multi-GPU exchange (csrc/exchange.cpp) needs RCCL: header + library.  A single-GPU install without it still gets
+    the whole compression path; the exchange entry points are then simply not exported (GLC_NO_RCCL=1 forces that)."""
+    if os.environ.get("GLC_NO_RCCL") == "1":
+        return False
+    return os.path.exists("/opt/rocm/include/rccl/rccl.h") and any(
+        os.path.exists(os.path.join(d, "librccl.so")) for d in ("/opt/rocm/lib", "/opt/rocm/lib64"))
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    rccl = have_rccl()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s)) and (rccl or s != "exchange.cpp")]
     os.makedirs(OBJ, exist_ok=True)
     hm = _header_mtime()
     jobs = []
@@ -57,7 +67,7 @@ def build(force=False, verbose=False):
                 sys.stderr.write(r.stdout + r.stderr)
                 raise RuntimeError("hipcc failed compiling " + src)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + \
-          [os.path.join(OBJ, s + ".o") for s in srcs] + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+          [os.path.join(OBJ, s + ".o") for s in srcs] + (["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"] if rccl else [])
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
