@@ -686,7 +686,7 @@ def compact_line(res, details_path):
                       "dtype", "data"])
     line["vs_baseline"] = res.get("vs_baseline")
     cfg = res.get("config", {})
-    line["config"] = pick(cfg, ["workload", "block_bytes", "blocks_per_gpu", "batch_rows", "output_layout", "stage_pipelining", "parallelism",
+    line["config"] = pick(cfg, ["workload", "block_bytes", "blocks_per_gpu", "batch_rows", "output_layout", "stage_pipelining", "drain_between_steps", "parallelism",
                                 "blocks_left_by_bucket_sorter", "blocks_left_by_sample_sorter"])
     if "output_layout" in line["config"]:
         line["config"]["output_layout"] = line["config"]["output_layout"].split(":")[0]
@@ -774,6 +774,7 @@ def main():
     ap.add_argument("--no-overlap-pass", action="store_true",
                     help="no stage overlap anywhere and no separate profile pass: the timed region itself is profiled "
                          "(profiles/collect.sh, tools/exp/pmc_insts.sh: keeps rocprofv3's per-kernel averages equal to the bench's)")
+    ap.add_argument("--sync-each-step", action="store_true", help="drain the plan after every step of the timed region (rounds 1-3)")
     ap.add_argument("--details", default=None,
                     help="file for the full result (per-kernel tables, every leg's sub-figures); default gpurun_out/bench_full.json "
                          "when that directory exists, else no file")
@@ -899,6 +900,8 @@ def main():
             return compact[o:o + size]
         return out["words"][b * stride: b * stride + size]
 
+    keep_queued = [False]         # timed region, compact layout, one encoding thread: a step does not drain the plan
+
     def enc_worker(t, nt):
         torch.cuda.set_device(dev)                            # the HIP device is per host thread
         pl = plans[t]
@@ -908,12 +911,13 @@ def main():
             st2 = pl.last_sort_stats()
             flagged[0] += st2[0]
             flagged[1] += st2[1]
-        pl.synchronize()
+        if not keep_queued[0]:
+            pl.synchronize()
 
     def encode_all():
         run_threads(enc_worker, args.enc_threads)
         if use_compact:
-            return                                            # (enc_worker has waited for its plan)
+            return                                            # (enc_worker has waited for its plan, or the timed loop will)
         rc = L.glcCompactStreams(plan.handle, out["words"].data_ptr(), stride, out["size"].data_ptr(), nblocks,
                                  compact.data_ptr(), compact_off.data_ptr())
         if rc != 0:
@@ -1007,11 +1011,18 @@ def main():
     flagged[0] = flagged[1] = 0
     barrier()
     step_s = []
+    # A step is one pass over the per-GPU input.  Between the K steps the plan is NOT drained (a caller that streams batches
+    # never does: each call's own wait -- the sorter's flagged-block count -- keeps the host one batch ahead, no more); the
+    # wait for everything queued is inside the bracket, after the last step.  --sync-each-step restores rounds 1-3's drain.
+    keep_queued[0] = use_compact and use_pipe and args.enc_threads <= 1 and not args.sync_each_step and not (world > 1 and args.with_gather)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
         gathered = step()
         step_s.append(time.perf_counter() - ts)
+    for pl in plans:
+        pl.synchronize()                                      # (raises if a kernel faulted or a block overflowed the format)
+    keep_queued[0] = False
     barrier()
     t1 = time.perf_counter()
     no_overlap_gbps = None
@@ -1302,6 +1313,8 @@ def main():
                                          3: "bucket sorter, then general sorter", 4: "sample sorter first"}[args.sorter],
                        "blocks_left_by_bucket_sorter": flagged[0], "blocks_left_by_sample_sorter": flagged[1],
                        "stage_pipelining": {"encode": bool(use_pipe), "decode": not args.no_dec_pipeline},
+                       "drain_between_steps": not (use_compact and use_pipe and args.enc_threads <= 1 and not args.sync_each_step
+                                                   and not (world > 1 and args.with_gather)),
                        "parallelism": "blocks round-robin over %d GPU(s), no data-path collective" % world},
             "per_rank_GBps": [round(v, 3) for v in per_rank_gbps],
             "compression_ratio": round(ratio, 4),
