@@ -468,11 +468,13 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
                 one = d_in[:n].clone()
             del d_in, out, back
     # the cliff, measured: blocks whose repeats are deeper than the sample sorter's cap (~500 symbols) take the general
-    # sorter (LSD radix passes + prefix doubling, host-driven rounds).  64 blocks, 16 of each: a 4 KiB random page repeated, all-equal
-    # bytes, a two-byte period, text with a 2000-byte phrase pasted in every 16 KiB.
+    # sorter (LSD radix passes + prefix doubling, host-driven rounds).  64 blocks, 16 of each: a 4 KiB random page repeated, one
+    # byte repeated up to the last position, a two-byte period, text with a 2000-byte phrase pasted in every 16 KiB.
     import numpy as np
     rng = np.random.default_rng(7)
-    deep = [np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), n // 4096), np.full(n, 65, dtype=np.uint8),
+    onebyte = np.full(n, 65, dtype=np.uint8)
+    onebyte[-1] = 66                                          # (a block of ONE symbol is finished by k_fs_const: no cliff there any more)
+    deep = [np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), n // 4096), onebyte,
             np.tile(np.frombuffer(b"ab", dtype=np.uint8), n // 2)]
     t = one.cpu().numpy().copy()
     for o in range(0, n - 2000, 16384):
@@ -493,8 +495,8 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
         torch.cuda.synchronize()
         out_res["deep_repeats"] = {"GBps": round(n * nd / dt / 1e9, 3), "ms_per_block": round(dt * 1e3 / nd, 3), "blocks": nd,
                                    "blocks_left_by_sample_sorter": f2, "round_trip_ok": bool(torch.equal(back, d_deep)),
-                                   "what": "repeats deeper than the sample sorter's ~500-symbol cap (repeated 4 KiB page, all-equal bytes, "
-                                           "two-byte period, text with a 2000-byte phrase every 16 KiB): the general sorter's cliff"}
+                                   "what": "repeats deeper than the sample sorter's ~500-symbol cap (repeated 4 KiB page, one byte repeated up to the "
+                                           "last position, two-byte period, text with a 2000-byte phrase every 16 KiB): the general sorter's cliff"}
     del d_deep, outd, back
     out_res["single_call_text"] = leg_single_call(torch, glc, dev, one, what="text")
     out_res["note"] = ("cudppCompress path (glcCompressBatch, one plan, %d distinct synthetic 1 MiB blocks per call); best of %d calls "

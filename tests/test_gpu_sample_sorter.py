@@ -55,7 +55,9 @@ CASES = {
     "dna": (lambda: np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(23).integers(0, 4, N)], 1, 0),
     "text_then_zipf": (lambda: np.concatenate([datagen.text_bytes(N // 2, seed=24), datagen.zipf_bytes(N // 2, seed=25)]), 1, 0),
     # beyond the depth cap of the tier (~500 symbols past the common prefix of a bucket): the general sorter takes over
-    "zeros": (lambda: np.zeros(N, dtype=np.uint8), 1, 1),
+    # (a block of ONE symbol is no tier's business any more: k_fs_const writes its rows -- see test_constant_blocks)
+    "zeros": (lambda: np.zeros(N, dtype=np.uint8), 0, 0),
+    "period_1_then_one_byte": (lambda: np.concatenate([np.zeros(N - 1, dtype=np.uint8), np.ones(1, dtype=np.uint8)]), 1, 1),
     "period_3": (lambda: np.tile(np.frombuffer(b"abc", dtype=np.uint8), N // 3 + 1)[:N], 1, 1),
     "chunk_repeated_16x": (lambda: np.tile(np.random.default_rng(9).integers(0, 256, N // 16, dtype=np.uint8), 16), 1, 1),
     "text_with_a_long_run": (lambda: np.concatenate([datagen.text_bytes(N // 2, seed=26), np.full(6000, 32, dtype=np.uint8),
@@ -87,7 +89,7 @@ def test_sample_sorter_cases(glc, ctx, cuda, name):
         plan.set_sorter(4)                                     # sample sorter first (the caller's hint): same bytes, no attempt
         g4, i4 = _bwt(glc, plan, torch, x)
         assert int(i4[0]) == widx and np.array_equal(g4, want), "%s with the sample sorter first" % name
-        assert plan.last_sort_stats() == (1, flagged2)
+        assert plan.last_sort_stats() == ((1, flagged2) if name != "zeros" else (0, 0))
         plan.set_sorter(0)
         g0, i0 = _bwt(glc, plan, torch, x)                     # and the plan is reusable afterwards
         assert int(i0[0]) == widx and np.array_equal(g0, want)
@@ -116,7 +118,7 @@ def test_sample_sorter_mixed_batch(glc, ctx, cuda):
     with glc.Plan(ctx, glc.CUDPP_BWT, N, rows=len(blocks)) as plan:
         for rep in range(2):                                   # twice: scratch of the first call must not leak into the second
             got, gidx = _bwt(glc, plan, torch, x, rows=len(blocks))
-            assert plan.last_sort_stats() == (6, 2)
+            assert plan.last_sort_stats() == (5, 1)             # (the all-zero block is finished by k_fs_const, not by a tier)
             for i, blk in enumerate(blocks):
                 want, widx = O.bwt(blk)
                 assert int(gidx[i]) == widx and np.array_equal(got[i * N:(i + 1) * N], want), "block %d (call %d)" % (i, rep)
@@ -271,4 +273,46 @@ def test_bucket_past_its_slot_gets_a_second_attempt(glc, cuda):
         for i, b in enumerate((others[0], blk, others[1])):
             want, idx = O.bwt(b)
             assert np.array_equal(got[i * n:(i + 1) * n], want) and int(d_idx[i].item()) == idx, i
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, 65536, 1048576])
+def test_constant_blocks(glc, ctx, cuda, n):
+    """a block of one symbol: BWT = the symbol n times, index n - 1, SA = n-1 .. 0, written by k_fs_const -- no tier runs
+    (it used to be every tier's worst case: 1.3 ms per 1 MiB block on the general sorter).  Alone, under every sorter
+    mode that goes through the bucket sorter's front end, and inside a batch whose other blocks must not notice."""
+    import torch
+    for sym in (0, 65, 255):
+        x = np.full(n, sym, dtype=np.uint8)
+        want, widx = O.bwt(x)
+        assert widx == n - 1 and np.array_equal(want, x)
+        with glc.Plan(ctx, glc.CUDPP_BWT, n, rows=1) as plan:
+            for mode in (0, 3, 4):
+                plan.set_sorter(mode)
+                got, gidx = _bwt(glc, plan, torch, x)
+                assert int(gidx[0]) == widx and np.array_equal(got, want), (n, sym, mode)
+                assert plan.last_sort_stats() == (0, 0), (n, sym, mode)
+    if n >= 4096:
+        blocks = [datagen.zipf_bytes(n, seed=61), np.full(n, 7, dtype=np.uint8), datagen.text_bytes(n, seed=62), np.zeros(n, dtype=np.uint8)]
+        x = np.concatenate(blocks)
+        with glc.Plan(ctx, glc.CUDPP_BWT, n, rows=4) as plan:
+            got, gidx = _bwt(glc, plan, torch, x, rows=4)
+            for i, blk in enumerate(blocks):
+                want, widx = O.bwt(blk)
+                assert int(gidx[i]) == widx and np.array_equal(got[i * n:(i + 1) * n], want), i
+        with glc.Plan(ctx, glc.CUDPP_SA, n, rows=1) as plan:                   # cudppSuffixArray: out[0] = n, out[1 ..] = SA
+            d_in = torch.from_numpy(np.full(n, 9, dtype=np.uint8)).to(cuda)
+            d_out = torch.zeros(n + 1, dtype=torch.int32, device=cuda)
+            assert glc.lib().cudppSuffixArray(plan.handle, d_in.data_ptr(), d_out.data_ptr(), n) == 0
+            plan.synchronize()
+            assert np.array_equal(d_out.cpu().numpy()[1:], np.arange(n - 1, -1, -1, dtype=np.int32))
+        with glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=2) as plan:             # through the whole pipeline and back
+            two = torch.from_numpy(np.concatenate([np.zeros(n, dtype=np.uint8), datagen.zipf_bytes(n, seed=63)])).to(cuda)
+            out = glc.compress_batch(plan, two, n, 2)
+            plan.synchronize()
+            w0 = O.compress(np.zeros(n, dtype=np.uint8))
+            assert int(out["bwt_index"][0].item()) == w0["bwt_index"] and int(out["size"][0].item()) == w0["size"]
+            assert np.array_equal(out["words"][: w0["size"]].cpu().numpy().view(np.uint32), w0["words"])
+            back = glc.decompress_batch(plan, out, n, 2)
+            plan.synchronize()
+            assert torch.equal(back, two)
 
