@@ -473,7 +473,7 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
     import numpy as np
     rng = np.random.default_rng(7)
     onebyte = np.full(n, 65, dtype=np.uint8)
-    onebyte[-1] = 66                                          # (a block of ONE symbol is finished by k_fs_const: no cliff there any more)
+    onebyte[-1] = 66                                          # (a block of ONE symbol is finished by k_fs_tables: no cliff there any more)
     deep = [np.tile(rng.integers(0, 256, 4096, dtype=np.uint8), n // 4096), onebyte,
             np.tile(np.frombuffer(b"ab", dtype=np.uint8), n // 2)]
     t = one.cpu().numpy().copy()

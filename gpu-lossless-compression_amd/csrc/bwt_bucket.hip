@@ -137,11 +137,13 @@ __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ tex
 }
 
 // {C, p} scaled to 2^32.  floor() on both keeps C[s] + p[s] <= C[s+1], which is what makes the code monotone.
-constexpr uint32_t FS_DONE = 8u;                    // flag value: the block is finished (a constant block: k_fs_const wrote its rows)
+constexpr uint32_t FS_DONE = 8u;                    // flag value: the block is finished (a constant block: k_fs_tables wrote its rows)
 
 __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ hist, uint32_t n,
                                                    uint2 *__restrict__ tab, const uint32_t *__restrict__ dup,
-                                                   uint32_t *__restrict__ flag)
+                                                   uint32_t *__restrict__ flag, const uint8_t *__restrict__ text, size_t stride,
+                                                   uint8_t *__restrict__ bwt_out, size_t bwt_stride, int *__restrict__ d_index,
+                                                   uint32_t *__restrict__ sa_out, size_t sa_stride)
 {
     __shared__ uint32_t s_tmp[5];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
@@ -150,35 +152,32 @@ __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ 
     // index row is n - 1.  Left to the tiers it is their worst case -- every suffix ties with every other for the whole
     // block: bucket overflow, the sample sorter's depth cap, then ~20 prefix-doubling rounds of the general sorter (1.3 ms
     // where a Zipf block takes 0.012).  FS_DONE overrides whatever the flag was (text-likeness, a caller's "sample sorter
-    // first"): every tier skips a flagged block, and k_fs_finish does not list this one for anybody.
+    // first"): every tier skips a flagged block, and k_fs_finish does not list this one for anybody.  Its rows are written
+    // right here, by this workgroup (a kernel of its own was one more launch in every call's chain).
     const bool constant = __syncthreads_or((int)(h == n)) != 0;
     if (tid == 0) {
         if (constant) flag[b] = FS_DONE;
         else if (dup[b] >= FS_DUP_FLAG) flag[b] = 1u;          // text-like (see k_fs_hist): straight to the sample sorter
     }
+    if (constant) {
+        const uint32_t sym = text[(size_t)b * stride];
+        const uint32_t v = sym * 0x01010101u;
+        if (bwt_out) {
+            uint8_t *O = bwt_out + (size_t)b * bwt_stride;
+            const uint32_t head = min(n, (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 15u)) & 15u));
+            const uint32_t nvec = (n - head) / 16;
+            for (uint32_t i = tid; i < head; i += 256) O[i] = (uint8_t)sym;
+            for (uint32_t i = tid; i < nvec; i += 256) reinterpret_cast<uint4 *>(O + head)[i] = make_uint4(v, v, v, v);
+            for (uint32_t i = head + nvec * 16 + tid; i < n; i += 256) O[i] = (uint8_t)sym;
+        }
+        if (sa_out) for (uint32_t i = tid; i < n; i += 256) sa_out[(size_t)b * sa_stride + i] = n - 1 - i;
+        if (d_index && tid == 0) d_index[b] = (int)(n - 1);
+        return;                                                // (uniform; the table of a flagged block is never read)
+    }
     const uint32_t c = block_excl_add<256>(h, s_tmp);
     const uint64_t C32 = ((uint64_t)c << 32) / n, P32 = ((uint64_t)h << 32) / n;
     tab[(size_t)b * 256 + tid] = make_uint2((uint32_t)(C32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : C32),
                                             (uint32_t)(P32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : P32));
-}
-
-// the rows of a constant block (see k_fs_tables): BWT = the symbol n times, index n - 1, SA = n-1 .. 0
-__global__ __launch_bounds__(256) void k_fs_const(const uint32_t *__restrict__ flag, const uint8_t *__restrict__ text, size_t stride,
-                                                  uint32_t n, uint8_t *__restrict__ bwt_out, size_t bwt_stride,
-                                                  int *__restrict__ d_index, uint32_t *__restrict__ sa_out, size_t sa_stride)
-{
-    const uint32_t b = blockIdx.y;
-    if (flag[b] != FS_DONE) return;
-    const uint32_t sym = text[(size_t)b * stride];
-    const uint32_t v = sym * 0x01010101u;
-    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 16;
-    if (bwt_out) {
-        uint8_t *O = bwt_out + (size_t)b * bwt_stride;
-        if (i0 + 16 <= n && ((reinterpret_cast<uintptr_t>(O) + i0) & 15) == 0) *reinterpret_cast<uint4 *>(O + i0) = make_uint4(v, v, v, v);
-        else for (uint32_t i = i0; i < n && i < i0 + 16; i++) O[i] = (uint8_t)sym;
-    }
-    if (sa_out) for (uint32_t i = i0; i < n && i < i0 + 16; i++) sa_out[(size_t)b * sa_stride + i] = n - 1 - i;
-    if (d_index && blockIdx.x == 0 && threadIdx.x == 0) d_index[b] = (int)(n - 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -1021,7 +1020,7 @@ __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint3
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nblk) {
-        const uint32_t f = (flag[b] && flag[b] != FS_DONE) ? n : 0u;    // (FS_DONE: a constant block, finished by k_fs_const)
+        const uint32_t f = (flag[b] && flag[b] != FS_DONE) ? n : 0u;    // (FS_DONE: a constant block, finished by k_fs_tables)
         lcnt[b] = f;
         redo[b] = f;
         keep[b] = f ? 0u : 1u;
@@ -1695,9 +1694,8 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
                        s.fs_hist, s.fs_dup);
     if (pi >= 0) s.prof->end(pi, units, st);
-    hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab, s.fs_dup, s.fs_flag);
-    hipLaunchKernelGGL(k_fs_const, dim3((n + 4095) / 4096, nblk), dim3(256), 0, st, s.fs_flag, text, text_stride, n, bwt_out, bwt_stride,
-                       d_index, sa_out, (size_t)s.nmax);
+    hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab, s.fs_dup, s.fs_flag, text, text_stride,
+                       bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     if (s.skip_tier1) {
         // most blocks of the plan's previous call were flagged: no attempt, every block goes to the sample sorter
         hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,

@@ -47,7 +47,7 @@ CASES = {
     "chunk_repeated_16x": (lambda: np.tile(np.random.default_rng(9).integers(0, 256, N // 16, dtype=np.uint8), 16), True),
     "text": (lambda: datagen.text_bytes(N), True),
     "log": (lambda: datagen.log_bytes(N), True),
-    "zeros": (lambda: np.zeros(N, dtype=np.uint8), False),               # one symbol: finished by k_fs_const, no tier runs
+    "zeros": (lambda: np.zeros(N, dtype=np.uint8), False),               # one symbol: finished by k_fs_tables, no tier runs
     "zeros_but_one": (lambda: np.concatenate([np.zeros(N - 1, dtype=np.uint8), np.ones(1, dtype=np.uint8)]), True),
     "run_inside_random": (lambda: np.concatenate([np.random.default_rng(10).integers(0, 256, N // 2, dtype=np.uint8),
                                                   np.full(5000, 7, dtype=np.uint8),

@@ -55,7 +55,7 @@ CASES = {
     "dna": (lambda: np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(23).integers(0, 4, N)], 1, 0),
     "text_then_zipf": (lambda: np.concatenate([datagen.text_bytes(N // 2, seed=24), datagen.zipf_bytes(N // 2, seed=25)]), 1, 0),
     # beyond the depth cap of the tier (~500 symbols past the common prefix of a bucket): the general sorter takes over
-    # (a block of ONE symbol is no tier's business any more: k_fs_const writes its rows -- see test_constant_blocks)
+    # (a block of ONE symbol is no tier's business any more: k_fs_tables writes its rows -- see test_constant_blocks)
     "zeros": (lambda: np.zeros(N, dtype=np.uint8), 0, 0),
     "period_1_then_one_byte": (lambda: np.concatenate([np.zeros(N - 1, dtype=np.uint8), np.ones(1, dtype=np.uint8)]), 1, 1),
     "period_3": (lambda: np.tile(np.frombuffer(b"abc", dtype=np.uint8), N // 3 + 1)[:N], 1, 1),
@@ -118,7 +118,7 @@ def test_sample_sorter_mixed_batch(glc, ctx, cuda):
     with glc.Plan(ctx, glc.CUDPP_BWT, N, rows=len(blocks)) as plan:
         for rep in range(2):                                   # twice: scratch of the first call must not leak into the second
             got, gidx = _bwt(glc, plan, torch, x, rows=len(blocks))
-            assert plan.last_sort_stats() == (5, 1)             # (the all-zero block is finished by k_fs_const, not by a tier)
+            assert plan.last_sort_stats() == (5, 1)             # (the all-zero block is finished by k_fs_tables, not by a tier)
             for i, blk in enumerate(blocks):
                 want, widx = O.bwt(blk)
                 assert int(gidx[i]) == widx and np.array_equal(got[i * N:(i + 1) * N], want), "block %d (call %d)" % (i, rep)
@@ -277,7 +277,7 @@ def test_bucket_past_its_slot_gets_a_second_attempt(glc, cuda):
 
 @pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, 65536, 1048576])
 def test_constant_blocks(glc, ctx, cuda, n):
-    """a block of one symbol: BWT = the symbol n times, index n - 1, SA = n-1 .. 0, written by k_fs_const -- no tier runs
+    """a block of one symbol: BWT = the symbol n times, index n - 1, SA = n-1 .. 0, written by k_fs_tables -- no tier runs
     (it used to be every tier's worst case: 1.3 ms per 1 MiB block on the general sorter).  Alone, under every sorter
     mode that goes through the bucket sorter's front end, and inside a batch whose other blocks must not notice."""
     import torch
