@@ -257,13 +257,17 @@ def log_buffers_on_device(torch, dev, nbuf, seed=0x5EED0003, chunk=64):
 
 
 def float_blocks_on_device(torch, dev, nblocks, first_global_block, stride_blocks, seed=0x5EED0004):
-    """configs[3]: float32 ~ N(0,1) as little-endian bytes (cuSZ quant-code surrogate); block g from seed+g."""
+    """configs[3] as SURVEY.md 8(d) defines it: float32 ~ N(0, 1) as little-endian bytes (cuSZ quant-code surrogate) from a
+    counter-based Philox4x32-10 stream: global block g is bytes [g MiB, (g + 1) MiB) of that stream whatever the rank or N,
+    the same bits on the host (tests/datagen.float_philox_bytes) and on the device (glcGenFloatPhilox)."""
+    L = (_GLC or sys.modules.get("glc_binding") or _load("glc_binding", os.path.join(PKG, "glc_binding.py"))).lib()
     out = torch.empty(nblocks * MiB, dtype=torch.uint8, device=dev)
-    gen = torch.Generator(device=dev)
-    for i in range(nblocks):
-        g = first_global_block + i * stride_blocks
-        gen.manual_seed(seed + g)
-        out[i * MiB:(i + 1) * MiB] = torch.randn(MiB // 4, generator=gen, device=dev, dtype=torch.float32).view(torch.uint8)
+    if stride_blocks == 1:
+        assert L.glcGenFloatPhilox(out.data_ptr(), nblocks * MiB, first_global_block * MiB, seed, None) == 1
+    else:
+        for i in range(nblocks):
+            assert L.glcGenFloatPhilox(out.data_ptr() + i * MiB, MiB, (first_global_block + i * stride_blocks) * MiB, seed, None) == 1
+    torch.cuda.synchronize(dev)
     return out
 
 
@@ -339,7 +343,7 @@ def effective_cores():
     return max(1, n)
 
 
-def cpu_baseline(sample_blocks, log_sample):
+def cpu_baseline(sample_blocks, log_sample, kind="zipf"):
     """Reported baselines (not targets), bounded to ~20-30 s: the oracle port of cudppCompress and libbz2 -9 on the
     same Zipf blocks, single core and on all effective cores; the reference's serial LZSS on log-style ASCII."""
     import bz2
@@ -374,7 +378,7 @@ def cpu_baseline(sample_blocks, log_sample):
         list(ex.map(bz2.decompress, comp))
         bz_dec = nall * MiB / (time.perf_counter() - t0) / 1e9
     res = {"value": round(single, 5), "unit": "GB/s", "cores": 1, "kind": "port",
-           "sample": "6 x 1 MiB Zipf blocks of this workload through oracle/glc_oracle.c orc_compress (same bitstream), one thread",
+           "sample": "6 x 1 MiB %s blocks of this workload through oracle/glc_oracle.c orc_compress (same bitstream), one thread" % ("Zipf" if kind == "zipf" else "float32-as-bytes"),
            "all_cores": {"cores": cores, "cpu_count": os.cpu_count(), "blocks": nall,
                          "oracle_port_encode_GBps": round(allcore, 5),
                          "libbz2_9_encode_GBps": round(bz_enc, 5), "libbz2_9_decode_GBps": round(bz_dec, 5)},
@@ -1299,7 +1303,7 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("configs[1]: %g GiB/GPU Zipf(1.0) bytes (Philox4x32-10, key 0x5eed0002, counter = byte index / 4)" if kind == "zipf" else
-                                    "configs[3]: %g GiB/GPU random-float32-as-bytes, blocks round-robin over the GPUs") % args.gib
+                                    "configs[3]: %g GiB/GPU random-float32-as-bytes (Philox4x32-10, key 0x5eed0004), blocks round-robin over the GPUs") % args.gib
                                    + ", 1 MiB blocks, cudppCompress BWT+MTF+Huffman encode",
                        "value_is": "encode input bytes of all ranks / wall time (inputs resident in HBM; no data-path collective"
                                    + ("; RCCL gather of records + streams to rank 0 included)" if args.with_gather else ")"),
@@ -1372,9 +1376,9 @@ def main():
             res["hd_decode"] = leg_hd(torch, glc, dev, args.hd_mib)
         res["text_like"] = leg_text_like(torch, glc, dev)
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sample_host, log_sample)
+            res["cpu_baseline"] = cpu_baseline(sample_host, log_sample, kind)
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(sample_host, None)
+        res["cpu_baseline"] = cpu_baseline(sample_host, None, kind)
     gather_failed = False
     if world > 1:
         # the gather leg last, under a watchdog: a rank that waits for a peer that is gone still lets the line out

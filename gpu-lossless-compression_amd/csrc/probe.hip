@@ -64,9 +64,42 @@ __global__ __launch_bounds__(256) void k_gen_zipf_philox(uint4 *__restrict__ out
     }
 }
 
+// config 4 of SURVEY.md 8(d): float32 values ~ N(0, 1) as raw little-endian bytes, from the same counter-based generator.
+// Value i = ((sum of the four Philox words of counter i, each >> 10) * 2^-22 - 2) * sqrt(3): an Irwin-Hall(4) variate scaled
+// to unit variance.  Integer sum, ONE exact conversion, exact scaling and subtraction, one correctly rounded multiply: the
+// same float32 bits on the host (tests/datagen.float_philox_bytes) and on the device, which a Box-Muller transform (logf,
+// cosf) would not give.
+__global__ __launch_bounds__(256) void k_gen_float_philox(uint4 *__restrict__ out, size_t n16, unsigned long long first_val, uint32_t seed)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long ctr = first_val + 4 * i + k;
+            uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+            philox4x32_10(c0, c1, c2, c3, seed, 0u);
+            const uint32_t s = (c0 >> 10) + (c1 >> 10) + (c2 >> 10) + (c3 >> 10);      // < 2^24: exact in float32
+            const float z = __fmul_rn(__fsub_rn(__fmul_rn((float)s, 2.384185791015625e-07f), 2.0f), 1.7320508075688772f);
+            w[k] = __float_as_uint(z);
+        }
+        out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+// config 4 of SURVEY.md 8(d): bytes [first_byte, first_byte + bytes) (multiples of 16) of the float32 stream of `seed`
+int glcGenFloatPhilox(void *d_out, size_t bytes, unsigned long long first_byte, unsigned int seed, void *stream)
+{
+    if (!d_out || (bytes & 15) || (first_byte & 15)) return 0;
+    if (bytes == 0) return 1;
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)(n16 / 256 < 256 * 32 ? (n16 + 255) / 256 : 256 * 32);
+    hipLaunchKernelGGL(k_gen_float_philox, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4 *)d_out, n16, first_byte / 4, seed);
+    return hipGetLastError() == hipSuccess ? 1 : 0;
+}
 
 // config 2 of SURVEY.md 8(d): bytes [first_byte, first_byte + bytes) of the Zipf stream of `seed` into d_out (both
 // multiples of 16; d_thr255: the 255 cumulative thresholds, device memory).  Enqueues on `stream`; returns 1 on success.

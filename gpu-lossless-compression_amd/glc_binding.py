@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcPlanKernelProfileLost",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcGenFloatPhilox", "glcPlanKernelProfileLost",
     "glcCompressBatchCompact", "glcDecompressBatchCompact",
 ]
 CULZSS_SYMBOLS = [
@@ -120,6 +120,8 @@ def lib():
     L.glcProbeStreamRead.restype = C.c_int
     L.glcGenZipfPhilox.argtypes = [vp, sz, C.c_ulonglong, C.c_uint, vp, vp]
     L.glcGenZipfPhilox.restype = C.c_int
+    L.glcGenFloatPhilox.argtypes = [vp, sz, C.c_ulonglong, C.c_uint, vp]
+    L.glcGenFloatPhilox.restype = C.c_int
     # CULZSS
     if hasattr(L, "compression_kernel_wrapper"):
         L.compression_kernel_wrapper.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,

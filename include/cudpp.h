@@ -293,6 +293,10 @@ int glcProbeStreamRead(const void *d_buf, size_t bytes, int iters, float *ms, vo
  * twin (same bytes).  Enqueues on the stream; returns 1 on success. */
 int glcGenZipfPhilox(void *d_out, size_t bytes, unsigned long long first_byte, unsigned int seed,
                      const unsigned int *d_thr255, void *stream);
+/* The config-4 workload: bytes [first_byte, first_byte + bytes) (multiples of 16) of a float32 ~ N(0, 1) stream as raw
+ * little-endian bytes -- value i = ((sum of the four Philox4x32-10 words of counter i, each >> 10) * 2^-22 - 2) * sqrt(3), the
+ * same float32 bits as tests/datagen.py float_philox_bytes on the host. */
+int glcGenFloatPhilox(void *d_out, size_t bytes, unsigned long long first_byte, unsigned int seed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -44,6 +44,19 @@ def zipf_philox_bytes(first_byte, n, seed=0x5eed0002, s=1.0):
     return np.searchsorted(zipf_thresholds(s), u, side="right").astype(np.uint8)
 
 
+def float_philox_bytes(first_byte, n, seed=0x5eed0004):
+    """bytes [first_byte, first_byte + n) of a float32 ~ N(0, 1) stream as raw little-endian bytes.
+    Value i = ((sum of the four Philox4x32-10 words of counter i, each >> 10) * 2^-22 - 2) * sqrt(3) -- Irwin-Hall(4) scaled
+    to unit variance; integer sum, one exact conversion, exact scaling and subtraction, one correctly rounded multiply, so
+    glcGenFloatPhilox (csrc/probe.hip) produces the same bits on the device."""
+    assert first_byte % 4 == 0 and n % 4 == 0
+    ctr = np.arange(first_byte // 4, (first_byte + n) // 4, dtype=np.uint64)
+    w = philox4x32_10(ctr & np.uint64(0xFFFFFFFF), ctr >> np.uint64(32), np.zeros_like(ctr), np.zeros_like(ctr), seed, 0)
+    s = sum((x >> np.uint64(10)) for x in w).astype(np.float32)                # < 2^24: exact
+    z = (s * np.float32(2.384185791015625e-07) - np.float32(2.0)) * np.float32(1.7320508075688772)
+    return z.astype(np.float32).view(np.uint8).copy()
+
+
 def float_bytes(n, seed=0x5eed0004):
     """float32 ~ N(0,1) as little-endian bytes (config 4)."""
     rng = np.random.Generator(np.random.Philox(key=seed))

@@ -21,3 +21,17 @@ def test_device_zipf_stream_equals_host_stream(glc, cuda):
     out = torch.zeros(32, dtype=torch.uint8, device=cuda)
     assert L.glcGenZipfPhilox(out.data_ptr(), 24, 0, 1, thr.data_ptr(), None) == 0          # not a multiple of 16
     assert L.glcGenZipfPhilox(None, 16, 0, 1, thr.data_ptr(), None) == 0
+
+
+def test_device_float_stream_equals_host_stream(glc, cuda):
+    """config 4: the same float32 BITS on both sides (an integer sum, exact steps and one correctly rounded multiply)"""
+    import torch
+    L = glc.lib()
+    for first, n in ((0, 1 << 20), (7 << 20, 1 << 16), ((1 << 34) + 32, 4096)):
+        out = torch.zeros(n, dtype=torch.uint8, device=cuda)
+        assert L.glcGenFloatPhilox(out.data_ptr(), n, first, 0x5EED0004, None) == 1
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), datagen.float_philox_bytes(first, n)), (first, n)
+    f = datagen.float_philox_bytes(0, 1 << 20).view(np.float32)
+    assert abs(float(f.mean())) < 0.01 and abs(float(f.std()) - 1.0) < 0.01
+
