@@ -1039,6 +1039,18 @@ __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint3
 // rounds of 5 symbols read from the text, starting behind the common prefix of the bucket's two splitters
 // (everything between two suffixes shares their common prefix); see k_ss_cut / k_ss_windows.
 // Same words, same slots, same outputs as the first tier; only very deep repeats are left to the general sorter.
+#ifdef GLC_SS_CLOCKS
+// experiment builds only (tools/exp/ss_clocks.py): s_memrealtime ticks (100 MHz) per phase, summed over thread 0 of every
+// workgroup of k_ss_cut ([0, 8)) and over every wave of k_ss_windows ([16, 24)); [8] / [24] count them
+__device__ unsigned long long g_ss_clk[256][32];           // 256 copies: the adds of a million workgroups do not queue on 32 addresses
+#define SS_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); clk_[k] += t_ - clk_t_; clk_t_ = t_; } } while (0)
+#define SS_CLK_BEGIN() unsigned long long clk_[8] = {}, clk_t_ = __builtin_amdgcn_s_memrealtime()
+#define SS_CLK_END(base) do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) if (clk_[k_]) atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + k_], clk_[k_]); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + 8], 1ull); } } while (0)
+#else
+#define SS_CLK(k) do { } while (0)
+#define SS_CLK_BEGIN() do { } while (0)
+#define SS_CLK_END(base) do { } while (0)
+#endif
 constexpr int SSA_NT = 1024;                                   // k_ss_sample: threads
 constexpr uint32_t SS_PER_BUCKET = 32, SS_MAXS = FS_MAXNB * SS_PER_BUCKET;
 constexpr uint32_t SS_L0_CAP = 1024;                           // longest splitter prefix skipped at once
@@ -1182,12 +1194,16 @@ __device__ __forceinline__ uint64_t ss_sym_key(uint64_t raw)
 
 constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
-constexpr uint32_t SS_NPL = 4, SS_NPIV0 = 64 * SS_NPL;         // first cut: 256 pivots
+#ifndef GLC_SS_NPL
+#define GLC_SS_NPL 4
+#endif
+constexpr uint32_t SS_NPL = GLC_SS_NPL, SS_NPIV0 = 64 * SS_NPL; // first cut: 256 pivots
 // shares of a bucket's positions handed out to the waves (two per wave).  A share is what a wave cuts into windows, so it
 // should hold at least one full window: with 64 shares of ~32 positions each window filled an eighth of the wave's 256
 // slots and k_ss_windows took 8.0 ms per 256 text blocks; 32 / 16 / 8 / 4 shares: 6.6 / 5.8 / 5.4 / 5.3 ms.
 constexpr uint32_t SS_SHARES = 8;
 constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
+constexpr uint32_t SSL_SMALL = 1024;                           // k_ss_long: members of a "small" long bin
 // k_ss_windows' form of a round's key: the SS_STEP = 7 text bytes themselves in the top 56 bits (0 past the end of
 // the text) and the window slot in the low 8, so that no two keys of a window are equal: a position's new place is
 // ONE count (keys below it) and the start of its new run a second one (keys below the key with slot 0).  Bytes cannot
@@ -1258,7 +1274,8 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
                                                     uint32_t nbl, uint64_t *__restrict__ keys, size_t kstride,
                                                     const uint32_t *__restrict__ fill,
                                                     uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
-                                                    const uint32_t *__restrict__ l0_in)
+                                                    const uint32_t *__restrict__ l0_in, uint2 *__restrict__ long_list,
+                                                    size_t long_cap, unsigned long long *__restrict__ long_count)
 {
     __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position; scratch of a cut
     __shared__ uint32_t s_v[FS_FILLMAX];                       // index << 8 | BWT byte of the suffix at a position
@@ -1279,6 +1296,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
         s_l0 = c > 1 ? l0_in[(size_t)b * FS_MAXNB + bk] : 0u;   // common prefix of the bucket's two splitters (k_ss_sample)
     }
     uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+    SS_CLK_BEGIN();
     // ---- first cut, by the whole workgroup (thread = the positions r NT + tid) ----
     uint32_t vv[SSS_ITEMS];
 #pragma unroll
@@ -1289,6 +1307,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
     for (uint32_t i = tid; i < SSS_WAVES * (SS_NBIN + 3); i += SSS_NT) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     if (s_deep || c == 0 || c > FS_FILLMAX) return;
+    SS_CLK(0);                                                 // words loaded
     const uint32_t l0 = s_l0;
     if (c == 1) { if (tid == 0) { s_v[0] = vv[0]; s_seg[0] = ss_run(0, 1, 0); } }
     else {
@@ -1304,6 +1323,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
             if (p < c) { key[r] = ss_sym_key(key[r]); s_k[p] = key[r]; }
         }
         __syncthreads();
+        SS_CLK(1);                                             // text gathered, keys in LDS
         // 256 pivots for the first cut (bins of ~c / 513: the windows count inside runs directly, quadratic in their
         // length, and with 64 pivots that counting was what k_ss_windows spent its time on): four waves sort 64 sampled
         // keys each, every pivot then finds its place among the other three lists
@@ -1327,6 +1347,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
             s_piv0[rank] = kv;
         }
         __syncthreads();
+        SS_CLK(2);                                             // pivots
         uint32_t *cnt0 = &s_cnt[0][0];                         // (the counter rows of all waves as one array: 2 * 256 + 3 entries)
         uint32_t bin[SSS_ITEMS], rk[SSS_ITEMS];
 #pragma unroll
@@ -1340,6 +1361,7 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
             }
         }
         __syncthreads();
+        SS_CLK(3);                                             // binned
         if (wv == 0) {
             constexpr int PER = (2 * SS_NPIV0 + 2 + 63) / 64;     // 514 starts + the end
             uint32_t cc[PER], tot = 0;
@@ -1361,92 +1383,187 @@ __global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict_
         }
         __syncthreads();
         // bins still longer than a window (a key shared by hundreds of suffixes, or an unlucky gap between pivots)
-        if (tid < 2 * SS_NPIV0 + 1) {
-            const uint32_t gs = cnt0[tid], ge = cnt0[tid + 1];
+        for (uint32_t i = tid; i < 2 * SS_NPIV0 + 1; i += SSS_NT) {
+            const uint32_t gs = cnt0[i], ge = cnt0[i + 1];
             if (ge - gs > SS_WIN) s_bound[atomicAdd(&s_nlong, 1u)] = gs | (ge << 16);
         }
         __syncthreads();
         for (uint32_t i = tid; i < SSS_WAVES * (SS_NBIN + 3); i += SSS_NT) cnt0[i] = 0;
     }
     __syncthreads();
-    // ---- such bins are cut again, each by one wave, until no run in them is longer than a window ----
+    SS_CLK(4);                                                 // scanned, scattered, long bins listed
+    // ---- such bins go on a list: k_ss_long cuts them again, a wave per bin (when that was the tail of this kernel, one
+    //      or two waves worked and the other fourteen sat on 73 KB of LDS: 40 % of a text bucket's time here, 60 % of a log
+    //      bucket's).  Two size classes, counted in the halves of one 64-bit counter: up to SSL_SMALL members, and more. ----
     const uint32_t nlong = s_nlong;
-    for (;;) {
-        uint32_t ch = 0;
-        if (lane == 0) ch = atomicAdd(&s_next, 1u);
-        ch = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
-        if (ch >= nlong) break;
-        const uint32_t A = s_bound[ch] & 0xFFFFu, B = s_bound[ch] >> 16;
-        uint32_t *cnt = s_cnt[wv];
+    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    if (nlong) {
+        __shared__ unsigned long long s_at;
+        uint32_t mine = 0, big = 0;
+        if (tid < nlong) { mine = s_bound[tid]; big = (mine >> 16) - (mine & 0xFFFFu) > SSL_SMALL ? 1u : 0u; }
+        if (tid < 64) {                                        // (nlong <= 15: all in wave 0)
+            const unsigned long long bigs = __ballot(tid < nlong && big), smalls = __ballot(tid < nlong && !big);
+            if (tid == 0) s_at = atomicAdd(long_count, (unsigned long long)__popcll(smalls) | ((unsigned long long)__popcll(bigs) << 32));
+            __builtin_amdgcn_wave_barrier();
+            if (tid < nlong) {
+                const unsigned long long below = (1ull << tid) - 1ull;
+                const size_t at = big ? long_cap + (size_t)(s_at >> 32) + __popcll(bigs & below)
+                                      : (size_t)(uint32_t)s_at + __popcll(smalls & below);
+                long_list[at] = make_uint2(b | (bk << 20), mine);
+            }
+        }
+    }
+    SS_CLK(5);
+    // the bucket goes back to its slot in run order: [run : 32 | index : 20 | bwt : 8 ...] (bits 28..31 unused)
+    for (uint32_t p = tid; p < c; p += SSS_NT) K[p] = (uint64_t)s_v[p] | ((uint64_t)s_seg[p] << 32);
+    SS_CLK(7);
+    SS_CLK_END(0);
+}
+
+// the long bins k_ss_cut listed (runs of more than a window: a key that hundreds of suffixes of a bucket share), each cut
+// by ONE workgroup with 64 pivots of its own members until no run in it is longer than a window.  The bin lives in LDS
+// meanwhile (16 bytes per member), so there are two instances: bins of up to SSL_SMALL members, a wave each (nine per
+// CU), and the others, four waves each (two workgroups per CU).  Workgroups take the list's entries i, i + G, ... -- no
+// tickets.  A cut: the members' next 7 bytes (8 loads in flight per lane); all equal -> the run is one round deeper and
+// nothing moves; else 64 of the keys, sorted by a wave, are the pivots the members search (in LDS, four searches per
+// lane at a time) for their bin -- "between two pivots": a run at the same depth, "equal to a pivot": one round deeper.
+template <uint32_t CAP, uint32_t NT, bool BIG>
+__global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                                uint64_t *__restrict__ keys, size_t kstride, uint32_t *__restrict__ flag,
+                                                const uint32_t *__restrict__ l0_in, const uint2 *__restrict__ long_list,
+                                                size_t long_cap, const unsigned long long *__restrict__ long_count)
+{
+    __shared__ uint64_t s_kl[CAP];
+    __shared__ uint32_t s_vl[CAP], s_segl[CAP];
+    __shared__ uint32_t cnt[SS_NBIN + 3];
+    __shared__ uint64_t s_piv[SS_NPIV + 1];
+    __shared__ uint32_t s_any[2];                              // [0]: a member's 8 bytes reach the end of the text; [1]: a key differs from the first
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    auto sync = [] { if (NT == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
+    const unsigned long long both = *long_count;
+    const uint32_t count = BIG ? (uint32_t)(both >> 32) : (uint32_t)both;
+    const uint2 *LST = long_list + (BIG ? long_cap : 0);
+    for (uint32_t i = tid; i < SS_NBIN + 3; i += NT) cnt[i] = 0;
+    if (tid < 2) s_any[tid] = 0;
+    for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+        const uint2 ent = LST[e];
+        const uint32_t b = ent.x & 0xFFFFFu, bk = ent.x >> 20, A = ent.y & 0xFFFFu, B = ent.y >> 16;
+        if (flag[b] || B - A > CAP) continue;                  // (given up on already; the second cannot happen)
+        const uint8_t *T = text + (size_t)b * stride;
+        uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
+        const uint32_t l0 = l0_in[(size_t)b * FS_MAXNB + bk];
+        // positions are the bucket's; the LDS arrays hold [A, B)
+        uint64_t *s_k = s_kl - A;
+        uint32_t *s_v = s_vl - A, *s_seg = s_segl - A;
+        sync();
+        for (uint32_t p = A + tid; p < B; p += NT) { const uint64_t x = K[p]; s_v[p] = (uint32_t)x; s_seg[p] = (uint32_t)(x >> 32); }
+        sync();
+        bool deep = false;
         uint32_t pos = A;
         while (pos < B) {
-            if (s_deep) break;                                 // (another wave gave the block up)
-            // window [pos, W): the runs that start in it and end within SS_WIN positions
+            // window [pos, W): the runs that start in it and end within SS_WIN positions (every wave works it out for itself)
             const uint32_t lim = min(B, pos + SS_WIN);
-            uint32_t g4[4], W = lim;
+            uint32_t W = lim, g0 = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t p = pos + lane + 64 * j;
-                g4[j] = p < lim ? s_seg[p] : 0u;
                 if (p < lim) {
-                    const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu;
+                    const uint32_t g = s_seg[p], ss = g & 0xFFFu, se = (g >> 12) & 0xFFFu;
+                    if (j == 0) g0 = g;
                     if (se > lim) W = min(W, ss);              // a run that runs out of the window: the window ends before it
                 }
             }
             W = (uint32_t)wave_min_u64((uint64_t)W);
-            if (W == pos) {
-                // ---- the run at pos is longer than a window: cut it with pivots ----
-                const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g4[0]);
-                const uint32_t ss = g & 0xFFFu, se = (g >> 12) & 0xFFFu, st = g >> 24, gsz = se - ss;
-                if (st > SS_MAXSTEP) { s_deep = 1; break; }
-                for (uint32_t p0 = ss; p0 < se; p0 += 256) {   // keys of the members, 4 loads in flight per lane
-                    uint64_t raw[4];
+            if (W != pos) { pos = W; continue; }               // (windows are finished by k_ss_windows)
+            // ---- the run at pos is longer than a window: cut it ----
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
+            const uint32_t ss = g & 0xFFFu, se = (g >> 12) & 0xFFFu, st = g >> 24, gsz = se - ss;
+            if (st > SS_MAXSTEP) { deep = true; break; }
+            const uint32_t off = l0 + SS_STEP * st;
+            {   // does a member's load reach the end of the text?  Then the whole cut uses the 9-bit digits (ss_sym_key)
+                bool t = false;
+                for (uint32_t p = ss + tid; p < se; p += NT) t |= (s_v[p] >> 8) + off + 12 > n;
+                if (__ballot(t) != 0 && lane == 0) s_any[0] = 1;
+            }
+            sync();
+            const bool digits = s_any[0] != 0;
+            const uint64_t k0 = 0;
+            for (uint32_t p0 = ss; p0 < se; p0 += NT * 8) {    // keys of the members, 8 loads in flight per lane
+                uint64_t raw[8];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { const uint32_t p = p0 + lane + 64 * j; raw[j] = p < se ? ss_sym_load(T, n, (s_v[p] >> 8) + l0 + SS_STEP * st) : 0ull; }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { const uint32_t p = p0 + lane + 64 * j; if (p < se) s_k[p] = ss_sym_key(raw[j]); }
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t p = p0 + tid + NT * j;
+                    raw[j] = p < se ? (digits ? ss_sym_load(T, n, (s_v[p] >> 8) + off) : fs_load_be64(T + (s_v[p] >> 8) + off) >> 8) : 0ull;
                 }
-                __builtin_amdgcn_wave_barrier();
-                const uint64_t piv = wave_sort_u64(s_k[ss + (lane * gsz) / SS_NPIV], lane);
-                for (uint32_t p0 = ss; p0 < se; p0 += 64) {    // bin and arrival rank of every member -> s_seg (the run's descriptor is in g)
-                    const uint32_t p = p0 + lane;
-                    const uint32_t bn = ss_pivot_bin(piv, p < se ? s_k[p] : 0ull);
-                    if (p < se) s_seg[p] = bn | (atomicAdd(&cnt[bn], 1u) << 8);
-                }
-                __builtin_amdgcn_wave_barrier();
-                {
-                    uint32_t c3[3], tot = 0;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; c3[k] = i < SS_NBIN ? cnt[i] : 0u; tot += c3[k]; }
-                    uint32_t run = ss + wave_incl_add(tot) - tot;
+                for (int j = 0; j < 8; j++) { const uint32_t p = p0 + tid + NT * j; if (p < se) s_k[p] = digits ? ss_sym_key(raw[j]) : raw[j]; }
+            }
+            (void)k0;
+            sync();
+            {   // all keys equal: the run is one round deeper, nothing moves
+                const uint64_t first = s_k[ss];
+                bool d = false;
+                for (uint32_t p = ss + tid; p < se; p += NT) d |= s_k[p] != first;
+                if (__ballot(d) != 0 && lane == 0) s_any[1] = 1;
+            }
+            sync();
+            const bool differ = s_any[1] != 0;
+            sync();
+            if (tid < 2) s_any[tid] = 0;
+            if (!differ) {
+                const uint32_t r1 = ss_run(ss, se, st + 1);
+                for (uint32_t p = ss + tid; p < se; p += NT) s_seg[p] = r1;
+                sync();
+                continue;
+            }
+            if (tid < 64) s_piv[lane] = wave_sort_u64(s_k[ss + (lane * gsz) / SS_NPIV], lane);
+            sync();
+            for (uint32_t p0 = ss; p0 < se; p0 += NT * 4) {    // bin and arrival rank of every member -> s_seg (the run's descriptor is in g)
+                uint64_t key[4];
+                uint32_t lo[4], hi[4];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; if (i <= SS_NBIN) cnt[i] = run; run += c3[k]; }
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t p0 = ss; p0 < se; p0 += 64) {    // to the bins, through s_k (the keys are used up)
-                    const uint32_t p = p0 + lane;
-                    if (p < se) {
-                        const uint32_t x = s_seg[p], bn = x & 0xFFu, gs = cnt[bn], ge = cnt[bn + 1];
-                        s_k[gs + (x >> 8)] = (uint64_t)s_v[p] | ((uint64_t)ss_run(gs, ge, st + (bn & 1)) << 32);
+                for (int j = 0; j < 4; j++) { const uint32_t p = p0 + tid + NT * j; key[j] = p < se ? s_k[p] : 0ull; lo[j] = 0; hi[j] = SS_NPIV; }
+#pragma unroll
+                for (int it = 0; it < 7; it++) {               // first pivot >= key
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t mid = (lo[j] + hi[j]) >> 1;
+                        const uint64_t pm = s_piv[mid < SS_NPIV ? mid : SS_NPIV - 1];
+                        if (lo[j] < hi[j]) { if (pm < key[j]) lo[j] = mid + 1; else hi[j] = mid; }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t p0 = ss; p0 < se; p0 += 64) {
-                    const uint32_t p = p0 + lane;
-                    if (p < se) { const uint64_t x = s_k[p]; s_v[p] = (uint32_t)x; s_seg[p] = (uint32_t)(x >> 32); }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t p = p0 + tid + NT * j;
+                    if (p < se) {
+                        const uint32_t bn = 2 * lo[j] + ((lo[j] < SS_NPIV && s_piv[lo[j]] == key[j]) ? 1u : 0u);
+                        s_seg[p] = bn | (atomicAdd(&cnt[bn], 1u) << 8);
+                    }
                 }
-                for (uint32_t i = lane; i < SS_NBIN + 3; i += 64) cnt[i] = 0;
-                __builtin_amdgcn_wave_barrier();
-                continue;                                      // look at pos again: the runs there are shorter or deeper now
             }
-            // (windows are finished by k_ss_windows)
-            pos = W;
+            sync();
+            if (tid < 64) {
+                uint32_t c3[3], tot = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; c3[k] = i < SS_NBIN ? cnt[i] : 0u; tot += c3[k]; }
+                uint32_t run = ss + wave_incl_add(tot) - tot;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const uint32_t i = 3 * lane + k; if (i <= SS_NBIN) cnt[i] = run; run += c3[k]; }
+            }
+            sync();
+            for (uint32_t p = ss + tid; p < se; p += NT) {     // to the bins, through s_k (the keys are used up)
+                const uint32_t x = s_seg[p], bn = x & 0xFFu, gs = cnt[bn], ge = cnt[bn + 1];
+                s_k[gs + (x >> 8)] = (uint64_t)s_v[p] | ((uint64_t)ss_run(gs, ge, st + (bn & 1)) << 32);
+            }
+            sync();
+            for (uint32_t p = ss + tid; p < se; p += NT) { const uint64_t x = s_k[p]; s_v[p] = (uint32_t)x; s_seg[p] = (uint32_t)(x >> 32); }
+            for (uint32_t i = tid; i < SS_NBIN + 3; i += NT) cnt[i] = 0;
+            sync();                                            // look at pos again: the runs there are shorter or deeper now
         }
+        sync();
+        if (deep) { if (tid == 0) atomicOr(&flag[b], 2u); continue; }
+        for (uint32_t p = A + tid; p < B; p += NT) K[p] = (uint64_t)s_v[p] | ((uint64_t)s_seg[p] << 32);
     }
-    __syncthreads();
-    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-    // the bucket goes back to its slot in run order: [run : 32 | index : 20 | bwt : 8 ...] (bits 28..31 unused)
-    for (uint32_t p = tid; p < c; p += SSS_NT) K[p] = (uint64_t)s_v[p] | ((uint64_t)s_seg[p] << 32);
 }
 
 constexpr int SSW_PER_BUCKET = 4;                              // one-wave workgroups per bucket; wave w takes shares w, w + 4, ...
@@ -1475,6 +1592,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
     bool deep = flag[b] != 0;                                  // (set by earlier kernels only, or by other waves: then it does not matter what this one does)
     if (deep || c == 0 || c > FS_FILLMAX) return;
     const uint32_t l0 = l0_in[(size_t)b * FS_MAXNB + bk];
+    SS_CLK_BEGIN();
     // shares [A, B) of the positions; a share ends where a run ends
     for (uint32_t t = lane; t <= SS_SHARES; t += 64) {
         uint32_t A = (uint32_t)(((uint64_t)c * t) / SS_SHARES);
@@ -1482,6 +1600,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
         s_bound[t] = A;
     }
     __builtin_amdgcn_wave_barrier();
+    SS_CLK(0);                                                 // prologue + share bounds
     uint64_t *KW = s_kw;
     uint32_t *VW = s_vw, *SW = s_sw;
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
@@ -1507,6 +1626,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                 }
             }
             W = (uint32_t)wave_min_u64((uint64_t)W);
+            SS_CLK(1);                                         // window's words loaded
             if (W == pos) { deep = true; break; }               // (k_ss_cut leaves no run longer than a window)
             und = false;
 #pragma unroll
@@ -1536,6 +1656,20 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                 }
                 if (__ballot(dp) != 0) { deep = true; break; }
                 uint32_t np[4];
+                SS_CLK(2);                                     // round set up
+#ifdef GLC_SS_CLOCKS
+                {
+                    uint32_t tr = 0, und_n = 0;
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t p = pos + lane + 64 * j;
+                        const uint32_t L = p < W ? ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) : 0u;
+                        tr += wave_max(L > 1 ? L : 0u);
+                        und_n += (uint32_t)__popcll(__ballot(L > 1));
+                    }
+                    if (lane == 0) { atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][25], 1ull); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][26], (unsigned long long)tr);
+                                     atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][27], (unsigned long long)und_n); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][28], (unsigned long long)(W - pos)); }
+                }
+#endif
                 if (__ballot(tail) == 0) {
                     // the usual round: keys that cannot be equal (ss_raw7), two counts per member
 #pragma unroll
@@ -1550,6 +1684,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+                    SS_CLK(3);                                 // text gathered
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t p = pos + lane + 64 * j;
@@ -1570,6 +1705,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+                    SS_CLK(4);                                 // counted
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if (np[j] != 0xFFFFFFFFu) {
@@ -1625,6 +1761,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                         und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1;
                     }
                 }
+                SS_CLK(5);                                     // moved, runs re-read
             }
             // rows R0 + pos .. R0 + W
             __builtin_amdgcn_wave_barrier();
@@ -1639,9 +1776,11 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            SS_CLK(6);                                         // rows written
             pos = W;
         }
     }
+    SS_CLK_END(16);
     if (deep && lane == 0) atomicOr(&flag[b], 2u);
 }
 
@@ -1765,8 +1904,15 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                        n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, list, s.ss_split, s.ss_cell,
                        s.ss_split + (size_t)s.rows * FS_MAXNB, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, list);
+    GLC_TRY(hipMemsetAsync(s.ss_long_count, 0, 8, st));
+    const size_t long_cap = (size_t)s.rows * FS_MAXNB * SSL_PER_BUCKET;
     hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.ss_flag, list, s.ss_l0);
+                       s.fs_fill, s.ss_flag, list, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
+    // the long bins: as many workgroups as fit the GPU (LDS: 17 KB / 65.5 KB each), the list's entries strided over them
+    hipLaunchKernelGGL((k_ss_long<SSL_SMALL, 64, false>), dim3(256 * 9), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+                       s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
+    hipLaunchKernelGGL((k_ss_long<FS_FILLMAX, 256, true>), dim3(256 * 2), dim3(256), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+                       s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
     hipLaunchKernelGGL(k_ss_windows, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                        s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
                        (size_t)s.nmax);
@@ -1785,3 +1931,16 @@ hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s)
 }
 
 } // namespace glc
+
+#ifdef GLC_SS_CLOCKS
+extern "C" int glcSsClocks(unsigned long long *out32, int reset)
+{
+    static unsigned long long h[256][32];
+    if (out32) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(glc::g_ss_clk), sizeof(glc::g_ss_clk)) != hipSuccess) return 0;
+        for (int k = 0; k < 32; k++) { out32[k] = 0; for (int c = 0; c < 256; c++) out32[k] += h[c][k]; }
+    }
+    if (reset) { for (auto &r : h) for (auto &x : r) x = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(glc::g_ss_clk), h, sizeof h) != hipSuccess) return 0; }
+    return 1;
+}
+#endif

@@ -20,6 +20,7 @@ constexpr uint32_t FS_CAP   = 4096;             // slot size in the word array
 constexpr uint32_t FS_FILLMAX = 4032;            // fullest bucket the in-LDS sort takes (a fuller one flags its block)
 constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20 (256 buckets of 4096 words: k_fs_sort 1.62 vs 1.3 ms)
 constexpr uint32_t FS_MAXNB_LOG2 = 9;
+constexpr uint32_t SSL_PER_BUCKET = 15, SSL_BIG_PER_BUCKET = 3;   // most bins of > 256 / > 1024 members a bucket of <= 4032 can have
 
 // status bits accumulated on the device (PlanBase::d_status)
 constexpr uint32_t ST_BLOCK_OVERFLOW = 1u;       // a 4096-symbol block needs > 1536 words
@@ -162,6 +163,8 @@ struct SaScratch {
     uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]
     uint32_t *ss_flag = nullptr;                 // [rows] this tier's give-up flags
     uint32_t *ss_l0 = nullptr;                   // [rows][FS_MAXNB] common prefix of a bucket's two splitters
+    uint2    *ss_long = nullptr;                 // [rows * FS_MAXNB * (SSL_PER_BUCKET + SSL_BIG_PER_BUCKET)] long bins of the sample sorter's first cut
+    unsigned long long *ss_long_count = nullptr; // their number: small ones in the low half, big ones in the high half
     uint16_t *ss_cell = nullptr;                 // [rows][4098] first splitter of every cell of the code space
     hipEvent_t ev_flag = nullptr;                // marks the readback of fs_nflag (sa_build_begin / sa_build_finish)
     bool      pending = false;

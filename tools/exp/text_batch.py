@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A batch of text-like blocks through glcCompressBatch a few times (for rocprofv3 --kernel-trace: tools/exp/kstats.sh).
-usage: text_batch.py [text|log|zipf] [rows] [iters]"""
+usage: text_batch.py [text|log|text256|log256|zipf] [rows] [iters]"""
 import importlib.util, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,6 +14,9 @@ n, distinct = 1 << 20, 8
 dev = torch.device("cuda:0")
 if kind == "zipf":
     d_in = bench.zipf_blocks_on_device(torch, dev, rows, 0, 1)
+elif kind in ("text256", "log256"):                          # as bench.py's text_like leg: every block distinct
+    bench._GLC = glc
+    d_in = (bench.text_blocks_on_device(torch, dev, rows) if kind == "text256" else bench.log_buffers_on_device(torch, dev, rows)).view(-1)
 else:
     x = {"text": datagen.text_bytes, "log": datagen.log_bytes}[kind](n * distinct).reshape(distinct, n)
     d_in = torch.from_numpy(np.tile(x, (rows // distinct, 1))).to(dev).contiguous().view(-1)
