@@ -1192,7 +1192,10 @@ __device__ __forceinline__ uint64_t ss_sym_key(uint64_t raw)
     return k;
 }
 
-constexpr int SSS_NT = 1024, SSS_ITEMS = FS_CAP / SSS_NT, SSS_WAVES = SSS_NT / 64;
+#ifndef GLC_SSS_NT
+#define GLC_SSS_NT 512
+#endif
+constexpr int SSS_NT = GLC_SSS_NT;                              // k_ss_cut: threads
 constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
 #ifndef GLC_SS_NPL
 #define GLC_SS_NPL 4
@@ -1270,152 +1273,145 @@ __device__ __forceinline__ uint32_t ss_pivot_bin(uint64_t piv, uint64_t key)
 //                when this was the tail of the cutting kernel, the slowest of 16 waves took 3x the mean and the
 //                other 15 sat on 73 KB of LDS meanwhile.
 // Nothing here depends on the symbol statistics.
-__global__ __launch_bounds__(SSS_NT, 8) void k_ss_cut(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
-                                                    uint32_t nbl, uint64_t *__restrict__ keys, size_t kstride,
-                                                    const uint32_t *__restrict__ fill,
-                                                    uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
-                                                    const uint32_t *__restrict__ l0_in, uint2 *__restrict__ long_list,
-                                                    size_t long_cap, unsigned long long *__restrict__ long_count)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+                                               uint32_t nbl, uint64_t *__restrict__ keys, size_t kstride,
+                                               const uint32_t *__restrict__ fill,
+                                               uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
+                                               const uint32_t *__restrict__ l0_in, uint2 *__restrict__ long_list,
+                                               size_t long_cap, unsigned long long *__restrict__ long_count)
 {
-    __shared__ uint64_t s_k[FS_FILLMAX];                       // key of the suffix at a position; scratch of a cut
-    __shared__ uint32_t s_v[FS_FILLMAX];                       // index << 8 | BWT byte of the suffix at a position
-    __shared__ uint32_t s_seg[FS_FILLMAX];                     // run of a position (ss_run)
-    __shared__ uint32_t s_cnt[SSS_WAVES][SS_NBIN + 3];          // bin counters, then bin starts (+ end), of the cut a wave is making
-    __shared__ uint64_t s_piv0[SS_NPIV0];                      // pivots of the first cut, sorted
+    // The first cut of a bucket, nothing else: keys and words stay in registers, the pivots are gathered on their own
+    // (256 threads read the word and the text of one sample each, beside the loads of everybody's positions), and LDS
+    // only stages the bucket on its way back to the slot -- 39 KB, four workgroups per CU, where the cut-until-done form
+    // (keys, words and runs of 4032 positions: 73 KB) had two, each a chain of memory and LDS round trips between barriers.
+    constexpr int ITEMS = FS_CAP / NT;
+    static_assert(NT >= (int)SS_NPIV0 && FS_CAP % NT == 0, "one pivot sample per thread of the first four waves");
+    __shared__ uint64_t s_out[FS_FILLMAX];                     // the bucket in its new order: [run : 32 | index : 20 | bwt : 8 ...]
+    __shared__ uint32_t s_cnt[2 * SS_NPIV0 + 4];               // bin counters, then bin starts (+ end)
+    __shared__ uint64_t s_piv0[SS_NPIV0];                      // pivots, sorted
     __shared__ uint64_t s_pl[SS_NPL][64];                      // ... as the four sorted lists they are merged from
-    __shared__ uint32_t s_deep, s_l0, s_next, s_nlong, s_bound[SS_NBIN + 1];
+    __shared__ uint32_t s_nlong, s_bound[16];
+    __shared__ unsigned long long s_at;
     uint32_t gx, gy;
     xcd_order(gx, gy);
-    const uint32_t b = list[gy], bk = gx, tid = threadIdx.x, nb = 1u << nbl;
+    const uint32_t b = list[gy], bk = gx, tid = threadIdx.x;
     const uint32_t lane = tid & 63, wv = tid >> 6;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
-    if (tid == 0) {
-        s_deep = flag[b];
-        s_next = 0; s_nlong = 0;
-        s_l0 = c > 1 ? l0_in[(size_t)b * FS_MAXNB + bk] : 0u;   // common prefix of the bucket's two splitters (k_ss_sample)
-    }
+    if (flag[b] || c == 0 || c > FS_FILLMAX) return;           // (uniform; the flags are set by earlier kernels only)
     uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
     SS_CLK_BEGIN();
-    // ---- first cut, by the whole workgroup (thread = the positions r NT + tid) ----
-    uint32_t vv[SSS_ITEMS];
+    if (c == 1) { if (tid == 0) K[0] = (K[0] & FS_LOW_MASK) | ((uint64_t)ss_run(0, 1, 0) << 32); return; }
+    const uint32_t l0 = l0_in[(size_t)b * FS_MAXNB + bk];      // common prefix of the bucket's two splitters (k_ss_sample)
+    uint32_t vv[ITEMS];
 #pragma unroll
-    for (int r = 0; r < SSS_ITEMS; r++) {
-        const uint32_t p = r * SSS_NT + tid;
-        vv[r] = (c <= FS_FILLMAX && p < c) ? (uint32_t)(K[p] & FS_LOW_MASK) : 0u;
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t p = r * NT + tid;
+        vv[r] = p < c ? (uint32_t)(K[p] & FS_LOW_MASK) : 0u;
     }
-    for (uint32_t i = tid; i < SSS_WAVES * (SS_NBIN + 3); i += SSS_NT) (&s_cnt[0][0])[i] = 0;
-    __syncthreads();
-    if (s_deep || c == 0 || c > FS_FILLMAX) return;
+    uint32_t sv = 0;                                           // pivot sample of this thread: position tid c / 256
+    if (tid < SS_NPIV0) sv = (uint32_t)(K[(uint32_t)(((uint64_t)tid * c) / SS_NPIV0)] & FS_LOW_MASK);
+    for (uint32_t i = tid; i < 2 * SS_NPIV0 + 4; i += NT) s_cnt[i] = 0;
+    if (tid == 0) s_nlong = 0;
     SS_CLK(0);                                                 // words loaded
-    const uint32_t l0 = s_l0;
-    if (c == 1) { if (tid == 0) { s_v[0] = vv[0]; s_seg[0] = ss_run(0, 1, 0); } }
-    else {
-        uint64_t key[SSS_ITEMS];
+    // a member whose 8 bytes reach the end of the text: the whole cut uses the 9-bit digits that tell "ended" from a zero byte
+    bool tl = false;
 #pragma unroll
-        for (int r = 0; r < SSS_ITEMS; r++) {
-            const uint32_t p = r * SSS_NT + tid;
-            key[r] = p < c ? ss_sym_load(T, n, (vv[r] >> 8) + l0) : 0ull;
-        }
+    for (int r = 0; r < ITEMS; r++) tl |= r * NT + tid < c && (vv[r] >> 8) + l0 + 12 > n;
+    const bool digits = __syncthreads_or(tl) != 0;
+    uint64_t key[ITEMS], skey = 0;
+    if (tid < SS_NPIV0) skey = digits ? ss_sym_load(T, n, (sv >> 8) + l0) : fs_load_be64(T + (sv >> 8) + l0) >> 8;
 #pragma unroll
-        for (int r = 0; r < SSS_ITEMS; r++) {
-            const uint32_t p = r * SSS_NT + tid;
-            if (p < c) { key[r] = ss_sym_key(key[r]); s_k[p] = key[r]; }
-        }
-        __syncthreads();
-        SS_CLK(1);                                             // text gathered, keys in LDS
-        // 256 pivots for the first cut (bins of ~c / 513: the windows count inside runs directly, quadratic in their
-        // length, and with 64 pivots that counting was what k_ss_windows spent its time on): four waves sort 64 sampled
-        // keys each, every pivot then finds its place among the other three lists
-        if (wv < SS_NPL) s_pl[wv][lane] = wave_sort_u64(s_k[(uint32_t)(((uint64_t)(wv * 64 + lane) * c) / SS_NPIV0)], lane);
-        __syncthreads();
-        if (tid < SS_NPIV0) {
-            const uint32_t w = tid >> 6;
-            const uint64_t kv = s_pl[w][lane];
-            uint32_t rank = lane;
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t p = r * NT + tid;
+        key[r] = p < c ? (digits ? ss_sym_load(T, n, (vv[r] >> 8) + l0) : fs_load_be64(T + (vv[r] >> 8) + l0) >> 8) : 0ull;
+    }
+    // 256 pivots (bins of ~c / 513: the windows count inside runs directly, quadratic in their length): four waves sort 64
+    // sampled keys each, every pivot then finds its place among the other three lists
+    if (tid < SS_NPIV0) s_pl[wv][lane] = wave_sort_u64(digits ? ss_sym_key(skey) : skey, lane);
+    if (digits) {
 #pragma unroll
-            for (uint32_t ow = 0; ow < SS_NPL; ow++) {
-                if (ow == w) continue;
-                uint32_t lo = 0, hi = 64;                      // elements of list ow that come before kv (ties: the lower list first)
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const uint64_t x = s_pl[ow][mid];
-                    if (x < kv || (x == kv && ow < w)) lo = mid + 1; else hi = mid;
-                }
-                rank += lo;
+        for (int r = 0; r < ITEMS; r++) key[r] = ss_sym_key(key[r]);
+    }
+    __syncthreads();
+    SS_CLK(1);
+    if (tid < SS_NPIV0) {
+        const uint32_t w = tid >> 6;
+        const uint64_t kv = s_pl[w][lane];
+        uint32_t rank = lane;
+#pragma unroll
+        for (uint32_t ow = 0; ow < SS_NPL; ow++) {
+            if (ow == w) continue;
+            uint32_t lo = 0, hi = 64;                          // elements of list ow that come before kv (ties: the lower list first)
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint64_t x = s_pl[ow][mid];
+                if (x < kv || (x == kv && ow < w)) lo = mid + 1; else hi = mid;
             }
-            s_piv0[rank] = kv;
+            rank += lo;
         }
-        __syncthreads();
-        SS_CLK(2);                                             // pivots
-        uint32_t *cnt0 = &s_cnt[0][0];                         // (the counter rows of all waves as one array: 2 * 256 + 3 entries)
-        uint32_t bin[SSS_ITEMS], rk[SSS_ITEMS];
+        s_piv0[rank] = kv;
+    }
+    __syncthreads();
+    SS_CLK(2);                                                 // pivots
+    uint32_t bin[ITEMS], rk[ITEMS];
 #pragma unroll
-        for (int r = 0; r < SSS_ITEMS; r++) {
-            const uint32_t p = r * SSS_NT + tid;
-            if (p < c) {
-                uint32_t lo = 0, hi = SS_NPIV0;                // first pivot >= key
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_piv0[mid] < key[r]) lo = mid + 1; else hi = mid; }
-                bin[r] = 2 * lo + ((lo < SS_NPIV0 && s_piv0[lo] == key[r]) ? 1u : 0u);
-                rk[r] = atomicAdd(&cnt0[bin[r]], 1u);
-            }
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t p = r * NT + tid;
+        if (p < c) {
+            uint32_t lo = 0, hi = SS_NPIV0;                    // first pivot >= key
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_piv0[mid] < key[r]) lo = mid + 1; else hi = mid; }
+            bin[r] = 2 * lo + ((lo < SS_NPIV0 && s_piv0[lo] == key[r]) ? 1u : 0u);
+            rk[r] = atomicAdd(&s_cnt[bin[r]], 1u);
         }
-        __syncthreads();
-        SS_CLK(3);                                             // binned
-        if (wv == 0) {
-            constexpr int PER = (2 * SS_NPIV0 + 2 + 63) / 64;     // 514 starts + the end
-            uint32_t cc[PER], tot = 0;
+    }
+    __syncthreads();
+    SS_CLK(3);                                                 // binned
+    if (wv == 0) {
+        constexpr int PER = (2 * SS_NPIV0 + 2 + 63) / 64;      // 514 starts + the end
+        uint32_t cc[PER], tot = 0;
 #pragma unroll
-            for (int k = 0; k < PER; k++) { const uint32_t i = PER * lane + k; cc[k] = i < 2 * SS_NPIV0 + 1 ? cnt0[i] : 0u; tot += cc[k]; }
-            uint32_t run = wave_incl_add(tot) - tot;
+        for (int k = 0; k < PER; k++) { const uint32_t i = PER * lane + k; cc[k] = i < 2 * SS_NPIV0 + 1 ? s_cnt[i] : 0u; tot += cc[k]; }
+        uint32_t run = wave_incl_add(tot) - tot;
 #pragma unroll
-            for (int k = 0; k < PER; k++) { const uint32_t i = PER * lane + k; if (i <= 2 * SS_NPIV0 + 1) cnt0[i] = run; run += cc[k]; }
-        }
-        __syncthreads();
+        for (int k = 0; k < PER; k++) { const uint32_t i = PER * lane + k; if (i <= 2 * SS_NPIV0 + 1) s_cnt[i] = run; run += cc[k]; }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < SSS_ITEMS; r++) {
-            const uint32_t p = r * SSS_NT + tid;
-            if (p < c) {
-                const uint32_t gs = cnt0[bin[r]], ge = cnt0[bin[r] + 1], q = gs + rk[r];
-                s_v[q] = vv[r];
-                s_seg[q] = ss_run(gs, ge, bin[r] & 1);         // a pivot's bin: all keys equal, one round done
-            }
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t p = r * NT + tid;
+        if (p < c) {
+            const uint32_t gs = s_cnt[bin[r]], ge = s_cnt[bin[r] + 1];
+            s_out[gs + rk[r]] = (uint64_t)vv[r] | ((uint64_t)ss_run(gs, ge, bin[r] & 1) << 32);   // a pivot's bin: all keys equal, one round done
         }
-        __syncthreads();
-        // bins still longer than a window (a key shared by hundreds of suffixes, or an unlucky gap between pivots)
-        for (uint32_t i = tid; i < 2 * SS_NPIV0 + 1; i += SSS_NT) {
-            const uint32_t gs = cnt0[i], ge = cnt0[i + 1];
-            if (ge - gs > SS_WIN) s_bound[atomicAdd(&s_nlong, 1u)] = gs | (ge << 16);
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < SSS_WAVES * (SS_NBIN + 3); i += SSS_NT) cnt0[i] = 0;
+    }
+    // bins still longer than a window (a key shared by hundreds of suffixes, or an unlucky gap between pivots) go on a
+    // list: k_ss_long cuts them again, a workgroup per bin (when that was the tail of this kernel, one or two waves worked
+    // and the other fourteen sat on 73 KB of LDS: 40 % of a text bucket's time here, 60 % of a log bucket's).  Two size
+    // classes, counted in the halves of one 64-bit counter: up to SSL_SMALL members, and more.
+    for (uint32_t i = tid; i < 2 * SS_NPIV0 + 1; i += NT) {
+        const uint32_t gs = s_cnt[i], ge = s_cnt[i + 1];
+        if (ge - gs > SS_WIN) s_bound[atomicAdd(&s_nlong, 1u)] = gs | (ge << 16);
     }
     __syncthreads();
     SS_CLK(4);                                                 // scanned, scattered, long bins listed
-    // ---- such bins go on a list: k_ss_long cuts them again, a wave per bin (when that was the tail of this kernel, one
-    //      or two waves worked and the other fourteen sat on 73 KB of LDS: 40 % of a text bucket's time here, 60 % of a log
-    //      bucket's).  Two size classes, counted in the halves of one 64-bit counter: up to SSL_SMALL members, and more. ----
     const uint32_t nlong = s_nlong;
-    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
-    if (nlong) {
-        __shared__ unsigned long long s_at;
+    if (nlong && tid < 64) {                                   // (nlong <= 15)
         uint32_t mine = 0, big = 0;
         if (tid < nlong) { mine = s_bound[tid]; big = (mine >> 16) - (mine & 0xFFFFu) > SSL_SMALL ? 1u : 0u; }
-        if (tid < 64) {                                        // (nlong <= 15: all in wave 0)
-            const unsigned long long bigs = __ballot(tid < nlong && big), smalls = __ballot(tid < nlong && !big);
-            if (tid == 0) s_at = atomicAdd(long_count, (unsigned long long)__popcll(smalls) | ((unsigned long long)__popcll(bigs) << 32));
-            __builtin_amdgcn_wave_barrier();
-            if (tid < nlong) {
-                const unsigned long long below = (1ull << tid) - 1ull;
-                const size_t at = big ? long_cap + (size_t)(s_at >> 32) + __popcll(bigs & below)
-                                      : (size_t)(uint32_t)s_at + __popcll(smalls & below);
-                long_list[at] = make_uint2(b | (bk << 20), mine);
-            }
+        const unsigned long long bigs = __ballot(tid < nlong && big), smalls = __ballot(tid < nlong && !big);
+        if (tid == 0) s_at = atomicAdd(long_count, (unsigned long long)__popcll(smalls) | ((unsigned long long)__popcll(bigs) << 32));
+        __builtin_amdgcn_wave_barrier();
+        if (tid < nlong) {
+            const unsigned long long below = (1ull << tid) - 1ull;
+            const size_t at = big ? long_cap + (size_t)(s_at >> 32) + __popcll(bigs & below)
+                                  : (size_t)(uint32_t)s_at + __popcll(smalls & below);
+            long_list[at] = make_uint2(b | (bk << 20), mine);
         }
     }
     SS_CLK(5);
-    // the bucket goes back to its slot in run order: [run : 32 | index : 20 | bwt : 8 ...] (bits 28..31 unused)
-    for (uint32_t p = tid; p < c; p += SSS_NT) K[p] = (uint64_t)s_v[p] | ((uint64_t)s_seg[p] << 32);
+    for (uint32_t p = tid; p < c; p += NT) K[p] = s_out[p];    // back to the slot in run order
     SS_CLK(7);
     SS_CLK_END(0);
 }
@@ -1906,7 +1902,7 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, list);
     GLC_TRY(hipMemsetAsync(s.ss_long_count, 0, 8, st));
     const size_t long_cap = (size_t)s.rows * FS_MAXNB * SSL_PER_BUCKET;
-    hipLaunchKernelGGL(k_ss_cut, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
+    hipLaunchKernelGGL(k_ss_cut<SSS_NT>, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
                        s.fs_fill, s.ss_flag, list, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
     // the long bins: as many workgroups as fit the GPU (LDS: 17 KB / 65.5 KB each), the list's entries strided over them
     hipLaunchKernelGGL((k_ss_long<SSL_SMALL, 64, false>), dim3(256 * 9), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,

@@ -16,7 +16,7 @@ bench._GLC = glc
 d_in = (bench.text_blocks_on_device(torch, dev, rows) if kind == "text256" else bench.log_buffers_on_device(torch, dev, rows)).view(-1)
 L = glc.lib()
 L.glcSsClocks.argtypes = [C.c_void_p, C.c_int]
-cut = ["load words", "gather + keys", "pivots", "bin", "scan + scatter", "own long bins", "wait others' long bins", "write back"]
+cut = ["load words", "gather + sort samples", "merge pivots", "bin", "scan + scatter", "list long bins", "-", "write back"]
 win = ["prologue", "window words", "round setup", "gather", "count", "move + re-read", "rows", "-"]
 with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
     out = glc.compress_batch(plan, d_in, n, rows)
