@@ -1207,6 +1207,7 @@ constexpr uint32_t SS_NPL = GLC_SS_NPL, SS_NPIV0 = 64 * SS_NPL; // first cut: 25
 constexpr uint32_t SS_SHARES = 8;
 constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
 constexpr uint32_t SSL_SMALL = 1024;                           // k_ss_long: members of a "small" long bin
+// (SS_LONG, glc_internal.h: runs longer than that are cut with pivots by k_ss_long; shorter ones are counted out in the windows)
 // k_ss_windows' form of a round's key: the SS_STEP = 7 text bytes themselves in the top 56 bits (0 past the end of
 // the text) and the window slot in the low 8, so that no two keys of a window are equal: a position's new place is
 // ONE count (keys below it) and the start of its new run a second one (keys below the key with slot 0).  Bytes cannot
@@ -1291,7 +1292,7 @@ __global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text,
     __shared__ uint32_t s_cnt[2 * SS_NPIV0 + 4];               // bin counters, then bin starts (+ end)
     __shared__ uint64_t s_piv0[SS_NPIV0];                      // pivots, sorted
     __shared__ uint64_t s_pl[SS_NPL][64];                      // ... as the four sorted lists they are merged from
-    __shared__ uint32_t s_nlong, s_bound[16];
+    __shared__ uint32_t s_nlong, s_bound[64];
     __shared__ unsigned long long s_at;
     uint32_t gx, gy;
     xcd_order(gx, gy);
@@ -1392,12 +1393,12 @@ __global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text,
     // classes, counted in the halves of one 64-bit counter: up to SSL_SMALL members, and more.
     for (uint32_t i = tid; i < 2 * SS_NPIV0 + 1; i += NT) {
         const uint32_t gs = s_cnt[i], ge = s_cnt[i + 1];
-        if (ge - gs > SS_WIN) s_bound[atomicAdd(&s_nlong, 1u)] = gs | (ge << 16);
+        if (ge - gs > SS_LONG) s_bound[atomicAdd(&s_nlong, 1u)] = gs | (ge << 16);
     }
     __syncthreads();
     SS_CLK(4);                                                 // scanned, scattered, long bins listed
     const uint32_t nlong = s_nlong;
-    if (nlong && tid < 64) {                                   // (nlong <= 15)
+    if (nlong && tid < 64) {                                   // (nlong <= SSL_PER_BUCKET < 64)
         uint32_t mine = 0, big = 0;
         if (tid < nlong) { mine = s_bound[tid]; big = (mine >> 16) - (mine & 0xFFFFu) > SSL_SMALL ? 1u : 0u; }
         const unsigned long long bigs = __ballot(tid < nlong && big), smalls = __ballot(tid < nlong && !big);
@@ -1458,7 +1459,7 @@ __global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text
         uint32_t pos = A;
         while (pos < B) {
             // window [pos, W): the runs that start in it and end within SS_WIN positions (every wave works it out for itself)
-            const uint32_t lim = min(B, pos + SS_WIN);
+            const uint32_t lim = min(B, pos + SS_LONG);
             uint32_t W = lim, g0 = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {

@@ -20,7 +20,12 @@ constexpr uint32_t FS_CAP   = 4096;             // slot size in the word array
 constexpr uint32_t FS_FILLMAX = 4032;            // fullest bucket the in-LDS sort takes (a fuller one flags its block)
 constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20 (256 buckets of 4096 words: k_fs_sort 1.62 vs 1.3 ms)
 constexpr uint32_t FS_MAXNB_LOG2 = 9;
-constexpr uint32_t SSL_PER_BUCKET = 15, SSL_BIG_PER_BUCKET = 3;   // most bins of > 256 / > 1024 members a bucket of <= 4032 can have
+#ifndef GLC_SS_LONG
+#define GLC_SS_LONG 256
+#endif
+constexpr uint32_t SS_LONG = GLC_SS_LONG;        // sample sorter: a run of more positions is cut with pivots (k_ss_long), a shorter one counted out (k_ss_windows)
+constexpr uint32_t SSL_PER_BUCKET = FS_FILLMAX / (SS_LONG + 1), SSL_BIG_PER_BUCKET = 3;   // most bins of > SS_LONG / > 1024 members a bucket of <= 4032 can have
+static_assert(SSL_PER_BUCKET < 64, "k_ss_cut lists a bucket's long bins with one wave");
 
 // status bits accumulated on the device (PlanBase::d_status)
 constexpr uint32_t ST_BLOCK_OVERFLOW = 1u;       // a 4096-symbol block needs > 1536 words
