@@ -35,13 +35,13 @@ def _records(n, seed, key_len=24):
     return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
 
 
-def _phrases(n, seed, nphrases=40, plen=90):
+def _phrases(n, seed, nphrases=40, plen=90, nsep=3):
     """a few long phrases repeated thousands of times between random separators: runs of equal keys hundreds long, for a dozen rounds"""
     rng = np.random.default_rng(seed)
     ph = [bytes(rng.integers(97, 123, plen, dtype=np.uint8)) for _ in range(nphrases)]
     out = bytearray()
     while len(out) < n:
-        out += ph[int(rng.integers(0, nphrases))] + bytes(rng.integers(48, 58, 3, dtype=np.uint8))
+        out += ph[int(rng.integers(0, nphrases))] + bytes(rng.integers(48, 58, nsep, dtype=np.uint8))
     return np.frombuffer(bytes(out[:n]), dtype=np.uint8).copy()
 
 
@@ -51,6 +51,9 @@ CASES = {
     "log": (lambda: datagen.log_bytes(N), 1, 0),
     "records_long_prefix": (lambda: _records(N, 21), 1, 0),
     "phrases": (lambda: _phrases(N, 22), 1, 0),
+    # four phrases of 200 bytes, ~1270 copies each: every offset inside a phrase is a run of > 1024 suffixes that agree for up
+    # to 28 rounds (k_ss_long's four-wave instance and its all-equal rounds), then differ in the six digits behind the phrase
+    "few_long_phrases": (lambda: _phrases(N, 26, nphrases=4, plen=200, nsep=6), 1, 0),
     "two_symbols_iid": (lambda: np.random.default_rng(2).integers(0, 2, N, dtype=np.uint8) * 255, 1, 0),
     "dna": (lambda: np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(23).integers(0, 4, N)], 1, 0),
     "text_then_zipf": (lambda: np.concatenate([datagen.text_bytes(N // 2, seed=24), datagen.zipf_bytes(N // 2, seed=25)]), 1, 0),
