@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ 
 // ---------------------------------------------------------------------------
 // suffix comparison in the text (runs of equal codes; the sample tier's splitters)
 // ---------------------------------------------------------------------------
-constexpr uint32_t FS_LCP_CAP = 512;                           // a longer common prefix flags the block as deep
+// (FS_LCP_CAP, glc_internal.h: a longer common prefix flags the block as deep)
 
 // 8 bytes at any address as a big-endian number: ONE unaligned 8-byte load (global memory takes any alignment on
 // gfx9+; built from aligned dwords it is three scattered loads per lane, and the gathers of the refinement
@@ -196,7 +196,11 @@ __device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
 }
 
 // suffix a < suffix b ?  (a != b; the shorter of two suffixes that agree to the end of one is the smaller)
-__device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep, uint32_t k = 0)
+// tol (the sample sorter's second form, for blocks with repeats deeper than its cap: see ss_build): two suffixes that
+// agree in their first SS_TOL_CAP + 8 bytes are ordered by their POSITIONS -- a total order that every comparison of the
+// pass agrees on, and a (SS_TOL_CAP)-order of the suffixes, which is all the prefix-doubling rounds behind it need.
+__device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep, uint32_t k = 0,
+                                               bool tol = false)
 {
     for (;;) {
         const uint32_t m = max(a, b) + k;
@@ -210,6 +214,7 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
             if (ca != cb) return ca < cb;
             k++;
         }
+        if (tol && k > SS_TOL_CAP) { *deep = true; return a < b; }   // (*deep: "agreed up to the cap" -- a tie, not a give-up, for these callers)
         if (k > FS_LCP_CAP) { *deep = true; return false; }
     }
 }
@@ -223,7 +228,7 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
 // equal codes they decide most comparisons without going to the text (text-like blocks are exactly those with thousands
 // of suffixes under one code)
 __device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t *sp8, const uint16_t *cell, uint64_t w,
-                                              uint64_t w8, const uint8_t *T, uint32_t n, bool *deep)
+                                              uint64_t w8, const uint8_t *T, uint32_t n, bool *deep, bool tol)
 {
     const uint64_t cw = w >> 28;
     const uint32_t iw = (uint32_t)(w >> 8) & 0xFFFFFu;
@@ -240,7 +245,7 @@ __device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t
             const uint32_t is = (uint32_t)(sw >> 8) & 0xFFFFFu;
             const uint64_t s8 = sp8[mid];
             if (s8 != w8) le = s8 < w8;
-            else le = is == iw || !fs_suffix_less(T, n, iw, is, deep, 8);
+            else le = is == iw || !fs_suffix_less(T, n, iw, is, deep, 8, tol);
         }
         if (le) lo = mid; else hi = mid;
     }
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
                                                     const uint32_t *__restrict__ list, const uint64_t *__restrict__ split,
                                                     const uint16_t *__restrict__ cell, const uint64_t *__restrict__ split8,
-                                                    uint32_t *__restrict__ zero_bucket)
+                                                    uint32_t *__restrict__ zero_bucket, bool tol)
 {
     __shared__ uint32_t s_cnt[FS_MAXNB], s_start[FS_MAXNB], s_gbase[FS_MAXNB];
     __shared__ uint64_t s_w[FSP_TILE];
@@ -348,8 +353,8 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
             const uint32_t d0 = (o0 & 3) ? __builtin_amdgcn_alignbyte(by4[(o0 >> 2) + 1], by4[o0 >> 2], o0 & 3) : by4[o0 >> 2];
             const uint32_t d1 = (o1 & 3) ? __builtin_amdgcn_alignbyte(by4[min((o1 >> 2) + 1, 3u)], by4[o1 >> 2], o1 & 3) : by4[o1 >> 2];
             const uint64_t w8 = ((uint64_t)__builtin_bswap32(d0) << 32) | __builtin_bswap32(d1);
-            bk = gi < n ? ss_bucket(s_split, s_split8, s_cell, w[j], w8, T, n, &deep) : 0u;
-            if (deep) atomicOr(&flag[b], 2u);
+            bk = gi < n ? ss_bucket(s_split, s_split8, s_cell, w[j], w8, T, n, &deep, tol) : 0u;
+            if (deep && !tol) atomicOr(&flag[b], 2u);
         } else bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
         br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
         if (!SPLIT && j == 0 && gi == 0) zero_bucket[b] = bk;  // where the word of suffix 0 goes: k_fs_sort_bwt looks for the BWT index there only
@@ -1067,7 +1072,7 @@ __device__ __forceinline__ uint64_t fs_code_at(const uint2 *tab, const uint8_t *
 }
 
 // a < b for sample words [code : 36 | index : 20 | 0 : 8]; ~0 = padding, larger than everything
-__device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8_t *T, uint32_t n, bool *deep)
+__device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8_t *T, uint32_t n, bool *deep, bool tol)
 {
     if (a == ~0ull) return false;
     if (b == ~0ull) return true;
@@ -1075,25 +1080,27 @@ __device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8
     if (ca != cb) return ca < cb;
     const uint32_t ia = (uint32_t)(a >> 8) & 0xFFFFFu, ib = (uint32_t)(b >> 8) & 0xFFFFFu;
     if (ia == ib) return false;
-    return fs_suffix_less(T, n, ia, ib, deep);
+    return fs_suffix_less(T, n, ia, ib, deep, 0, tol);
 }
 
+template <bool TOL>
 __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                       uint32_t nbl, const uint2 *__restrict__ tab,
                                                       const uint32_t *__restrict__ list, uint64_t *__restrict__ split,
                                                       uint16_t *__restrict__ cell, uint32_t *__restrict__ flag,
                                                       uint32_t *__restrict__ l0_out, uint64_t *__restrict__ split8, uint32_t seed)
 {
+    constexpr bool tol = TOL;
     __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
     __shared__ uint2 s_tab[256];
-    __shared__ uint32_t s_deep;
+    __shared__ uint32_t s_deep, s_ties;
     const uint32_t b = list[blockIdx.x], tid = threadIdx.x, nb = 1u << nbl;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t S = min(nb * SS_PER_BUCKET, n);
     uint32_t S2 = 1;
     while (S2 < S) S2 <<= 1;
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
-    if (tid == 0) s_deep = 0;
+    if (tid == 0) { s_deep = 0; s_ties = 0; }
     __syncthreads();
     for (uint32_t j = tid; j < S2; j += SSA_NT) {
         uint64_t w = ~0ull;
@@ -1113,6 +1120,8 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         s_s[j] = w;
     }
     __syncthreads();
+    uint32_t ties_before = 0;                                  // (tolerant form) ties counted up to the last stage
+    bool many = false;
     for (uint32_t k = 2; k <= S2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < S2 / 2; t += SSA_NT) {
@@ -1120,16 +1129,43 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                 const uint64_t a = s_s[i], c = s_s[q];
                 bool deep = false;
                 const bool up = (i & k) == 0;                  // ascending run?
-                const bool swap = up ? ss_word_less(c, a, T, n, &deep) : ss_word_less(a, c, T, n, &deep);
-                if (deep) s_deep = 1;
+                const bool swap = up ? ss_word_less(c, a, T, n, &deep, tol) : ss_word_less(a, c, T, n, &deep, tol);
+                if (deep) { if (tol) atomicAdd(&s_ties, 1u); else s_deep = 1; }
                 if (swap) { s_s[i] = c; s_s[q] = a; }
             }
             __syncthreads();
-            if (s_deep) break;                                 // (uniform: read after the barrier, written before it)
+            // tolerant form: a comparison that ran into the cap is a tie, not a give-up -- but a block where they are the
+            // rule (periodic data, a block made of copies: a quarter or more of a stage's comparisons walk to the cap) is
+            // no business of this tier, and is given up at the first such stage (a duplicated 20 KB makes ~600 ties per
+            // stage of 8192 comparisons, a repeated page all of them)
+            if (tol) { const uint32_t now = s_ties; many = now - ties_before > S2 / 8; ties_before = now; }
+            if (s_deep || many) break;                         // (uniform: read after the barrier, written before it)
         }
-        if (s_deep) break;
+        if (s_deep || many) break;
     }
-    if (s_deep) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    if (s_deep || many) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    if (tol) {
+        // the tolerant form is for blocks with deep repeats INSIDE otherwise ordinary data.  Where a quarter of the
+        // neighbouring samples agree beyond the cap (periodic data, a block made of copies) nearly every suffix would be left
+        // to the doubling rounds anyway, and every round of this tier on the way there is wasted: such a block is given up
+        // here and takes the general sorter from scratch (repeated 4 KiB page, 64 blocks: 148 ms resumed, 116 from scratch)
+        uint32_t ties = 0;
+        for (uint32_t j = tid + 1; j < S; j += SSA_NT) {
+            const uint64_t a = s_s[j - 1], c = s_s[j];
+            if ((a >> 28) == (c >> 28)) {
+                const uint32_t ia = (uint32_t)(a >> 8) & 0xFFFFFu, ic = (uint32_t)(c >> 8) & 0xFFFFFu;
+                bool same = max(ia, ic) + SS_TOL_CAP + 8 <= n;
+                for (uint32_t k = 0; same && k < SS_TOL_CAP + 8; k += 8) same = fs_load_be64(T + ia + k) == fs_load_be64(T + ic + k);
+                ties += same ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_ties = 0;
+        __syncthreads();
+        if (ties) atomicAdd(&s_ties, ties);
+        __syncthreads();
+        if (s_ties * 4u > S) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    }
     for (uint32_t k = tid; k < nb; k += SSA_NT) {
         const uint64_t sw = k ? s_s[(uint32_t)(((uint64_t)k * S) / nb)] : 0ull;
         split[(size_t)b * FS_MAXNB + k] = sw;
@@ -1219,6 +1255,11 @@ __device__ __forceinline__ uint64_t ss_raw7(const uint8_t *T, uint32_t n, uint32
     return fs_load_be64(T + i) & ~0xFFull;                     // (callers: i + 8 <= n)
 }
 constexpr uint32_t SS_MAXSTEP = FS_LCP_CAP / SS_STEP + 1;      // rounds of a run before the block is given up as deep
+// ... or, in the tolerant form (ss_build), SS_TOL_MAXSTEP rounds before the run is left as it is: its members agree in more
+// than SS_TOL_CAP + 8 bytes, the rounds of prefix doubling behind the sample sorter order them.  A capped run's step count:
+constexpr uint32_t SS_TOL_MAXSTEP = SS_TOL_CAP / SS_STEP + 1;
+constexpr uint32_t SS_CAPPED = 255;
+static_assert(SS_MAXSTEP + 2 < SS_CAPPED, "the step field of a run descriptor holds the rounds and the marker");
 
 // run descriptor of a position: start : 12 | end : 12 | rounds done : 8   (a decided position: end = start + 1)
 __device__ __forceinline__ uint32_t ss_run(uint32_t ss, uint32_t se, uint32_t st) { return ss | (se << 12) | (st << 24); }
@@ -1428,7 +1469,7 @@ template <uint32_t CAP, uint32_t NT, bool BIG>
 __global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                 uint64_t *__restrict__ keys, size_t kstride, uint32_t *__restrict__ flag,
                                                 const uint32_t *__restrict__ l0_in, const uint2 *__restrict__ long_list,
-                                                size_t long_cap, const unsigned long long *__restrict__ long_count)
+                                                size_t long_cap, const unsigned long long *__restrict__ long_count, bool tol)
 {
     __shared__ uint64_t s_kl[CAP];
     __shared__ uint32_t s_vl[CAP], s_segl[CAP];
@@ -1475,7 +1516,15 @@ __global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text
             // ---- the run at pos is longer than a window: cut it ----
             const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g0);
             const uint32_t ss = g & 0xFFFu, se = (g >> 12) & 0xFFFu, st = g >> 24, gsz = se - ss;
-            if (st > SS_MAXSTEP) { deep = true; break; }
+            if (st == SS_CAPPED) { pos = se; continue; }         // (tolerant form: left as it is)
+            if (st > (tol ? SS_TOL_MAXSTEP : SS_MAXSTEP)) {
+                if (!tol) { deep = true; break; }
+                const uint32_t rc = ss_run(ss, se, SS_CAPPED);
+                for (uint32_t p = ss + tid; p < se; p += NT) s_seg[p] = rc;
+                sync();
+                pos = se;
+                continue;
+            }
             const uint32_t off = l0 + SS_STEP * st;
             {   // does a member's load reach the end of the text?  Then the whole cut uses the 9-bit digits (ss_sym_key)
                 bool t = false;
@@ -1565,6 +1614,11 @@ __global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text
 
 constexpr int SSW_PER_BUCKET = 4;                              // one-wave workgroups per bucket; wave w takes shares w, w + 4, ...
 
+// a run descriptor whose positions still have to be ordered: more than one member, and not left as it is (SS_CAPPED)
+template <bool TOL>
+__device__ __forceinline__ bool ss_undecided_t(uint32_t g) { return ((g >> 12) & 0xFFFu) - (g & 0xFFFu) > 1 && (!TOL || (g >> 24) != SS_CAPPED); }
+
+template <bool TOL>
 __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                       const uint64_t *__restrict__ keys, size_t kstride,
                                                       const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
@@ -1573,6 +1627,8 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                                                       size_t bwt_stride, int *__restrict__ d_index,
                                                       uint32_t *__restrict__ sa_out, size_t sa_stride)
 {
+    constexpr bool tol = TOL;
+    auto ss_undecided = [](uint32_t g) { return ss_undecided_t<TOL>(g); };
     __shared__ uint64_t s_kw[SS_WIN];                          // keys of the window
     __shared__ uint32_t s_vw[SS_WIN];                          // index << 8 | BWT byte
     __shared__ uint32_t s_sw[SS_WIN];                          // run descriptors (bucket positions)
@@ -1619,20 +1675,34 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                 if (p < lim) {
                     const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu;
                     if (se > lim) W = min(W, ss);              // a run that runs out of the window: the window ends before it
-                    und |= se - ss > 1;
                 }
             }
             W = (uint32_t)wave_min_u64((uint64_t)W);
             SS_CLK(1);                                         // window's words loaded
-            if (W == pos) { deep = true; break; }               // (k_ss_cut leaves no run longer than a window)
+            if (W == pos) {
+                // a run longer than a window: k_ss_long leaves none -- except, in the tolerant form, the runs it capped.
+                // Their rows are written as they are (any order: the doubling rounds behind this kernel order them).
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g4[0]);
+                if (!tol || (g >> 24) != SS_CAPPED) { deep = true; break; }
+                const uint32_t se = (g >> 12) & 0xFFFu;
+                for (uint32_t p = pos + lane; p < se; p += 64) {
+                    const uint32_t v = (uint32_t)K[p] & (uint32_t)FS_LOW_MASK, idx = v >> 8;
+                    if (O) O[p] = (uint8_t)v;
+                    if (SAo) SAo[p] = idx;
+                    if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
+                }
+                pos = se;
+                continue;
+            }
             und = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t p = pos + lane + 64 * j;
-                if (p < W) { VW[p - pos] = x4[j]; SW[p - pos] = g4[j]; und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1; }
+                if (p < W) { VW[p - pos] = x4[j]; SW[p - pos] = g4[j]; und |= ss_undecided(g4[j]); }
             }
             __builtin_amdgcn_wave_barrier();
             // ---- window [pos, W): rounds in registers until every position is decided ----
+            uint32_t rounds_here = 0;
             while (__ballot(und) != 0) {
                 uint64_t key[4];
                 uint32_t v4[4], at[4];
@@ -1643,15 +1713,22 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                     key[j] = 0; v4[j] = 0; at[j] = 0;
                     if (p < W) {
                         const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
-                        if (se - ss > 1) {
+                        if (ss_undecided(g4[j]) && st > (tol ? SS_TOL_MAXSTEP : SS_MAXSTEP)) {
+                            if (tol) { g4[j] = ss_run(ss, se, SS_CAPPED); SW[p - pos] = g4[j]; }   // left as it is (all its members do this)
+                            else dp = true;
+                        }
+                        if (ss_undecided(g4[j])) {
                             v4[j] = VW[p - pos];
                             at[j] = (v4[j] >> 8) + l0 + SS_STEP * st;
-                            dp |= st > SS_MAXSTEP;
                             tail |= at[j] + 8 > n;                 // its 7 bytes (or the 8-byte load) reach the end of the text
                         }
                     }
                 }
                 if (__ballot(dp) != 0) { deep = true; break; }
+                // (a window this deep: another wave may have given the block up meanwhile -- a run 75 rounds deep costs
+                //  ~0.4 ms and a block with a duplicated region has thousands of them; without this look every wave went
+                //  through its own before the kernel ended, 6 ms per 64 such blocks)
+                if (!tol && (++rounds_here & 7u) == 0 && __hip_atomic_load(&flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
                 uint32_t np[4];
                 SS_CLK(2);                                     // round set up
 #ifdef GLC_SS_CLOCKS
@@ -1674,7 +1751,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                         const uint32_t p = pos + lane + 64 * j;
                         if (p < W) {
                             s_cw[p - pos] = 0;
-                            if (((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) {
+                            if (ss_undecided(g4[j])) {
                                 key[j] = ss_raw7(T, n, at[j]) | (uint64_t)(p - pos);
                                 KW[p - pos] = key[j];
                             }
@@ -1688,7 +1765,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                         np[j] = 0xFFFFFFFFu;
                         if (p < W) {
                             const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
-                            if (se - ss > 1) {
+                            if (ss_undecided(g4[j])) {
                                 const uint64_t klow = key[j] & ~0xFFull;
                                 uint32_t below = 0, below_run = 0;
 #pragma unroll 4
@@ -1715,7 +1792,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const uint32_t p = pos + lane + 64 * j;
-                        if (p < W && ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1) {
+                        if (p < W && ss_undecided(g4[j])) {
                             key[j] = ss_sym_key(ss_sym_load(T, n, at[j]));
                             KW[p - pos] = key[j];
                         }
@@ -1727,7 +1804,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                         np[j] = 0xFFFFFFFFu;
                         if (p < W) {
                             const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
-                            if (se - ss > 1) {
+                            if (ss_undecided(g4[j])) {
                                 uint32_t less = 0, eqt = 0, eqb = 0;
                                 for (uint32_t q = ss; q < se; q++) {
                                     const uint64_t kq = KW[q - pos];
@@ -1755,7 +1832,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                             g4[j] = ss_run(ss, ss + s_cw[ss - pos], g4[j] >> 24);
                             SW[p - pos] = g4[j];
                         }
-                        und |= ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) > 1;
+                        und |= ss_undecided(g4[j]);
                     }
                 }
                 SS_CLK(5);                                     // moved, runs re-read
@@ -1784,13 +1861,16 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
 // second attempt: the blocks of `list` whose ONLY trouble was a bucket past its slot (flag == 1: the samples' luck --
 // bucket populations of text-like blocks have a heavier tail than 32 samples per bucket suggest, ~1 % of log blocks end up
 // with a bucket of 4033-4200 words) are listed again, their flags and fills cleared, for a pass with other samples
+// (want = 2: the blocks whose only trouble was a repeat deeper than the cap -- listed for the tolerant form)
 __global__ void k_ss_retry_list(uint32_t *__restrict__ flag, const uint32_t *__restrict__ list, uint32_t nflag,
-                                uint32_t *__restrict__ list2, uint32_t *__restrict__ count, uint32_t *__restrict__ fill)
+                                uint32_t *__restrict__ list2, uint32_t *__restrict__ count, uint32_t *__restrict__ fill,
+                                uint32_t want, const uint32_t *__restrict__ dup)
 {
     const uint32_t j = blockIdx.x;
     if (j >= nflag) return;
     const uint32_t b = list[j];
-    if (flag[b] != 1u) return;                                 // (uniform per workgroup)
+    if (flag[b] != want) return;                               // (uniform per workgroup)
+    (void)dup;
     __shared__ uint32_t s_at;
     if (threadIdx.x == 0) s_at = atomicAdd(count, 1u);
     for (uint32_t i = threadIdx.x; i < FS_MAXNB; i += blockDim.x) fill[(size_t)b * FS_MAXNB + i] = 0;
@@ -1859,7 +1939,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nbk), dim3(FSP_NT), 0, st, text + (size_t)b0 * text_stride,
                            text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
                            s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0, (const uint32_t *)nullptr,
-                           (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr, s.fs_zero + b0);
+                           (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr, s.fs_zero + b0, false);
         if (pi >= 0) s.prof->end(pi, u, st);
         hipLaunchKernelGGL(k_fs_scan, dim3(nbk), dim3(FS_MAXNB), 0, st, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB,
                            s.fs_flag + b0, (const uint32_t *)nullptr);
@@ -1889,17 +1969,26 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out, uint32_t attempt)
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
-    // attempt 0: the blocks k_fs_finish listed in ss_list; attempt 1: the ones k_ss_retry_list listed behind them
-    const uint32_t *list = s.ss_list + (attempt ? s.rows : 0u);
+    // attempt 0: the blocks k_fs_finish listed in ss_list; attempt 1: the ones k_ss_retry_list listed behind them (a bucket
+    // past its slot: other samples); attempt 2: the ones listed behind those (a repeat deeper than the cap), in the TOLERANT
+    // form -- suffixes that agree in more than FS_LCP_CAP + 8 bytes are left in the order of their positions (comparisons)
+    // or as they are (runs), nothing is given up on for depth: the result is the suffixes ordered by their first
+    // FS_LCP_CAP symbols, for the prefix-doubling rounds to finish (sa_build_finish)
+    const uint32_t *list = s.ss_list + (size_t)attempt * s.rows;
+    const bool tol = attempt == 2;
     if (attempt == 0) {
         GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
         GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
     }
-    hipLaunchKernelGGL(k_ss_sample, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, list,
-                       s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt);
+    if (tol)
+        hipLaunchKernelGGL(k_ss_sample<true>, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, list,
+                           s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt);
+    else
+        hipLaunchKernelGGL(k_ss_sample<false>, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, list,
+                           s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt);
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
                        n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, list, s.ss_split, s.ss_cell,
-                       s.ss_split + (size_t)s.rows * FS_MAXNB, (uint32_t *)nullptr);
+                       s.ss_split + (size_t)s.rows * FS_MAXNB, (uint32_t *)nullptr, tol);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, list);
     GLC_TRY(hipMemsetAsync(s.ss_long_count, 0, 8, st));
     const size_t long_cap = (size_t)s.rows * FS_MAXNB * SSL_PER_BUCKET;
@@ -1907,23 +1996,27 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                        s.fs_fill, s.ss_flag, list, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
     // the long bins: as many workgroups as fit the GPU (LDS: 17 KB / 65.5 KB each), the list's entries strided over them
     hipLaunchKernelGGL((k_ss_long<SSL_SMALL, 64, false>), dim3(256 * 9), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
-                       s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
+                       s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count, tol);
     hipLaunchKernelGGL((k_ss_long<FS_FILLMAX, 256, true>), dim3(256 * 2), dim3(256), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
-                       s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
-    hipLaunchKernelGGL(k_ss_windows, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
-                       s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out,
-                       (size_t)s.nmax);
+                       s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count, tol);
+    if (tol)
+        hipLaunchKernelGGL(k_ss_windows<true>, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+                           s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+    else
+        hipLaunchKernelGGL(k_ss_windows<false>, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+                           s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_ss_finish, dim3((nflag + 255) / 256), dim3(256), 0, st, s.ss_flag, list, nflag, n, s.fs_lcnt,
                        s.fs_nflag + 1);
     return hipGetLastError();
 }
 
-// lists the blocks of the first attempt that deserve a second one (see k_ss_retry_list); their number -> s.fs_nflag[2]
-hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s)
+// lists the blocks of the first attempt (`from` = 0) that deserve another one, behind the list of attempt `to` - 1: to = 1,
+// flag == 1 (a bucket past its slot); to = 2, flag == 2 (a repeat deeper than the cap).  Their number -> s.fs_nflag[2]
+hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to)
 {
     GLC_TRY(hipMemsetAsync(s.fs_nflag + 2, 0, 4, st));
-    hipLaunchKernelGGL(k_ss_retry_list, dim3(nflag), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, s.ss_list + s.rows,
-                       s.fs_nflag + 2, s.fs_fill);
+    hipLaunchKernelGGL(k_ss_retry_list, dim3(nflag), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, s.ss_list + (size_t)to * s.rows,
+                       s.fs_nflag + 2, s.fs_fill, to, s.fs_dup);
     return hipGetLastError();
 }
 

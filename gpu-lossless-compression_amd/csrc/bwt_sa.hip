@@ -805,6 +805,102 @@ __global__ void k_sa_export(const uint32_t *__restrict__ sa, uint32_t n, uint32_
 }
 
 // ---------------------------------------------------------------------------
+// Resuming from the sample sorter's tolerant form (bwt_bucket.hip ss_build, attempt 2): s.sa holds the suffixes of a block
+// ordered by their first SS_TOL_CAP symbols -- exact everywhere except that suffixes which agree in more than that come in
+// no particular order.  The GROUPS the doubling rounds have to order are the maximal ranges of neighbouring rows whose
+// suffixes share SS_TOL_CAP symbols, found by looking (not taken from the sample sorter's own bookkeeping: its buckets are
+// cut at suffixes compared up to the cap, so a group can straddle two of them).  The words the rank kernel expects:
+// [group number : 44 | suffix : 20] in row order; everything else -- ISA, the compacted list of the unresolved, BWT
+// bytes, index -- comes out of the general sorter's own first round (k_sa_rank1<true>, MODE_ISA) over these words.
+// ---------------------------------------------------------------------------
+constexpr uint32_t GRP_NT = 256;
+constexpr uint32_t GRP_SAME = 0x80000000u;                     // marks a row that continues its predecessor's group, in s.sa for a moment
+
+__global__ __launch_bounds__(GRP_NT) void k_grp_flags(const uint8_t *__restrict__ text, size_t text_stride, uint32_t n,
+                                                      uint32_t *__restrict__ sa, uint32_t nmax, const uint32_t *__restrict__ list,
+                                                      const uint32_t *__restrict__ flag, uint32_t *__restrict__ tcount,
+                                                      uint32_t max_gtiles, uint32_t cap)
+{
+    __shared__ uint32_t s_c[GRP_NT / 64];
+    const uint32_t b = list[blockIdx.y], tid = threadIdx.x, r = blockIdx.x * GRP_NT + tid;
+    if (flag[b]) return;                                       // the tolerant form gave this block up too (a bucket past its slot)
+    const uint8_t *T = text + (size_t)b * text_stride;
+    uint32_t *SA = sa + (size_t)b * nmax;
+    bool head = false;
+    if (r < n) {
+        const uint32_t cur = SA[r];
+        bool same = false;
+        if (r > 0) {
+            const uint32_t prev = SA[r - 1];                   // (a neighbour may have set the mark in it already)
+            const uint32_t a = prev & ~GRP_SAME, c = cur & ~GRP_SAME;
+            if (max(a, c) + cap <= n) {                        // a suffix shorter than the cap shares less than the cap with anybody
+                same = true;
+                for (uint32_t k = 0; k < cap; k += 8) {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, T + a + k, 8);
+                    __builtin_memcpy(&y, T + c + k, 8);
+                    if (x != y) { same = false; break; }
+                }
+            }
+        }
+        head = !same;
+        if (same) atomicOr(&SA[r], GRP_SAME);                   // (atomic: the row's own thread only ever ORs this bit; readers mask it)
+    }
+    const uint32_t cw = (uint32_t)__popcll(__ballot(head));
+    if ((tid & 63) == 0) s_c[tid >> 6] = cw;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < GRP_NT / 64; w++) t += s_c[w];
+        tcount[(size_t)b * max_gtiles + blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of a block's tile counts, in place
+__global__ __launch_bounds__(1024) void k_grp_scan(uint32_t *__restrict__ tcount, uint32_t max_gtiles, uint32_t ntiles,
+                                                   const uint32_t *__restrict__ list, const uint32_t *__restrict__ flag)
+{
+    __shared__ uint32_t s_tmp[1024 / 64 + 1];
+    const uint32_t b = list[blockIdx.x], tid = threadIdx.x;
+    if (flag[b]) return;
+    uint32_t *C = tcount + (size_t)b * max_gtiles;
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 1024) {
+        const uint32_t t = t0 + tid, c = t < ntiles ? C[t] : 0u;
+        uint32_t tot = 0;
+        const uint32_t e = block_excl_add<1024>(c, s_tmp, &tot);
+        if (t < ntiles) C[t] = carry + e;
+        carry += tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(GRP_NT) void k_grp_keys(uint32_t n, uint32_t *__restrict__ sa, uint32_t nmax,
+                                                     const uint32_t *__restrict__ list, const uint32_t *__restrict__ flag,
+                                                     const uint32_t *__restrict__ tcount, uint32_t max_gtiles,
+                                                     uint64_t *__restrict__ key, uint32_t *__restrict__ cnt)
+{
+    __shared__ uint32_t s_c[GRP_NT / 64];
+    const uint32_t b = list[blockIdx.y], tid = threadIdx.x, r = blockIdx.x * GRP_NT + tid;
+    if (flag[b]) return;
+    uint32_t *SA = sa + (size_t)b * nmax;
+    const uint32_t v = r < n ? SA[r] : GRP_SAME;
+    const bool head = !(v & GRP_SAME);
+    const uint64_t bal = __ballot(head);
+    if ((tid & 63) == 0) s_c[tid >> 6] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t gid = tcount[(size_t)b * max_gtiles + blockIdx.x];          // heads in the tiles before this one
+    for (uint32_t w = 0; w < (tid >> 6); w++) gid += s_c[w];
+    gid += (uint32_t)__popcll(bal & ((2ull << (tid & 63)) - 1ull));       // ... and up to this row: the row's group, counted from 1
+    if (r < n) {
+        SA[r] = v & ~GRP_SAME;
+        key[(size_t)b * nmax + r] = ((uint64_t)gid << VAL_BITS) | (uint64_t)(v & ~GRP_SAME);
+    }
+    if (blockIdx.x == 0 && tid == 0) cnt[b] = n;
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 #define GLC_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
@@ -835,13 +931,15 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.fs_dup, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_zero, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_nflag, 16));
-    GLC_TRY(A((void **)&s.ss_list, (size_t)rows * 4 * 2));
+    GLC_TRY(A((void **)&s.ss_list, (size_t)rows * 4 * 3));
     GLC_TRY(A((void **)&s.ss_split, (size_t)rows * FS_MAXNB * 8 * 2));    // words, then the first 8 text bytes of every splitter
     GLC_TRY(A((void **)&s.ss_flag, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.ss_cell, (size_t)rows * 4098 * 2));
     GLC_TRY(A((void **)&s.ss_l0, (size_t)rows * FS_MAXNB * 4));
     GLC_TRY(A((void **)&s.ss_long, (size_t)rows * FS_MAXNB * (SSL_PER_BUCKET + SSL_BIG_PER_BUCKET) * sizeof(uint2)));
     GLC_TRY(A((void **)&s.ss_long_count, 8));
+    GLC_TRY(A((void **)&s.ss_gtile, (size_t)rows * ((nmax + GRP_NT - 1) / GRP_NT) * 4));
+    GLC_TRY(A((void **)&s.ss_cnt2, (size_t)rows * 4));
     s.fs_wl_cap = nmax / 8 < 1024 ? 1024 : nmax / 8;
     GLC_TRY(A((void **)&s.fs_wl, (size_t)rows * s.fs_wl_cap * 16));
     GLC_TRY(A((void **)&s.fs_wlcnt, (size_t)rows * 4));
@@ -883,7 +981,7 @@ hipError_t sa_general_reserve(SaScratch &s, bool only_sa)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.ss_long, s.ss_long_count, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
+    void *ps[] = {s.keyA, s.ss_long, s.ss_long_count, s.ss_gtile, s.ss_cnt2, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
@@ -956,16 +1054,18 @@ static hipError_t refine_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, co
 }
 
 // the general sorter; cnt0 (optional) = per-block element counts: n for the blocks to sort, 0 for the others
+// resume_depth != 0: s.keyA already holds, for the blocks of cnt0, the words [group : 44 | suffix : 20] of an order that is
+// exact for the first resume_depth symbols (k_grp_keys): no sort from the text, prefix doubling from that depth on
 static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
                                    SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, int *rounds_out,
-                                   const uint32_t *cnt0, uint32_t nsorted)
+                                   const uint32_t *cnt0, uint32_t nsorted, uint32_t resume_depth = 0)
 {
     GLC_TRY(sa_general_reserve(s, false));
     uint32_t tiles = (n + SA_TILE - 1) / SA_TILE;
     uint64_t *cur = s.keyA, *alt = s.keyB;
     double live_total = (double)n * nsorted;
     GLC_TRY(hipMemsetAsync(s.d_max_cnt, 0, 16, st));          // [2] doubles as the device error word of the sort
-    {   // 41 key bits at [20, 61): 8+8+8+8+9
+    if (!resume_depth) {   // 41 key bits at [20, 61): 8+8+8+8+9
         PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 16, VAL_BITS + 24, VAL_BITS + 32}, {8, 8, 8, 8, 9}};
         const TextSrc src{text, text_stride, n};               // pass 0 and the histograms read the text itself
         GLC_TRY(radix_sort(st, cur, alt, cnt0, n, pp, tiles, nblk, s, live_total, &src));
@@ -978,8 +1078,8 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
     // `depth` = symbols the current order is exact for; text refinement adds 3 per round,
     // prefix doubling doubles it.  Text refinement first: data whose suffixes separate
     // within ~11 symbols (i.i.d. bytes, float mantissas) never builds the rank array.
-    int mode = s.force_isa ? MODE_ISA : MODE_TEXT;
-    uint32_t depth = 5, live = n, text_rounds = 0;
+    int mode = (s.force_isa || resume_depth) ? MODE_ISA : MODE_TEXT;
+    uint32_t depth = resume_depth ? resume_depth : 5, live = n, text_rounds = 0;
     int rounds = 0;
     if (mode == MODE_ISA) {
         // ranks are needed from the first refinement on: k_sa_rank<true> writes them in MODE_ISA
@@ -1093,6 +1193,7 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
     s.last_flagged = nflag;
     s.last_general = 0;
     s.last_retried = 0;
+    s.last_resumed = 0;
     if (nflag == 0) return hipSuccess;
     if (nflagged) *nflagged = nflag;
     if (s.sorter != 3) {
@@ -1122,10 +1223,49 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
                 left = s.h_max_cnt[5];
             }
         }
+        s.last_general = left;                                 // what the sample sorter (both attempts) gave up on
+        s.last_resumed = 0;
+        if (left && s.resume_min) {
+            // Blocks whose only trouble was a repeat deeper than the cap (zero pages, a duplicated region, long periodic
+            // stretches inside otherwise ordinary data): the sample sorter once more, in its TOLERANT form and writing the
+            // suffix array -- everything it can order it orders, suffixes that agree in more than the cap stay as they come
+            // -- then prefix doubling from that depth on, over the groups of rows that still share the cap (a few thousand
+            // suffixes of such a block for ~11 rounds, where the general sorter from scratch takes a million through ~20).
+            GLC_TRY(ss_retry_prepare(st, nflag, s, 2));
+            GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.fs_nflag + 2, 4, hipMemcpyDeviceToHost, st));
+            GLC_TRY(hipEventRecord(s.ev_flag, st));
+            GLC_TRY(hipEventSynchronize(s.ev_flag));
+            const uint32_t deep2 = s.h_max_cnt[6];
+            // (a few blocks: the extra pass and its launches cost what the shorter doubling saves -- 2.6 against 2.2-2.7 ms for
+            //  one block, 3.5 against 4.4 for eight)
+            if (deep2 >= s.resume_min) {
+                GLC_TRY(sa_general_reserve(s, false));
+                s.h_max_cnt[7] = left - deep2;                 // the others stay given up on; this attempt adds its own
+                GLC_TRY(hipMemcpyAsync(s.fs_nflag + 1, s.h_max_cnt + 7, 4, hipMemcpyHostToDevice, st));
+                GLC_TRY(ss_build(st, text, text_stride, n, deep2, s, nullptr, 0, nullptr, s.sa, 2));
+                GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 5, s.fs_nflag + 1, 4, hipMemcpyDeviceToHost, st));
+                const uint32_t *list3 = s.ss_list + 2 * (size_t)s.rows;
+                const uint32_t gt = (n + GRP_NT - 1) / GRP_NT, max_gt = (s.nmax + GRP_NT - 1) / GRP_NT;
+                GLC_TRY(hipMemsetAsync(s.ss_cnt2, 0, (size_t)s.rows * 4, st));
+                hipLaunchKernelGGL(k_grp_flags, dim3(gt, deep2), dim3(GRP_NT), 0, st, text, text_stride, n, s.sa, s.nmax, list3,
+                                   s.ss_flag, s.ss_gtile, max_gt, SS_TOL_CAP);
+                hipLaunchKernelGGL(k_grp_scan, dim3(deep2), dim3(1024), 0, st, s.ss_gtile, max_gt, gt, list3, s.ss_flag);
+                hipLaunchKernelGGL(k_grp_keys, dim3(gt, deep2), dim3(GRP_NT), 0, st, n, s.sa, s.nmax, list3, s.ss_flag,
+                                   s.ss_gtile, max_gt, s.keyA, s.ss_cnt2);
+                GLC_TRY(hipEventRecord(s.ev_flag, st));
+                GLC_TRY(hipEventSynchronize(s.ev_flag));
+                const uint32_t left2 = s.h_max_cnt[5];          // = left - deep2 + what the tolerant form gave up on (a bucket past its slot)
+                const uint32_t resumed = left - left2;
+                if (resumed)
+                    GLC_TRY(sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nullptr, s.ss_cnt2,
+                                             resumed, SS_TOL_CAP));
+                s.last_resumed = resumed;
+                left = left2;
+            }
+        }
         nflag = left;
         if (nflag == 0) return hipSuccess;
-    }
-    s.last_general = nflag;
+    } else s.last_general = nflag;
     return sa_build_general(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nullptr, s.fs_lcnt, nflag);
 }
 

@@ -587,8 +587,9 @@ CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode)
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     SaScratch *s = sa_of(p);
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
-    if (mode < 0 || mode > 4) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
-    s->sorter = mode;
+    if (mode < 0 || mode > 6) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    s->sorter = mode >= 5 ? 0 : mode;
+    s->resume_min = mode == 5 ? 0u : (mode == 6 ? 1u : 4u);
     return CUDPP_SUCCESS;
 }
 
@@ -621,6 +622,17 @@ CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out)
     SaScratch *s = sa_of(p);
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
     out[0] = s->last_retried;
+    return CUDPP_SUCCESS;
+}
+
+// out[0] = blocks of the plan's last call whose doubling rounds resumed from the sample sorter's tolerant form
+CUDPPResult glcPlanLastSortResumed(CUDPPHandle planHandle, unsigned int *out)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    out[0] = s->last_resumed;
     return CUDPP_SUCCESS;
 }
 

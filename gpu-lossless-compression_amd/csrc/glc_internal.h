@@ -20,6 +20,11 @@ constexpr uint32_t FS_CAP   = 4096;             // slot size in the word array
 constexpr uint32_t FS_FILLMAX = 4032;            // fullest bucket the in-LDS sort takes (a fuller one flags its block)
 constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20 (256 buckets of 4096 words: k_fs_sort 1.62 vs 1.3 ms)
 constexpr uint32_t FS_MAXNB_LOG2 = 9;
+constexpr uint32_t FS_LCP_CAP = 512;             // suffix comparisons and the sample sorter's rounds give up behind this many symbols
+#ifndef GLC_SS_TOL_CAP
+#define GLC_SS_TOL_CAP 128
+#endif
+constexpr uint32_t SS_TOL_CAP = GLC_SS_TOL_CAP;  // ... and in the sample sorter's tolerant form STOP behind this many: prefix doubling takes over from there (a multiple of 8)
 #ifndef GLC_SS_LONG
 #define GLC_SS_LONG 256
 #endif
@@ -162,9 +167,13 @@ struct SaScratch {
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build the bucket sorter gave up on
     uint32_t  last_retried = 0;                  // ... the sample sorter took in a second attempt (a bucket past its slot in the first)
     uint32_t  last_general = 0;                  // ... of which the sample sorter gave up on too (general sorter)
+    uint32_t  last_resumed = 0;                  // ... of which the doubling rounds RESUMED from the sample sorter's tolerant form
+    uint32_t *ss_gtile = nullptr;                // [rows][ceil(nmax / 256)] group heads per tile of rows (k_grp_*)
+    uint32_t *ss_cnt2 = nullptr;                 // [rows] n for the blocks the resumed doubling works on, else 0
+    uint32_t  resume_min = 4;                    // fewest blocks given up on for depth that are worth the tolerant pass (0: never; sorter modes 5 / 6)
     bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
     // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
-    uint32_t *ss_list = nullptr;                 // [2 rows] their block numbers; behind them the ones that get a second attempt
+    uint32_t *ss_list = nullptr;                 // [3 rows] their block numbers; behind them the ones that get a second attempt; then the ones for the tolerant form
     uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]
     uint32_t *ss_flag = nullptr;                 // [rows] this tier's give-up flags
     uint32_t *ss_l0 = nullptr;                   // [rows][FS_MAXNB] common prefix of a bucket's two splitters
@@ -203,7 +212,7 @@ uint32_t   fs_bucket_log2(uint32_t n);
 hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nflag, SaScratch &s,
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out, uint32_t attempt = 0);
 // blocks of the first attempt whose only trouble was a bucket past its slot -> listed behind ss_list, count in s.fs_nflag[2]
-hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s);
+hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to = 1);
 
 // copy SA to the cudppSuffixArray layout (out[0]=n, out[1..n]=SA)
 hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out);

@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcGenFloatPhilox", "glcPlanKernelProfileLost",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanLastSortResumed", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcGenFloatPhilox", "glcPlanKernelProfileLost",
     "glcCompressBatchCompact", "glcDecompressBatchCompact",
 ]
 CULZSS_SYMBOLS = [
@@ -105,6 +105,7 @@ def lib():
     L.glcPlanLastSortStats.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanLastSortStatsEx.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanLastSortRetries.argtypes = [sz, C.POINTER(C.c_uint)]
+    L.glcPlanLastSortResumed.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanDebugSortFlags.argtypes = [sz, C.POINTER(C.c_uint), C.POINTER(C.c_uint), sz]
     L.glcPlanDebugBucketFill.argtypes = [sz, sz, C.POINTER(C.c_uint)]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
@@ -293,6 +294,12 @@ class Plan:
         """blocks of the last call the sample sorter finished in its second attempt (other samples)"""
         a = (C.c_uint * 1)()
         _chk("glcPlanLastSortRetries", lib().glcPlanLastSortRetries(self.handle, a))
+        return a[0]
+
+    def last_sort_resumed(self):
+        """blocks of the last call whose prefix doubling resumed from the sample sorter's order (deep repeats inside them)"""
+        a = (C.c_uint * 1)()
+        _chk("glcPlanLastSortResumed", lib().glcPlanLastSortResumed(self.handle, a))
         return a[0]
 
     def enable_timing(self, mode=1):

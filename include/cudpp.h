@@ -252,7 +252,10 @@ CUDPPResult glcHuffmanEncodeBatch(CUDPPHandle planHandle, const unsigned char *d
  * (buckets cut at sampled splitter suffixes, runs of equal codes refined from the text; text, logs), and for
  * what that flags (repeats deeper than ~500 symbols) the general sorter; 1: general sorter only; 2: general
  * sorter, prefix doubling from the first refinement round; 3: bucket sorter, then general sorter; 4: sample
- * sorter first, for a caller that knows its data is text-like (saves the bucket sorter's wasted attempt).  All
+ * sorter first, for a caller that knows its data is text-like (saves the bucket sorter's wasted attempt); 5: as 0, but
+ * a block the sample sorter gives up on for depth always goes to the general sorter from scratch (0: when a call has four
+ * or more such blocks, the sample sorter finishes what it can of them and the doubling rounds resume from there); 6: as 0,
+ * resuming for a single such block too.  All
  * produce the same bytes (the suffix array of a block is unique); the knob exists for tests and A/B timing. */
 CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode);
 /* number of blocks of the plan's last call the bucket sorter gave up on (0 for i.i.d.-like data) */
@@ -262,6 +265,10 @@ CUDPPResult glcPlanLastSortStatsEx(CUDPPHandle planHandle, unsigned int *out2);
 /* out[0] = how many blocks of the last call the sample sorter finished in its SECOND attempt (a bucket past its slot with the
  * first samples; other samples are drawn once before the block would go to the general sorter) */
 CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out);
+/* out[0] = how many of the blocks the sample sorter gave up on FOR DEPTH ALONE (out2[1] above counts them) were finished by
+ * prefix doubling RESUMED from its order -- the sample sorter run once more in a form that leaves suffixes agreeing in more
+ * than ~512 symbols as they come, doubling from that depth over the rows that still tie -- instead of from scratch */
+CUDPPResult glcPlanLastSortResumed(CUDPPHandle planHandle, unsigned int *out);
 /* diagnostics (tests, tools/exp): per-block give-up flags of the last sort (bucket sorter: 1 bucket overflow / text-like, 2 deep,
  * 4 work list full; sample sorter: 1 bucket overflow, 2 deep), numBlocks entries each, either pointer may be NULL; and the
  * 512 bucket fills of one block as the last bucketing pass left them.  Both wait for the plan's stream. */
