@@ -502,6 +502,47 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
                                    "what": "repeats deeper than the sample sorter's ~500-symbol cap (repeated 4 KiB page, one byte repeated up to the "
                                            "last position, two-byte period, text with a 2000-byte phrase every 16 KiB): the general sorter's cliff"}
     del d_deep, outd, back
+    # ... and what sits between: ordinary text / log blocks with something deep INSIDE (64 distinct blocks: 16 text blocks
+    # with a 20 000-byte region pasted in a second time, 16 with a 2000-byte phrase every 16 KiB, 16 log buffers with a run of
+    # 1500 blanks and one of 9000 zero bytes, 16 with a duplicated region).  The sample sorter gives these up for depth too;
+    # when a call has four or more of them it finishes what it can of them in a tolerant form and the doubling rounds
+    # resume from there.  Timed both ways (glcPlanSetSorter 5 = from scratch).
+    tb = text_blocks_on_device(torch, dev, 32, seed=0x5EED0011).view(32, n).clone()
+    lb = log_buffers_on_device(torch, dev, 32, seed=0x5EED0013).view(32, n).clone()
+    tb[:16, 600000:620000] = tb[:16, 100000:120000]
+    for o in range(5000, n - 2000, 16384):
+        tb[16:, o:o + 2000] = tb[16:, :2000]
+    lb[:16, 200000:201500] = 32
+    lb[:16, 700000:709000] = 0
+    lb[16:, 500000:520000] = lb[16:, 40000:60000]
+    d_pd = torch.cat([tb, lb]).reshape(-1).contiguous()
+    npd = 64
+    del tb, lb
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=npd) as plan:
+        outp = glc.compress_batch(plan, d_pd, n, npd)
+        plan.synchronize()
+        res = {}
+        for mode in (0, 5):
+            plan.set_sorter(mode)
+            ts = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                glc.compress_batch_into(plan, d_pd, n, npd, outp)
+                plan.synchronize()
+                ts.append(time.perf_counter() - t0)
+            res[mode] = (min(ts), plan.last_sort_stats()[1], plan.last_sort_resumed())
+        plan.set_sorter(0)
+        back = glc.decompress_batch(plan, outp, n, npd)
+        torch.cuda.synchronize()
+        out_res["partly_deep"] = {"GBps": round(n * npd / res[0][0] / 1e9, 2), "ms_per_block": round(res[0][0] * 1e3 / npd, 3),
+                                  "blocks": npd, "blocks_left_by_sample_sorter": res[0][1], "blocks_resumed": res[0][2],
+                                  "GBps_general_sorter_from_scratch": round(n * npd / res[5][0] / 1e9, 2),
+                                  "round_trip_ok": bool(torch.equal(back, d_pd)),
+                                  "what": "text / log blocks with a duplicated 20 KB region, a 2000-byte phrase every 16 KiB, or runs of 1500 / 9000 "
+                                          "equal bytes inside: given up by the sample sorter for depth, finished by prefix doubling resumed from "
+                                          "its tolerant form"}
+    del d_pd, outp, back
     out_res["single_call_text"] = leg_single_call(torch, glc, dev, one, what="text")
     out_res["note"] = ("cudppCompress path (glcCompressBatch, one plan, %d distinct synthetic 1 MiB blocks per call); best of %d calls "
                        "incl. the host wait" % (rows, iters))
@@ -716,6 +757,8 @@ def compact_line(res, details_path):
         line["text_like"] = {k: pick(tl[k], ["GBps", "ratio", "distinct_blocks", "blocks_left_by_sample_sorter", "round_trip_ok"]) for k in ("text", "log") if k in tl}
         if tl.get("deep_repeats"):
             line["text_like"]["deep_repeats"] = pick(tl["deep_repeats"], ["GBps", "ms_per_block", "blocks", "blocks_left_by_sample_sorter", "round_trip_ok"])
+        if tl.get("partly_deep"):
+            line["text_like"]["partly_deep"] = pick(tl["partly_deep"], ["GBps", "blocks", "blocks_resumed", "GBps_general_sorter_from_scratch", "round_trip_ok"])
     cz = res.get("culzss") or {}
     if cz:
         line["culzss"] = pick(cz, ["encode_GBps", "decode_GBps", "encode_with_pcie_staging_GBps", "compression_ratio", "parity", "roundtrip"])
