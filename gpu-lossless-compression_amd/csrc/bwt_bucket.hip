@@ -1864,13 +1864,12 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
 // (want = 2: the blocks whose only trouble was a repeat deeper than the cap -- listed for the tolerant form)
 __global__ void k_ss_retry_list(uint32_t *__restrict__ flag, const uint32_t *__restrict__ list, uint32_t nflag,
                                 uint32_t *__restrict__ list2, uint32_t *__restrict__ count, uint32_t *__restrict__ fill,
-                                uint32_t want, const uint32_t *__restrict__ dup)
+                                uint32_t want)
 {
     const uint32_t j = blockIdx.x;
     if (j >= nflag) return;
     const uint32_t b = list[j];
     if (flag[b] != want) return;                               // (uniform per workgroup)
-    (void)dup;
     __shared__ uint32_t s_at;
     if (threadIdx.x == 0) s_at = atomicAdd(count, 1u);
     for (uint32_t i = threadIdx.x; i < FS_MAXNB; i += blockDim.x) fill[(size_t)b * FS_MAXNB + i] = 0;
@@ -2016,7 +2015,7 @@ hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32
 {
     GLC_TRY(hipMemsetAsync(s.fs_nflag + 2, 0, 4, st));
     hipLaunchKernelGGL(k_ss_retry_list, dim3(nflag), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, s.ss_list + (size_t)to * s.rows,
-                       s.fs_nflag + 2, s.fs_fill, to, s.fs_dup);
+                       s.fs_nflag + 2, s.fs_fill, to);
     return hipGetLastError();
 }
 
