@@ -4,8 +4,10 @@
 //
 // Restates huffman_build_tree_kernel's merge loop (cudpp-inpar/src/cudpp/kernel/
 // compress_kernel.cuh:2306-2392) with FindMinimumCount's order (cta/compress_cta.cuh:
-// 550-571: lowest count, then lowest level, then lowest slot) with two sorted queues
-// held in the registers of one wave (see huff_tree_build).
+// 550-571: lowest count, then lowest level, then lowest slot) with two sorted queues -- the
+// leaves, ranked once, and the composites in creation order -- whose merged order is consumed
+// in batches of pairs by one wave (see huff_tree_build; GLC_HUFF_SERIAL keeps the one-merge-
+// at-a-time form with the queues in registers, for A/B).
 #pragma once
 #include "glc_device.h"
 
@@ -20,6 +22,11 @@ struct HuffTreeLds {
     int16_t  value[HUFF_NODES];                        // symbol, -1 for a composite node
     int16_t  left[HUFF_NODES], right[HUFF_NODES], parent[HUFF_NODES];
     int      nl, head;
+    // the batched merge loop (huff_tree_build): the composite queue in creation order, the children of every composite,
+    // the two windows' order keys and the elements of a batch in merged order
+    uint32_t qa[264], qb[264], kids[264];              // count << 5 | level, slot << 16 | node; left | right << 16
+    unsigned long long lw[64], cw[64];
+    uint2    pr[128];
 };
 
 // wave-wide minimum of a 64-bit key, broadcast to every lane: inclusive min-scan on DPP (row_shr within
@@ -127,6 +134,112 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
     if (!wave0) return;
 
     const uint32_t nl = (uint32_t)__builtin_amdgcn_readfirstlane(T.nl);
+#ifndef GLC_HUFF_SERIAL
+    // ---- the merges, in BATCHES.  The reference takes the two minima by (count, level, slot) 256 times, one after the
+    // other; as two sorted queues and scalar code that is ~680 cycles per merge for a wave on its own, 73 us per tree --
+    // a third of a single cudppCompress call.  But merges are far from all dependent on each other: with x0 <= x1 <= ...
+    // the live nodes in order (leaves and composites merged), the first new composite is c0 = x0 + x1, every composite
+    // made after it is no smaller, and composites only ever join the END of their queue -- so ALL the pairs (x2i, x2i+1)
+    // with x2i+1 < c0 are merges the serial loop would make, in that order, whatever they produce.  A batch: the heads
+    // of both queues (64 each) ranked in merged order by two binary searches, the elements below the bound paired up,
+    // one lane per pair.  A Zipf block's MTF histogram takes 11 batches for its 256 merges (55, 65, 52, 34, ... pairs).
+    // The queue must stay sorted by (count, level, slot): new composites come out in non-decreasing COUNT; where
+    // counts tie and level or slot do not follow, the live entries are ranked again (rare).
+    const uint32_t nm = nl - 1u;                               // merges
+    uint32_t lh = 0, ch = 0, k = 0;                            // leaves taken, composites taken, composites made (uniform)
+    auto leaf_ord = [](uint32_t key) -> unsigned long long { return ((unsigned long long)(key >> 9) << 14) | (key & 511u); };
+    auto comp_ord = [](uint32_t A, uint32_t B) -> unsigned long long {
+        return ((unsigned long long)(A >> 5) << 14) | ((unsigned long long)(A & 31u) << 9) | (B >> 16);
+    };
+    constexpr unsigned long long INF = ~0ull;
+    while (k < nm) {
+        const uint32_t li = lh + l, ci = ch + l;
+        const bool lval = li < nl, cval = ci < k;
+        const uint32_t lkey = lval ? T.sorted[li] : 0u;
+        const uint32_t qa = cval ? T.qa[ci] : 0u, qb = cval ? T.qb[ci] : 0u;
+        const unsigned long long kl = lval ? leaf_ord(lkey) : INF, kc = cval ? comp_ord(qa, qb) : INF;
+        T.lw[l] = kl; T.cw[l] = kc;
+        __builtin_amdgcn_wave_barrier();
+        // merged rank of this lane's leaf / composite: its own index + the elements of the other window below it (a leaf and
+        // a composite never tie: level 0 against level >= 1)
+        uint32_t lo0 = 0, hi0 = 64, lo1 = 0, hi1 = 64;
+#pragma unroll
+        for (int it = 0; it < 7; it++) {
+            const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+            const unsigned long long c = T.cw[m0 & 63u], f = T.lw[m1 & 63u];
+            if (lo0 < hi0) { if (c < kl) lo0 = m0 + 1; else hi0 = m0; }
+            if (lo1 < hi1) { if (f < kc) lo1 = m1 + 1; else hi1 = m1; }
+        }
+        const uint32_t rl_ = l + lo0, rc_ = l + lo1;
+        // the two smallest of all: among the first two of each window
+        unsigned long long x0, x1;
+        {
+            const unsigned long long a0 = T.lw[0], a1 = T.lw[1], b0 = T.cw[0], b1 = T.cw[1];
+            if (a0 < b0) { x0 = a0; x1 = a1 < b0 ? a1 : b0; } else { x0 = b0; x1 = b1 < a0 ? b1 : a0; }
+        }
+        const uint32_t lv0 = (uint32_t)(x0 >> 9) & 31u, lv1 = (uint32_t)(x1 >> 9) & 31u;
+        const unsigned long long c0 = (((x0 >> 14) + (x1 >> 14)) << 14) | ((unsigned long long)((lv0 > lv1 ? lv0 : lv1) + 1u) << 9) | (x0 & 511u);
+        // nothing outside the windows may be smaller than what is paired
+        unsigned long long bound = c0;
+        if (lh + 64u < nl) { const unsigned long long o = leaf_ord(T.sorted[lh + 64u]); bound = o < bound ? o : bound; }
+        if (ch + 64u < k) { const unsigned long long o = comp_ord(T.qa[ch + 64u], T.qb[ch + 64u]); bound = o < bound ? o : bound; }
+        const uint32_t nlb = (uint32_t)__popcll(__ballot(kl < bound)), ncb = (uint32_t)__popcll(__ballot(kc < bound));
+        const uint32_t mm = (nlb + ncb) >> 1;                  // pairs of this batch (>= 1: x0 and x1 are below the bound)
+        const uint32_t m = mm < nm - k ? mm : nm - k;
+        const bool lin = lval && rl_ < 2u * m, cin = cval && rc_ < 2u * m;
+        if (lin) T.pr[rl_] = make_uint2((lkey >> 9) << 5, (lkey & 511u) * 65537u);     // level 0; slot << 16 | node, node = slot
+        if (cin) T.pr[rc_] = make_uint2(qa, qb);
+        const uint32_t nlv = (uint32_t)__popcll(__ballot(lin)), ncv = (uint32_t)__popcll(__ballot(cin));
+        __builtin_amdgcn_wave_barrier();
+        if (l < m) {
+            const uint2 e0 = T.pr[2 * l], e1 = T.pr[2 * l + 1];
+            const uint32_t v0 = e0.x & 31u, v1 = e1.x & 31u;
+            T.qa[k + l] = (((e0.x >> 5) + (e1.x >> 5)) << 5) | ((v0 > v1 ? v0 : v1) + 1u);
+            T.qb[k + l] = (e0.y & 0xFFFF0000u) | (nl + k + l);
+            T.kids[k + l] = (e0.y & 0xFFFFu) | (e1.y << 16);   // first minimum = left child, second = right
+        }
+        __builtin_amdgcn_wave_barrier();
+        lh += nlv; ch += ncv;
+        // sorted by (count, level, slot)?  Look at every new entry and the live entry before it.
+        bool viol = false;
+        if (l < m && k + l > ch) viol = comp_ord(T.qa[k + l - 1], T.qb[k + l - 1]) > comp_ord(T.qa[k + l], T.qb[k + l]);
+        if (__ballot(viol) != 0) {
+            // rank the live entries [ch, k + m) again (at most 128 of them; keys are distinct: the slots of live composites
+            // are leaves of disjoint subtrees)
+            const uint32_t lo = ch, cnt = k + m - ch;
+            uint2 ent[2];
+            uint32_t rk[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint32_t e = l + 64 * r;
+                rk[r] = 0; ent[r] = make_uint2(0u, 0u);
+                if (e < cnt) {
+                    ent[r] = make_uint2(T.qa[lo + e], T.qb[lo + e]);
+                    const unsigned long long me = comp_ord(ent[r].x, ent[r].y);
+                    for (uint32_t f = 0; f < cnt; f++) rk[r] += comp_ord(T.qa[lo + f], T.qb[lo + f]) < me ? 1u : 0u;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (l + 64 * r < cnt) { T.qa[lo + rk[r]] = ent[r].x; T.qb[lo + rk[r]] = ent[r].y; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        k += m;
+    }
+    // the tree, written by all lanes: composite k = node nl + k with its children
+    const uint32_t root = nm ? nl + nm - 1u : 0u;              // 2 nl - 2; node 0 when the EOF leaf is alone
+    if (l == 0) T.parent[root] = -1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t kk = r * 64 + l;
+        if (kk < nm) {
+            const uint32_t id = nl + kk, kd = T.kids[kk], lf = kd & 0xFFFFu, rt = kd >> 16;
+            T.left[id] = (int16_t)lf; T.right[id] = (int16_t)rt; T.value[id] = -1;
+            T.parent[lf] = (int16_t)id; T.parent[rt] = (int16_t)id;
+        }
+    }
+#else
     // leaf queue: the 64 leaves around the head in one register, refilled from T.sorted every 64 leaves.
     // composite queue: a ring of 128 entries in two registers (entry q = lane q & 63 of register (q >> 6) & 1): live
     // composites are disjoint subtrees of >= 2 leaves, so at most 128 are live, and at most 127 when one is added (a
@@ -220,6 +333,7 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
             T.parent[lf] = (int16_t)id; T.parent[rt] = (int16_t)id;
         }
     }
+#endif
     if (l == 0) T.head = (int)root;
 }
 

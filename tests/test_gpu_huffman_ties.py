@@ -100,3 +100,44 @@ def test_tied_trees_give_the_oracle_stream(glc, cuda, name, hist):
     nsub = (n + 4095) // 4096
     assert np.array_equal(out["offsets"].cpu().numpy().view(np.uint32)[:nsub], want["offsets"])
     assert np.array_equal(out["words"][:size].cpu().numpy().view(np.uint32), want["words"])
+
+
+@pytest.mark.gpu
+def test_random_small_count_histograms_in_one_batch(glc, cuda):
+    """96 more histograms (random menus of small counts, geometric and near-equal ones), one call: the batched merge loop of
+    huff_tree.h -- pairs of the merged queue order formed 30-60 at a time -- against the oracle's tree, block by block"""
+    import torch
+    rng = np.random.default_rng(20260929)
+    rows, syms = 96, []
+    for r in range(rows):
+        kind = r % 4
+        if kind == 0:
+            menu = rng.integers(0, 9, size=int(rng.integers(2, 7)))
+            h = rng.choice(menu, size=256)
+        elif kind == 1:
+            h = np.minimum(rng.geometric(0.08, size=256), 200)
+        elif kind == 2:
+            h = rng.integers(5, 8, size=256)
+        else:
+            h = (2 ** rng.integers(0, 6, size=256)) * (rng.random(256) < 0.7)
+        h = h.astype(np.int64)
+        if h.sum() == 0:
+            h[r] = 3
+        while h.sum() > NMAX:
+            h = h // 2
+        s = rng.permutation(np.repeat(np.arange(256, dtype=np.uint8), h))
+        syms.append(s)
+    n = max(s.size for s in syms)
+    # one length per call: shorter blocks are padded with their own most frequent symbol (the histogram changes, the menu does not)
+    pad = [np.concatenate([s, np.full(n - s.size, np.bincount(s, minlength=256).argmax(), dtype=np.uint8)]) for s in syms]
+    x = np.concatenate(pad)
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, NMAX, rows=rows) as plan:
+        out = glc.huffman_encode_batch(plan, torch.from_numpy(x).to(cuda), n, rows)
+        plan.synchronize()
+    sizes = out["size"].cpu().numpy()
+    words = out["words"].cpu().numpy().view(np.uint32)
+    for r in range(rows):
+        want = O.huff_encode(pad[r])
+        assert want["rc"] == 0
+        assert int(sizes[r]) == want["size"], r
+        assert np.array_equal(words[r * out["stride"]:r * out["stride"] + want["size"]], want["words"]), r
