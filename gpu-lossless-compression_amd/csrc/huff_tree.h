@@ -184,7 +184,8 @@ __device__ __forceinline__ void huff_tree_build(HuffTreeLds &T, const uint32_t *
         if (lh + 64u < nl) { const unsigned long long o = leaf_ord(T.sorted[lh + 64u]); bound = o < bound ? o : bound; }
         if (ch + 64u < k) { const unsigned long long o = comp_ord(T.qa[ch + 64u], T.qb[ch + 64u]); bound = o < bound ? o : bound; }
         const uint32_t nlb = (uint32_t)__popcll(__ballot(kl < bound)), ncb = (uint32_t)__popcll(__ballot(kc < bound));
-        const uint32_t mm = (nlb + ncb) >> 1;                  // pairs of this batch (>= 1: x0 and x1 are below the bound)
+        uint32_t mm = (nlb + ncb) >> 1;                        // pairs of this batch (>= 1: x0 and x1 are below the bound)
+        mm = mm ? mm : 1u;                                     // (the two smallest are always a merge: the loop cannot stall)
         const uint32_t m = mm < nm - k ? mm : nm - k;
         const bool lin = lval && rl_ < 2u * m, cin = cval && rc_ < 2u * m;
         if (lin) T.pr[rl_] = make_uint2((lkey >> 9) << 5, (lkey & 511u) * 65537u);     // level 0; slot << 16 | node, node = slot
