@@ -226,9 +226,12 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
 // splitter suffixes (code first, text on equal codes) instead of in the top bits of the code.
 // sp8[k] / w8: the first 8 text bytes of splitter k / of the word's suffix (big-endian, 0 past the end of the text): on
 // equal codes they decide most comparisons without going to the text (text-like blocks are exactly those with thousands
-// of suffixes under one code)
-__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t *sp8, const uint16_t *cell, uint64_t w,
-                                              uint64_t w8, const uint8_t *T, uint32_t n, bool *deep, bool tol)
+// of suffixes under one code).  sp16[k] / wtxt[8 .. 16): the NEXT 8 bytes, the word's still in the staged tile -- log lines
+// share more than 8 bytes with the splitters around them all the time ("2026-09-28T12:3", " host-17 svc-"), and every such
+// tie was a walk through the text by one lane with its wave waiting: 2.1 of the kernel's 3.3 ms per 256 log blocks.
+__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t *sp8, const uint64_t *sp16, const uint16_t *cell,
+                                              uint64_t w, uint64_t w8, const uint8_t *wtxt, const uint8_t *T, uint32_t n,
+                                              bool *deep, bool tol)
 {
     const uint64_t cw = w >> 28;
     const uint32_t iw = (uint32_t)(w >> 8) & 0xFFFFFu;
@@ -245,7 +248,15 @@ __device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t
             const uint32_t is = (uint32_t)(sw >> 8) & 0xFFFFFu;
             const uint64_t s8 = sp8[mid];
             if (s8 != w8) le = s8 < w8;
-            else le = is == iw || !fs_suffix_less(T, n, iw, is, deep, 8, tol);
+            else if (is == iw) le = true;
+            else {
+                uint64_t w16 = 0;
+#pragma unroll
+                for (int t = 8; t < 16; t++) w16 = (w16 << 8) | wtxt[t];
+                const uint64_t s16 = sp16[mid];
+                if (s16 != w16) le = s16 < w16;
+                else le = !fs_suffix_less(T, n, iw, is, deep, 16, tol);
+            }
         }
         if (le) lo = mid; else hi = mid;
     }
@@ -259,7 +270,8 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
                                                     const uint32_t *__restrict__ list, const uint64_t *__restrict__ split,
                                                     const uint16_t *__restrict__ cell, const uint64_t *__restrict__ split8,
-                                                    uint32_t *__restrict__ zero_bucket, bool tol)
+                                                    uint32_t *__restrict__ zero_bucket, bool tol,
+                                                    const uint64_t *__restrict__ split16 = nullptr)
 {
     __shared__ uint32_t s_cnt[FS_MAXNB], s_start[FS_MAXNB], s_gbase[FS_MAXNB];
     __shared__ uint64_t s_w[FSP_TILE];
@@ -290,16 +302,19 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     uint64_t *s_split = s_w + 1024;                            // (SPLIT) behind the table and the staged text, dead with them
     uint16_t *s_cell = reinterpret_cast<uint16_t *>(s_w + 1024 + FS_MAXNB);
     uint64_t *s_split8 = s_w + 1024 + FS_MAXNB + (SS_CELLS + 2 + 3) / 4 + 1;    // behind the cell table (8196 bytes)
+    uint64_t *s_split16 = s_split8 + FS_MAXNB;                 // (3586 of s_w's 4096 words in all)
     if (SPLIT) {
         for (uint32_t i = tid; i < (1u << nbl); i += FSP_NT) {
             s_split[i] = split[(size_t)b * FS_MAXNB + i];
             s_split8[i] = split8[(size_t)b * FS_MAXNB + i];
+            s_split16[i] = split16[(size_t)b * FS_MAXNB + i];
         }
         for (uint32_t i = tid; i < SS_CELLS + 2; i += FSP_NT) s_cell[i] = cell[(size_t)b * (SS_CELLS + 2) + i];
     }
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
     if (tid < FS_MAXNB) s_cnt[tid] = 0;
-    const bool edge = base + FSP_TILE + 16 > n;
+    constexpr uint32_t STG = FSP_TILE + (SPLIT ? 24 : 16);     // staged bytes: T[base - 1 ..]; SPLIT looks 16 bytes into a suffix
+    const bool edge = base + STG > n;
     if (base > 0 && !edge && (reinterpret_cast<uintptr_t>(T) & 3) == 0) {
         // aligned dwords of T[base - 4 ...], shifted by 3 bytes on the way into LDS
         const uint32_t *D = reinterpret_cast<const uint32_t *>(T + base - 4);
@@ -307,17 +322,17 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const uint32_t q = r * FSP_NT + tid;
-            const bool in = q < (FSP_TILE + 16) / 4;
+            const bool in = q < STG / 4;
             lo[r] = in ? D[q] : 0u; hi[r] = in ? D[q + 1] : 0u;
         }
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const uint32_t q = r * FSP_NT + tid;
-            if (q < (FSP_TILE + 16) / 4)
+            if (q < STG / 4)
                 reinterpret_cast<uint32_t *>(s_txt)[q] = __builtin_amdgcn_alignbyte(hi[r], lo[r], 3);
         }
     } else {
-        for (uint32_t k = tid; k < FSP_TILE + 16; k += FSP_NT) {
+        for (uint32_t k = tid; k < STG; k += FSP_NT) {
             const int64_t g = (int64_t)base - 1 + k;
             s_txt[k] = g < 0 ? T[n - 1] : (g < (int64_t)n ? T[g] : (uint8_t)0);
         }
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
             const uint32_t d0 = (o0 & 3) ? __builtin_amdgcn_alignbyte(by4[(o0 >> 2) + 1], by4[o0 >> 2], o0 & 3) : by4[o0 >> 2];
             const uint32_t d1 = (o1 & 3) ? __builtin_amdgcn_alignbyte(by4[min((o1 >> 2) + 1, 3u)], by4[o1 >> 2], o1 & 3) : by4[o1 >> 2];
             const uint64_t w8 = ((uint64_t)__builtin_bswap32(d0) << 32) | __builtin_bswap32(d1);
-            bk = gi < n ? ss_bucket(s_split, s_split8, s_cell, w[j], w8, T, n, &deep, tol) : 0u;
+            bk = gi < n ? ss_bucket(s_split, s_split8, s_split16, s_cell, w[j], w8, s_txt + k0 + j + 1, T, n, &deep, tol) : 0u;
             if (deep && !tol) atomicOr(&flag[b], 2u);
         } else bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
         br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
@@ -1088,7 +1103,8 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                                                       uint32_t nbl, const uint2 *__restrict__ tab,
                                                       const uint32_t *__restrict__ list, uint64_t *__restrict__ split,
                                                       uint16_t *__restrict__ cell, uint32_t *__restrict__ flag,
-                                                      uint32_t *__restrict__ l0_out, uint64_t *__restrict__ split8, uint32_t seed)
+                                                      uint32_t *__restrict__ l0_out, uint64_t *__restrict__ split8, uint32_t seed,
+                                                      uint64_t *__restrict__ split16)
 {
     constexpr bool tol = TOL;
     __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
@@ -1174,6 +1190,10 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         if (is + 8 <= n) f8 = fs_load_be64(T + is);
         else for (uint32_t t = 0; t < 8; t++) f8 = (f8 << 8) | (is + t < n ? (uint64_t)T[is + t] : 0ull);
         split8[(size_t)b * FS_MAXNB + k] = f8;
+        uint64_t f16 = 0;                                      // ... and the 8 bytes behind them
+        if (is + 16 <= n) f16 = fs_load_be64(T + is + 8);
+        else for (uint32_t t = 8; t < 16; t++) f16 = (f16 << 8) | (is + t < n ? (uint64_t)T[is + t] : 0ull);
+        split16[(size_t)b * FS_MAXNB + k] = f16;
     }
     // every suffix of a bucket lies between its two splitters and shares their common prefix: l0 of bucket k, here
     // for all buckets at once (in k_ss_cut it was three dependent memory round trips of ONE thread, with the other
@@ -1981,13 +2001,15 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     }
     if (tol)
         hipLaunchKernelGGL(k_ss_sample<true>, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, list,
-                           s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt);
+                           s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt,
+                           s.ss_split + 2 * (size_t)s.rows * FS_MAXNB);
     else
         hipLaunchKernelGGL(k_ss_sample<false>, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, list,
-                           s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt);
+                           s.ss_split, s.ss_cell, s.ss_flag, s.ss_l0, s.ss_split + (size_t)s.rows * FS_MAXNB, attempt,
+                           s.ss_split + 2 * (size_t)s.rows * FS_MAXNB);
     hipLaunchKernelGGL(k_fs_part<true>, dim3((n + FSP_TILE - 1) / FSP_TILE, nflag), dim3(FSP_NT), 0, st, text, text_stride,
                        n, nbl, s.fs_tab, s.keyA, s.fs_kstride, s.fs_fill, s.ss_flag, list, s.ss_split, s.ss_cell,
-                       s.ss_split + (size_t)s.rows * FS_MAXNB, (uint32_t *)nullptr, tol);
+                       s.ss_split + (size_t)s.rows * FS_MAXNB, (uint32_t *)nullptr, tol, s.ss_split + 2 * (size_t)s.rows * FS_MAXNB);
     hipLaunchKernelGGL(k_fs_scan, dim3(nflag), dim3(FS_MAXNB), 0, st, s.fs_fill, s.fs_base, s.ss_flag, list);
     GLC_TRY(hipMemsetAsync(s.ss_long_count, 0, 8, st));
     const size_t long_cap = (size_t)s.rows * FS_MAXNB * SSL_PER_BUCKET;

@@ -932,7 +932,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.fs_zero, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_nflag, 16));
     GLC_TRY(A((void **)&s.ss_list, (size_t)rows * 4 * 3));
-    GLC_TRY(A((void **)&s.ss_split, (size_t)rows * FS_MAXNB * 8 * 2));    // words, then the first 8 text bytes of every splitter
+    GLC_TRY(A((void **)&s.ss_split, (size_t)rows * FS_MAXNB * 8 * 3));    // words, then the first 8 text bytes of every splitter, then the next 8
     GLC_TRY(A((void **)&s.ss_flag, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.ss_cell, (size_t)rows * 4098 * 2));
     GLC_TRY(A((void **)&s.ss_l0, (size_t)rows * FS_MAXNB * 4));
