@@ -199,12 +199,19 @@ __device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
 // tol (the sample sorter's second form, for blocks with repeats deeper than its cap: see ss_build): two suffixes that
 // agree in their first SS_TOL_CAP + 8 bytes are ordered by their POSITIONS -- a total order that every comparison of the
 // pass agrees on, and a (SS_TOL_CAP)-order of the suffixes, which is all the prefix-doubling rounds behind it need.
+template <bool W16 = false>
 __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uint32_t a, uint32_t b, bool *deep, uint32_t k = 0,
                                                bool tol = false)
 {
     for (;;) {
         const uint32_t m = max(a, b) + k;
-        if (m + 12 <= n) {
+        if (W16 && !tol && m + 20 <= n) {                      // (the tolerant form's ties must end where k_ss_sample's do: steps of 8)
+            const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
+            const uint64_t va2 = fs_load_be64(T + a + k + 8), vb2 = fs_load_be64(T + b + k + 8);
+            if (va != vb) return va < vb;
+            if (va2 != vb2) return va2 < vb2;
+            k += 16;
+        } else if (m + 12 <= n) {
             const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
             if (va != vb) return va < vb;
             k += 8;
@@ -255,7 +262,7 @@ __device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t
                 for (int t = 8; t < 16; t++) w16 = (w16 << 8) | wtxt[t];
                 const uint64_t s16 = sp16[mid];
                 if (s16 != w16) le = s16 < w16;
-                else le = !fs_suffix_less(T, n, iw, is, deep, 16, tol);
+                else le = !fs_suffix_less<true>(T, n, iw, is, deep, 16, tol);
             }
         }
         if (le) lo = mid; else hi = mid;
