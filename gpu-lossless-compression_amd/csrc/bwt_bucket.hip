@@ -1102,7 +1102,7 @@ __device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8
     if (ca != cb) return ca < cb;
     const uint32_t ia = (uint32_t)(a >> 8) & 0xFFFFFu, ib = (uint32_t)(b >> 8) & 0xFFFFFu;
     if (ia == ib) return false;
-    return fs_suffix_less(T, n, ia, ib, deep, 0, tol);
+    return fs_suffix_less<true>(T, n, ia, ib, deep, 0, tol);
 }
 
 template <bool TOL>
