@@ -437,6 +437,10 @@ constexpr int FSP2_T = GLC_FSP2_T;
 #ifndef GLC_FSP2_WAVES
 #define GLC_FSP2_WAVES 5
 #endif
+#ifndef GLC_FSP2_NT
+#define GLC_FSP2_NT 512
+#endif
+constexpr int FSP2_NT = GLC_FSP2_NT;                           // threads per workgroup; a thread takes 4096 / FSP2_NT consecutive suffixes
 
 __device__ __forceinline__ void lds_only_barrier()
 {
@@ -445,7 +449,8 @@ __device__ __forceinline__ void lds_only_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(GLC_FSP2_WAVES, 8))) void k_fs_part2(const uint8_t *__restrict__ text, size_t stride, uint32_t n, uint32_t nbl,
+template <int NT, int ITEMS, int WPE>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_fs_part2(const uint8_t *__restrict__ text, size_t stride, uint32_t n, uint32_t nbl,
                                                      const uint2 *__restrict__ tab, uint64_t *__restrict__ keys, size_t kstride,
                                                      uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
                                                      uint32_t *__restrict__ zero_bucket)
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(GLC_FSP2
     __shared__ uint16_t s_start[FS_MAXNB], s_gbase[FS_MAXNB];
     __shared__ uint64_t s_w[FSP_TILE];
     __shared__ uint2 s_tab[256];
-    __shared__ uint32_t s_tmp[FSP_NT / 64 + 1];
+    __shared__ uint32_t s_tmp[NT / 64 + 1];
     __shared__ uint32_t s_flagged;
     uint8_t *s_txt = reinterpret_cast<uint8_t *>(s_w);         // s_txt[k] = T[base - 1 + k]: dead before the first word is bucketed
     uint32_t bx, by;
@@ -467,13 +472,15 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(GLC_FSP2
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
     // text of a tile as the dwords of T[base - 1 ...] (unaligned 4-byte loads: global memory takes any alignment): dword
     // q = r NT + tid of the 4112 staged bytes.  Only for inner tiles; the first and the last tile of a block take the byte loop.
-    uint32_t stg[3] = {0, 0, 0};
+    static_assert(NT * ITEMS == FSP_TILE, "a tile is 4096 suffixes");
+    constexpr int NSTG = ((FSP_TILE + 16) / 4 + NT - 1) / NT;      // staged dwords per thread
+    uint32_t stg[NSTG] = {};
     auto inner = [&](uint32_t tile) { const uint32_t base = tile * FSP_TILE; return base > 0 && base + FSP_TILE + 16 <= n; };
     auto request = [&](uint32_t tile) {
         const uint8_t *D = T + (size_t)tile * FSP_TILE - 1;
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const uint32_t q = r * FSP_NT + tid;
+        for (int r = 0; r < NSTG; r++) {
+            const uint32_t q = r * NT + tid;
             const uint32_t qq = q < (FSP_TILE + 16) / 4 ? q : 0u;   // (every load is issued: a conditional one may sink to its use)
             uint32_t v;
             __builtin_memcpy(&v, D + 4 * (size_t)qq, 4);
@@ -491,12 +498,12 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(GLC_FSP2
         if (tid < FS_MAXNB) s_cnt[tid] = 0;
         if (have) {
 #pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const uint32_t q = r * FSP_NT + tid;
+            for (int r = 0; r < NSTG; r++) {
+                const uint32_t q = r * NT + tid;
                 if (q < (FSP_TILE + 16) / 4) reinterpret_cast<uint32_t *>(s_txt)[q] = stg[r];
             }
         } else {
-            for (uint32_t k = tid; k < FSP_TILE + 16; k += FSP_NT) {
+            for (uint32_t k = tid; k < FSP_TILE + 16; k += NT) {
                 const int64_t g = (int64_t)base - 1 + k;
                 s_txt[k] = g < 0 ? T[n - 1] : (g < (int64_t)n ? T[g] : (uint8_t)0);
             }
@@ -506,20 +513,31 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(GLC_FSP2
         if (next_inner) request(tile + 1);                     // in flight until this tile's words are in LDS
         if (s_flagged) return;
         // thread = 8 consecutive suffixes gi0 .. gi0+7; byte j of its 16 staged bytes is T[gi0 - 1 + j]
-        const uint32_t k0 = tid * FSP_ITEMS, gi0 = base + k0;
-        const uint2 qa = *reinterpret_cast<const uint2 *>(s_txt + k0), qb = *reinterpret_cast<const uint2 *>(s_txt + k0 + 8);
-        const uint32_t by4[4] = {qa.x, qa.y, qb.x, qb.y};
-#define FS_BYTE(j) ((by4[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
-        uint2 e[FSP_ITEMS + 5];                                // table entries of the 13 symbols the 8 codes share
+        const uint32_t k0 = tid * ITEMS, gi0 = base + k0;
+        constexpr int NBY = (ITEMS + 6 + 3) / 4;              // dwords that hold the thread's ITEMS + 6 staged bytes (k0 is a multiple of ITEMS)
+        uint32_t by4[NBY];
+        if (ITEMS % 8 == 0) {
 #pragma unroll
-        for (int k = 0; k < FSP_ITEMS + 5; k++) {
+            for (int q = 0; q < NBY; q += 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(s_txt + k0 + 4 * q);
+                by4[q] = v.x;
+                if (q + 1 < NBY) by4[q + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NBY; q++) by4[q] = *reinterpret_cast<const uint32_t *>(s_txt + k0 + 4 * q);
+        }
+#define FS_BYTE(j) ((by4[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
+        uint2 e[ITEMS + 5];                                // table entries of the 13 symbols the 8 codes share
+#pragma unroll
+        for (int k = 0; k < ITEMS + 5; k++) {
             const uint2 t = s_tab[FS_BYTE(1 + k)];
             e[k] = (edge && gi0 + k >= n) ? make_uint2(0u, 0u) : t;
         }
-        uint64_t w[FSP_ITEMS];
-        uint32_t br[FSP_ITEMS];                                // bucket << 16 | rank inside (tile, bucket)
+        uint64_t w[ITEMS];
+        uint32_t br[ITEMS];                                // bucket << 16 | rank inside (tile, bucket)
 #pragma unroll
-        for (int j = 0; j < FSP_ITEMS; j++) {
+        for (int j = 0; j < ITEMS; j++) {
             uint32_t y = e[j + 5].x;
 #pragma unroll
             for (int d = 4; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
@@ -535,26 +553,26 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(GLC_FSP2
         uint32_t g = 0, c = 0;
         {
             c = tid < FS_MAXNB ? s_cnt[tid] : 0u;
-            const uint32_t start = block_excl_add_lds<FSP_NT>(c, s_tmp);
+            const uint32_t start = block_excl_add_lds<NT>(c, s_tmp);
             if (c) g = atomicAdd(&fill[(size_t)b * FS_MAXNB + tid], c);     // issued here, looked at behind the scatter
             if (tid < FS_MAXNB) s_start[tid] = (uint16_t)start;
         }
         lds_only_barrier();                                    // (the staged text and the table reads are done: s_w takes the words)
 #pragma unroll
-        for (int j = 0; j < FSP_ITEMS; j++)
+        for (int j = 0; j < ITEMS; j++)
             if (gi0 + j < n) s_w[s_start[br[j] >> 16] + (br[j] & 0xFFFFu)] = w[j];
         if (c && g + c > FS_FILLMAX) { atomicOr(&flag[b], 1u); s_flagged = 1; }
         if (tid < FS_MAXNB) s_gbase[tid] = (uint16_t)(g < FS_CAP ? g : FS_CAP);
         if (next_inner) {                                      // the next tile's text has arrived before this tile's stores are issued
 #pragma unroll                                                 // (loads and stores share one in-order counter)
-            for (int r = 0; r < 3; r++) asm volatile("" : "+v"(stg[r]));
+            for (int r = 0; r < NSTG; r++) asm volatile("" : "+v"(stg[r]));
         }
         have = next_inner;
         lds_only_barrier();
         const uint32_t tile_n = min((uint32_t)FSP_TILE, n - base);
 #pragma unroll
-        for (int r = 0; r < FSP_ITEMS; r++) {
-            const uint32_t p = r * FSP_NT + tid;
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t p = r * NT + tid;
             if (p < tile_n) {
                 const uint64_t ww = s_w[p];
                 const uint32_t d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
@@ -577,6 +595,31 @@ __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict
     fbase[(size_t)b * FS_MAXNB + tid] = block_excl_add<FS_MAXNB>(f, s_tmp);
 }
 
+// Work-list space for a bucket's runs of equal codes (`tot` entries, > 0; called by every thread behind the barrier that
+// completed s_wl).  A bucket has wl_fixed entries of its own at bk * wl_fixed: nothing to ask anybody for, the count goes
+// to wl_bcnt with a plain store.  (One atomicAdd with return on a per-block counter was ~1.5 us of a workgroup's 7.6 us:
+// every bucket of an i.i.d. block has a handful of tied words, so every workgroup sat it out, and issuing it early
+// bought nothing -- the workgroup cannot end before it knows where its entries go.)  Only a bucket with more tied words
+// than that takes entries from the shared second half of the list, with the atomic; a full list flags the block.
+__device__ __forceinline__ uint32_t fs_wl_reserve(uint32_t tot, uint32_t *s_bcast, uint32_t b, uint32_t bk, uint32_t nbl,
+                                                  uint32_t tid, uint32_t wl_cap, uint32_t wl_fixed,
+                                                  uint32_t *__restrict__ wl_count, uint32_t *__restrict__ wl_bcnt,
+                                                  uint32_t *__restrict__ flag)
+{
+    if (tot <= wl_fixed) {                                     // (uniform)
+        if (tid == 0) wl_bcnt[(size_t)b * FS_MAXNB + bk] = tot;
+        return bk * wl_fixed;
+    }
+    const uint32_t shared0 = wl_fixed << nbl;                  // first entry of the shared part
+    if (tid == 0) {
+        uint32_t base = shared0 + atomicAdd(&wl_count[b], tot);
+        if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
+        *s_bcast = base;
+    }
+    __syncthreads();
+    return *s_bcast;
+}
+
 // ---------------------------------------------------------------------------
 // one workgroup sorts one bucket in LDS and writes its rows of the result.  Runs of equal codes (a few
 // per bucket on Zipf data) are not resolved here -- that needs the text, and a global-memory round trip on
@@ -592,7 +635,8 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
                                                     uint8_t *__restrict__ bwt_out, size_t bwt_stride,
                                                     int *__restrict__ d_index, uint32_t *__restrict__ sa_out,
                                                     size_t sa_stride, uint4 *__restrict__ wl, uint32_t wl_cap,
-                                                    uint32_t *__restrict__ wl_count)
+                                                    uint32_t *__restrict__ wl_count, uint32_t *__restrict__ wl_bcnt,
+                                                    uint32_t wl_fixed)
 {
     __shared__ uint64_t s_w[FS_FILLMAX + 4];                   // + 4 sentinels behind the last word
     __shared__ uint32_t s_cp[FS_BINS / 2 + 1];                 // bin counters, then bin starts (two 16-bit values per word), then BWT bytes
@@ -714,8 +758,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
     // rows R0 .. R0 + c of the block's BWT are staged so that aligned dwords of LDS are aligned dwords of the output
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
     const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
-    // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup
-    //    (an atomic per group on a shared counter serialised the whole kernel: +2.4 ms per 256 blocks).
+    // 3. tied groups -> the block's work list, into the bucket's own entries (fs_wl_reserve)
     bool any = false;
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
@@ -727,14 +770,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
         }
     }
     if (__syncthreads_or((int)any)) {
-        if (tid == 0) {
-            const uint32_t tot = s_wl;
-            uint32_t base = atomicAdd(&wl_count[b], tot);
-            if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
-            s_deep = base;
-        }
-        __syncthreads();
-        const uint32_t base = s_deep;
+        const uint32_t base = fs_wl_reserve(s_wl, &s_deep, b, bk, nbl, tid, wl_cap, wl_fixed, wl_count, wl_bcnt, flag);
         uint4 *WL = wl + (size_t)b * wl_cap;
         if (base != 0xFFFFFFFFu) {
 #pragma unroll
@@ -781,7 +817,8 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
                                                         uint32_t *__restrict__ flag, uint8_t *__restrict__ bwt_out,
                                                         size_t bwt_stride, int *__restrict__ d_index, uint4 *__restrict__ wl,
                                                         uint32_t wl_cap, uint32_t *__restrict__ wl_count,
-                                                        const uint32_t *__restrict__ zero_bucket)
+                                                        const uint32_t *__restrict__ zero_bucket,
+                                                        uint32_t *__restrict__ wl_bcnt, uint32_t wl_fixed)
 {
     __shared__ uint64_t s_w[FS_FILLMAX + 4];                   // + 4 sentinels behind the last word
     __shared__ uint32_t s_cp[FS_BINS / 2 + 1];                 // bin counters, then bin starts (two 16-bit values per word), then BWT bytes
@@ -922,7 +959,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
     // rows R0 .. R0 + c of the block's BWT are staged so that aligned dwords of LDS are aligned dwords of the output
     uint8_t *O = bwt_out + (size_t)b * bwt_stride + R0;
     const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
-    // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup
+    // 3. tied groups -> the block's work list, into the bucket's own entries (fs_wl_reserve: no atomic, nothing to wait for)
     bool any = false;
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
@@ -934,14 +971,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
         }
     }
     if (__syncthreads_or((int)any)) {
-        if (tid == 0) {
-            const uint32_t tot = s_wl;
-            uint32_t base = atomicAdd(&wl_count[b], tot);
-            if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
-            s_deep = base;
-        }
-        __syncthreads();
-        const uint32_t base = s_deep;
+        const uint32_t base = fs_wl_reserve(s_wl, &s_deep, b, bk, nbl, tid, wl_cap, wl_fixed, wl_count, wl_bcnt, flag);
         uint4 *WL = wl + (size_t)b * wl_cap;
         if (base != 0xFFFFFFFFu) {
 #pragma unroll
@@ -975,18 +1005,18 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                  const uint4 *__restrict__ wl, uint32_t wl_cap,
-                                                 const uint32_t *__restrict__ wl_count, uint32_t *__restrict__ flag,
+                                                 const uint32_t *__restrict__ wl_count, const uint32_t *__restrict__ wl_bcnt,
+                                                 uint32_t wl_fixed, uint32_t nb, uint32_t *__restrict__ flag,
                                                  uint8_t *__restrict__ bwt_out, size_t bwt_stride,
                                                  int *__restrict__ d_index, uint32_t *__restrict__ sa_out, size_t sa_stride)
 {
     uint32_t gx, gy;
     xcd_order(gx, gy);                                         // a block's text in one L2 for the comparisons
     const uint32_t b = gy;
-    const uint32_t total = wl_count[b];
-    if (total == 0 || total > wl_cap || flag[b]) return;       // (flags of this pass are all set before it starts)
+    if (flag[b]) return;                                       // (flags of this pass are all set before it starts)
     const uint4 *WL = wl + (size_t)b * wl_cap;
     const uint8_t *T = text + (size_t)b * stride;
-    for (uint32_t e = gx * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    auto member = [&](uint32_t e) {
         const uint4 me = WL[e];
         const uint32_t gs = me.w, idx = me.x >> 8;
         uint32_t rank = 0;
@@ -1010,26 +1040,38 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
                 else rank += fs_suffix_less(T, n, oi[k], idx, &deep) ? 1u : 0u;
             }
         }
-        if (deep) { atomicOr(&flag[b], 2u); continue; }
+        if (deep) { atomicOr(&flag[b], 2u); return; }
         const uint32_t row = me.y + rank;
         if (bwt_out) bwt_out[(size_t)b * bwt_stride + row] = (uint8_t)me.x;
         if (sa_out) sa_out[(size_t)b * sa_stride + row] = idx;
         if (idx == 0 && d_index) d_index[b] = (int)row;
+    };
+    // the buckets' own entries: sixteen lanes per bucket (an i.i.d. block has ~8 tied words per bucket)
+    const uint32_t gl = threadIdx.x & 15u;
+    for (uint32_t bk = (gx * 256 + threadIdx.x) >> 4; bk < nb; bk += gridDim.x * 16) {
+        const uint32_t cnt = min(wl_bcnt[(size_t)b * FS_MAXNB + bk], wl_fixed);
+        for (uint32_t k = gl; k < cnt; k += 16) member(bk * wl_fixed + k);
     }
+    // ... and what buckets with more of them took from the shared part
+    const uint32_t shared0 = wl_fixed * nb, total = wl_count[b];
+    if (total > wl_cap - shared0) return;                      // (it overflowed: the block is flagged)
+    for (uint32_t e = gx * 256 + threadIdx.x; e < total; e += gridDim.x * 256) member(shared0 + e);
 }
 
 // everything the pass accumulates into, cleared by ONE launch (six hipMemsetAsync calls were six dispatches of ~2 us with
 // ~8 us between them: 90 us of a 1 MiB call that takes 400)
 __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__restrict__ hist, uint32_t *__restrict__ fill,
                                                   uint32_t *__restrict__ flag, uint32_t flag_value, uint32_t *__restrict__ wlcnt,
-                                                  uint32_t *__restrict__ dup, uint32_t *__restrict__ nflag)
+                                                  uint32_t *__restrict__ dup, uint32_t *__restrict__ nflag,
+                                                  uint32_t *__restrict__ wlbcnt)
 {
-    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + nf + 3u * nblk + 2u;
+    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + 2u * nf + 3u * nblk + 2u;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         if (i < nh) hist[i] = 0;
         else if (i < nh + nf) fill[i - nh] = 0;
+        else if (i < nh + 2u * nf) wlbcnt[i - nh - nf] = 0;
         else {
-            const uint32_t j = i - nh - nf;
+            const uint32_t j = i - nh - 2u * nf;
             if (j < nblk) flag[j] = flag_value;
             else if (j < 2 * nblk) wlcnt[j - nblk] = 0;
             else if (j < 3 * nblk) dup[j - 2 * nblk] = 0;
@@ -1503,6 +1545,7 @@ __global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text
     __shared__ uint32_t cnt[SS_NBIN + 3];
     __shared__ uint64_t s_piv[SS_NPIV + 1];
     __shared__ uint32_t s_any[2];                              // [0]: a member's 8 bytes reach the end of the text; [1]: a key differs from the first
+    __shared__ uint32_t s_flag;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     auto sync = [] { if (NT == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
     const unsigned long long both = *long_count;
@@ -1513,7 +1556,17 @@ __global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text
     for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
         const uint2 ent = LST[e];
         const uint32_t b = ent.x & 0xFFFFFu, bk = ent.x >> 20, A = ent.y & 0xFFFFu, B = ent.y >> 16;
-        if (flag[b] || B - A > CAP) continue;                  // (given up on already; the second cannot happen)
+        // ONE read of the flag per entry, by one thread: other workgroups of this launch raise it (deep runs), and waves that
+        // read it for themselves could disagree -- one leaving for the next entry while the others wait at a barrier
+        uint32_t fl;
+        if (NT == 64) fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[b]);
+        else {
+            sync();
+            if (tid == 0) s_flag = flag[b];
+            sync();
+            fl = s_flag;
+        }
+        if (fl || B - A > CAP) continue;                       // (given up on already; the second cannot happen)
         const uint8_t *T = text + (size_t)b * stride;
         uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;
         const uint32_t l0 = l0_in[(size_t)b * FS_MAXNB + bk];
@@ -1926,11 +1979,12 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
     {
-        const uint32_t words = nblk * (256u + FS_MAXNB + 3u) + 2u, g = (words + 1023) / 1024;
+        const uint32_t words = nblk * (256u + 2u * FS_MAXNB + 3u) + 2u, g = (words + 1023) / 1024;
         // (skip_tier1: every block starts flagged -- no attempt, the sample sorter takes them all)
         hipLaunchKernelGGL(k_fs_clear, dim3(g < 2048 ? g : 2048), dim3(256), 0, st, nblk, s.fs_hist, s.fs_fill, s.fs_flag,
-                           s.skip_tier1 ? 1u : 0u, s.fs_wlcnt, s.fs_dup, s.fs_nflag);
+                           s.skip_tier1 ? 1u : 0u, s.fs_wlcnt, s.fs_dup, s.fs_nflag, s.fs_wlbcnt);
     }
+    const uint32_t wl_fixed = (s.fs_wl_cap / 2) >> nbl;     // work-list entries every bucket has of its own (fs_wl_reserve)
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
@@ -1957,7 +2011,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
         static const bool old_part = getenv("GLC_FS_PART_OLD") != nullptr;      // A/B: one tile per workgroup
         if (!old_part)
-            hipLaunchKernelGGL(k_fs_part2, dim3(((n + FSP_TILE - 1) / FSP_TILE + FSP2_T - 1) / FSP2_T, nbk), dim3(FSP_NT), 0, st,
+            hipLaunchKernelGGL((k_fs_part2<FSP2_NT, FSP_TILE / FSP2_NT, GLC_FSP2_WAVES>), dim3(((n + FSP_TILE - 1) / FSP_TILE + FSP2_T - 1) / FSP2_T, nbk), dim3(FSP2_NT), 0, st,
                                text + (size_t)b0 * text_stride, text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256,
                                s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
                                s.fs_zero + b0);
@@ -1976,16 +2030,16 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                                s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
                                bwt_out ? bwt_out + (size_t)b0 * bwt_stride : nullptr, bwt_stride, d_index ? d_index + b0 : nullptr,
                                sa_out ? sa_out + (size_t)b0 * s.nmax : nullptr, (size_t)s.nmax, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
-                               s.fs_wlcnt + b0);
+                               s.fs_wlcnt + b0, s.fs_wlbcnt + (size_t)b0 * FS_MAXNB, wl_fixed);
         else
             hipLaunchKernelGGL(k_fs_sort_bwt, dim3(nb, nbk), dim3(FSS_NT), 0, st, nbl, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
                                s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
                                bwt_out + (size_t)b0 * bwt_stride, bwt_stride, d_index + b0, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
-                               s.fs_wlcnt + b0, s.fs_zero + b0);
+                               s.fs_wlcnt + b0, s.fs_zero + b0, s.fs_wlbcnt + (size_t)b0 * FS_MAXNB, wl_fixed);
         if (pi >= 0) s.prof->end(pi, u, st);
     }
-    hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
-                       s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+    hipLaunchKernelGGL(k_fs_ties, dim3((nb + 15) / 16, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
+                       s.fs_wlbcnt, wl_fixed, nb, s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
                        s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
     return hipGetLastError();

@@ -98,7 +98,10 @@ struct CompressPlan : PlanBase {                 // CUDPPCompressPlan (cudpp_pla
             // 4 GiB bench: decode 26.6 (default priority) / 27.3 (lowest) / 25.9 GB/s (highest); encode unchanged.
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least);
+            // (GLC_SIDE_PRIO = least | same | greatest: A/B knob for the probes)
+            const char *pr = getenv("GLC_SIDE_PRIO");
+            const int prio = !pr ? least : (pr[0] == 's' ? 0 : (pr[0] == 'g' ? greatest : least));
+            e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio);
         }
         hipEvent_t *evs[] = {&ev_in, &ev_sorted[0], &ev_sorted[1], &ev_released[0], &ev_released[1],
                              &ev_dec_a[0], &ev_dec_a[1], &ev_dec_released[0], &ev_dec_released[1]};

@@ -897,6 +897,9 @@ __global__ __launch_bounds__(256) void k_ibwt_lf(const uint8_t *__restrict__ bwt
 // SLOT-byte slot; a walk that fills its slot before reaching the next splitter row continues in
 // a freshly allocated ("dynamic") segment, so slots are bounded whatever the cycle looks like.
 //   seg_info[id] = len | next << 9 ; ids < nsplit are the static splitters.
+#ifndef GLC_WALK_PAD
+#define GLC_WALK_PAD 100
+#endif
 template <int PAD>
 __global__ __launch_bounds__(256) void k_ibwt_walk(const uint32_t *__restrict__ lf, size_t lf_stride, uint32_t n,
                                                    uint32_t *__restrict__ seg_info, uint32_t max_seg,
@@ -1149,7 +1152,7 @@ hipError_t decode_stage_b(hipStream_t st, const int *d_bwt_index, const uint8_t 
     hipLaunchKernelGGL(k_ibwt_seg_init, dim3((nblk + 255) / 256), dim3(256), 0, st, s.seg_count, n, nblk);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_IBWT_WALK, st) : -1;
-    hipLaunchKernelGGL(k_ibwt_walk<100>, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,
+    hipLaunchKernelGGL(k_ibwt_walk<GLC_WALK_PAD>, dim3((nsplit + 255) / 256, nblk), dim3(256), 0, st, s.lf, lf_stride, n, s.seg,
                        s.max_seg, s.seg_count, s.slots);
     if (pi >= 0) s.prof->end(pi, units, st);
     pi = s.prof ? s.prof->begin(PROF_IBWT_EMIT, st) : -1;

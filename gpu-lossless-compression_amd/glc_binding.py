@@ -426,9 +426,10 @@ def decompress_batch_compact(plan, comp, n, nblk, first=0, d_out=None):
     return d_out
 
 
-def decompress_batch(plan, comp, n, nblk):
+def decompress_batch(plan, comp, n, nblk, d_out=None):
     import torch
-    d_out = torch.empty(nblk * n, dtype=torch.uint8, device=comp["words"].device)
+    if d_out is None:
+        d_out = torch.empty(nblk * n, dtype=torch.uint8, device=comp["words"].device)
     rc = lib().glcDecompressBatch(plan.handle, comp["bwt_index"].data_ptr(), comp["hist"].data_ptr(),
                                   comp["offsets"].data_ptr(), comp["nsub"], comp["words"].data_ptr(),
                                   comp["stride"], d_out.data_ptr(), n, nblk)

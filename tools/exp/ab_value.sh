@@ -1,7 +1,7 @@
-# usage: ab_value.sh tag...   -- bench.py `value` (4 GiB, main leg only) with build_variant/libglc_<tag>.so ("main" = the in-tree library); env passes through
+# usage: ab_value.sh tag...   -- bench.py `value` (4 GiB, main leg only) with variants/libglc_<tag>.so ("main" = the in-tree library); env passes through
 for v in "$@"; do
   unset GLC_LIB
-  if [ $v != main ]; then export GLC_LIB=$PWD/gpu-lossless-compression_amd/build_variant/libglc_$v.so; fi
+  if [ $v != main ]; then export GLC_LIB=$PWD/gpu-lossless-compression_amd/variants/libglc_$v.so; fi
   python bench.py --gib 4 --steps 3 --main-only --no-cpu-baseline --no-verify --details /tmp/ab_$v.json > /tmp/ab_$v.line 2>/tmp/ab_$v.err || tail -3 /tmp/ab_$v.err
   python - <<PY
 import json
