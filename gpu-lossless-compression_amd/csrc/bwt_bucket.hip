@@ -554,7 +554,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         {
             c = tid < FS_MAXNB ? s_cnt[tid] : 0u;
             const uint32_t start = block_excl_add_lds<NT>(c, s_tmp);
+#if defined(GLC_EXP_PART) && (GLC_EXP_PART == 2 || GLC_EXP_PART == 3)   // timing experiment: no global atomic (a made-up base)
+            if (c) g = (tile * 8u) & (FS_CAP / 2 - 1);
+#else
             if (c) g = atomicAdd(&fill[(size_t)b * FS_MAXNB + tid], c);     // issued here, looked at behind the scatter
+#endif
             if (tid < FS_MAXNB) s_start[tid] = (uint16_t)start;
         }
         lds_only_barrier();                                    // (the staged text and the table reads are done: s_w takes the words)
@@ -577,7 +581,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
                 const uint64_t ww = s_w[p];
                 const uint32_t d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
                 const uint32_t off = (uint32_t)s_gbase[d] + (p - (uint32_t)s_start[d]);
+#if defined(GLC_EXP_PART) && (GLC_EXP_PART == 1 || GLC_EXP_PART == 3)   // timing experiment: no stores
+                if (off == 0xFFFFFFFFu) K[(size_t)d * FS_CAP + off] = ww;
+#elif defined(GLC_EXP_PART) && GLC_EXP_PART == 4                   // timing experiment: 6 bytes per word, a dword array and a halfword array per slot
+                if (off < FS_CAP) {
+                    reinterpret_cast<uint32_t *>(K + (size_t)d * FS_CAP)[off] = (uint32_t)(ww >> 24);
+                    reinterpret_cast<uint16_t *>(K + (size_t)d * FS_CAP + FS_CAP / 2)[off] = (uint16_t)ww;
+                }
+#else
                 if (off < FS_CAP) K[(size_t)d * FS_CAP + off] = ww;
+#endif
             }
         }
         lds_only_barrier();                                    // s_w is free for the next tile's text
@@ -857,6 +870,15 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
     if (tid < 4 && cc) s_w[cc + tid] = ~0ull;                  // what the rank step reads past the last bin compares as larger
     __syncthreads();
     if (s_deep || cc == 0) return;                             // flagged: the block is another sorter's
+#if defined(GLC_EXP_SORT) && GLC_EXP_SORT == 3                     // timing experiment: the loads alone
+    {
+        uint64_t x = 0;
+#pragma unroll
+        for (int r = 0; r < FSS_ITEMS; r++) x ^= w[r];
+        if (x == 0x1234567ull) bwt_out[tid] = 1;
+        return;
+    }
+#endif
     // 1. counting sort on the 12 bits below the bucket number (arrival order inside a bin: any order will do)
     const uint32_t bshift = 64 - nbl - FS_BIN_BITS;
     uint32_t rk[FSS_ITEMS];
@@ -902,6 +924,9 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
             if ((uint32_t)r <= full) scatter(r);
     }
     __syncthreads();
+#if defined(GLC_EXP_SORT) && GLC_EXP_SORT == 4                     // timing experiment: up to the bin-sorted array
+    if (s_w[tid] != 0x1234567ull) return;
+#endif
     // 2. final position = bin start + number of smaller codes in the bin (thread = the words at positions i0 / (r - 1) NT +
     //    tid of the bin-sorted array).  The four words from the bin start are compared in straight-line code with no bounds
     //    at all -- what lies behind the bin's end is a larger code or a sentinel; a bin of more than four, or a second word
@@ -984,6 +1009,9 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
         }
     }
     // 4. the rows
+#if defined(GLC_EXP_SORT) && GLC_EXP_SORT == 1                     // timing experiment: no row stores
+    if (s_cp[tid] == 0x12345677u)
+#endif
     {
         const uint32_t end = shift + c;                        // staged bytes [shift, end)
         for (uint32_t q = tid; 4 * q < end; q += FSS_NT) {
@@ -2021,6 +2049,9 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                            s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0, (const uint32_t *)nullptr,
                            (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr, s.fs_zero + b0, false);
         if (pi >= 0) s.prof->end(pi, u, st);
+#ifdef GLC_EXP_PART
+        if (getenv("GLC_FS_STOP_AFTER_PART")) return hipGetLastError();        // timing experiments on the bucketing pass alone
+#endif
         hipLaunchKernelGGL(k_fs_scan, dim3(nbk), dim3(FS_MAXNB), 0, st, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB,
                            s.fs_flag + b0, (const uint32_t *)nullptr);
         pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;

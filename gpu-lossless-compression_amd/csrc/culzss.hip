@@ -783,6 +783,31 @@ hipError_t lzss_pack(hipStream_t st, const uint8_t *d_cand, int buf_length, int 
     return hipGetLastError();
 }
 
+// device memory -> PINNED host memory by a kernel (posted writes over PCIe, 16 bytes per lane).  Why not hipMemcpyAsync: a
+// copy-engine transfer queued BEHIND kernels of its stream is only handed to the engine when the host next looks at that
+// stream (measured with the reference's four-slot ring, culzss_ring_bench.c: every slot's copy-out started at its
+// onestream_finish_GPU, so nothing overlapped: 4.7 GB/s; 10.6 with AMD_DIRECT_DISPATCH=0, where a runtime thread keeps the
+// queue moving).  A kernel is just the next packet of the stream.
+__global__ __launch_bounds__(256) void k_lzss_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                      const uint8_t *__restrict__ tail_src, uint8_t *__restrict__ tail_dst,
+                                                      uint32_t tail)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail) tail_dst[threadIdx.x] = tail_src[threadIdx.x];
+}
+
+hipError_t lzss_copy_to_host(hipStream_t st, const void *d_src, void *h_dst, size_t bytes)
+{
+    if (!bytes) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(h_dst)) & 15) return hipErrorInvalidValue;
+    const size_t n16 = bytes / 16;
+    const uint32_t tail = (uint32_t)(bytes % 16);
+    const uint32_t grid = (uint32_t)(n16 / 256 < 1 ? 1 : (n16 / 256 > 128 ? 128 : n16 / 256));
+    hipLaunchKernelGGL(k_lzss_to_host, dim3(grid), dim3(256), 0, st, (const uint4 *)d_src, (uint4 *)h_dst, n16,
+                       (const uint8_t *)d_src + n16 * 16, (uint8_t *)h_dst + n16 * 16, tail);
+    return hipGetLastError();
+}
+
 hipError_t lzss_decode(hipStream_t st, const uint8_t *d_packed, const int *d_sizes, int buf_length, int nbuf,
                        uint8_t *d_out, int *d_err)
 {

@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 using namespace glc;
 
@@ -40,6 +41,10 @@ struct Slot {
     int len = 0;
     bool valid = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // One lock per ring slot: the reference's callers run a producer, a GPU thread and a CPU thread on DIFFERENT slots
+    // at the same time (culzss.c:85-176); under one global lock the launch of slot k + 1 (a dozen HIP calls) waited for
+    // the copy-out of slot k.  Order: g.mu (slot lookup, init) is never held while a slot lock is taken for long work.
+    std::mutex mu;
 };
 
 struct State {
@@ -94,12 +99,24 @@ bool ensure_slot(Slot &s, int buf_length)
     if (!ok(hipMalloc((void **)&s.d_packed, stride), "slot packed")) return false;
     if (!ok(hipMalloc((void **)&s.d_in, (size_t)buf_length), "slot in")) return false;
     if (!ok(hipMalloc((void **)&s.d_cand, (size_t)2 * buf_length), "slot candidates")) return false;
-    if (!ok(hipMalloc((void **)&s.d_size, sizeof(int)), "slot size")) return false;
+    if (!ok(hipMalloc((void **)&s.d_size, 16), "slot size")) return false;          // (leaves as one 16-byte piece: lzss_copy_to_host)
     if (!ok(hipMalloc(&s.d_work, lzss_work_bytes(buf_length, 1)), "slot work")) return false;
     if (!ok(hipHostMalloc((void **)&s.h_packed, stride, hipHostMallocDefault), "slot pinned")) return false;
-    if (!ok(hipHostMalloc((void **)&s.h_size, sizeof(int), hipHostMallocDefault), "slot pinned size")) return false;
+    if (!ok(hipHostMalloc((void **)&s.h_size, 16, hipHostMallocDefault), "slot pinned size")) return false;
     s.cap = buf_length;
     return true;
+}
+
+// is [p, p + bytes) pinned host memory the device can write (hipHostMalloc / initCPUmem) and 16-byte aligned?
+bool host_mapped(const void *p, size_t bytes)
+{
+    if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    hipPointerAttribute_t b;                                   // ... to its last byte
+    if (hipPointerGetAttributes(&b, (const char *)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return b.type == hipMemoryTypeHost && b.devicePointer != nullptr;
 }
 
 bool valid_len(int n) { return n > 0 && n % GLC_LZSS_PACKET == 0 && n <= GLC_LZSS_MAX_BUF; }
@@ -122,7 +139,7 @@ void resetGPU(void)
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.e0) (void)hipEventDestroy(s.e0);
         if (s.e1) (void)hipEventDestroy(s.e1);
-        s = Slot();
+        s.stream = nullptr; s.e0 = s.e1 = nullptr; s.key = nullptr; s.len = 0;
     }
     if (g.dd_in) (void)hipFree(g.dd_in);
     if (g.dd_out) (void)hipFree(g.dd_out);
@@ -143,7 +160,7 @@ void deleteGPUStreams(void)
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.e0) (void)hipEventDestroy(s.e0);
         if (s.e1) (void)hipEventDestroy(s.e1);
-        s = Slot();
+        s.stream = nullptr; s.e0 = s.e1 = nullptr; s.key = nullptr; s.len = 0;
     }
     g.inited = false;
 }
@@ -175,26 +192,55 @@ int compression_kernel_wrapper(unsigned char *buffer, int buf_length, unsigned c
                                int index, unsigned char *in_d, unsigned char *out_d)
 {
     if (!buffer || !compressed_buffer || !in_d || !out_d || !valid_len(buf_length)) return 0;
-    std::lock_guard<std::mutex> lk(g.mu);
-    init_locked();
-    Slot &s = g.slot[((index % NSLOTS) + NSLOTS) % NSLOTS];
+    Slot *sp;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        init_locked();
+        sp = &g.slot[((index % NSLOTS) + NSLOTS) % NSLOTS];
+    }
+    Slot &s = *sp;
+    std::lock_guard<std::mutex> lk(s.mu);
     (void)hipStreamSynchronize(s.stream);          // slot reuse: previous call on this slot must be done
     if (!ensure_slot(s, buf_length)) return 0;
     hipStream_t st = s.stream;
-    const size_t stride = lzss_pack_stride(buf_length);
     // The reference's pipeline hands EVERY ring slot the same in_d / out_d (culzss.c:85-86,108) and queues the slots
     // on different streams without waiting (gpu_compress.cu:426-460): slot s+1's copy-in can overwrite what slot
     // s's kernel is still reading.  The caller's device buffers are therefore accepted but not used: each slot
     // stages through buffers of its own.
     (void)in_d; (void)out_d;
+#ifdef GLC_LZ_HOSTTRACE
+    auto tnow = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+    const double t_0 = tnow();
+#endif
     if (!ok(hipMemcpyAsync(s.d_in, buffer, (size_t)buf_length, hipMemcpyHostToDevice, st), "H2D")) return 0;
+#ifdef GLC_LZ_HOSTTRACE
+    const double t_1 = tnow();
+#endif
     (void)hipEventRecord(s.e0, st);
     if (!ok(lzss_encode(st, s.d_in, buf_length, 1, s.d_cand, s.d_packed, s.d_size, s.d_work), "encode")) return 0;
     (void)hipEventRecord(s.e1, st);
-    if (!ok(hipMemcpyAsync(compressed_buffer, s.d_cand, (size_t)2 * buf_length, hipMemcpyDeviceToHost, st), "D2H cand")) return 0;
-    if (!ok(hipMemcpyAsync(s.h_packed, s.d_packed, stride, hipMemcpyDeviceToHost, st), "D2H packed")) return 0;
-    if (!ok(hipMemcpyAsync(s.h_size, s.d_size, sizeof(int), hipMemcpyDeviceToHost, st), "D2H size")) return 0;
-    s.key = compressed_buffer; s.len = buf_length; s.valid = true;
+#ifdef GLC_LZ_HOSTTRACE
+    const double t_2 = tnow();
+#endif
+    // what leaves the device here: the candidate stream (the interface's compressed_buffer: 2 B per input byte) and the
+    // packed size.  The packed bytes stay in the slot until aftercompression_wrapper knows how many there are and copies
+    // exactly those, straight into the caller's buffer (a whole-slot copy into pinned staging + a host memcpy were
+    // 1 MiB more over PCIe and ~60 us of the CPU thread per buffer).
+    if (host_mapped(compressed_buffer, (size_t)2 * buf_length)) {
+        // pinned (initCPUmem, as the reference's callers allocate it): written by a kernel -- see k_lzss_to_host
+        if (!ok(lzss_copy_to_host(st, s.d_cand, compressed_buffer, (size_t)2 * buf_length), "candidates to host")) return 0;
+    } else if (!ok(hipMemcpyAsync(compressed_buffer, s.d_cand, (size_t)2 * buf_length, hipMemcpyDeviceToHost, st), "D2H cand")) return 0;
+#ifdef GLC_LZ_HOSTTRACE
+    const double t_3 = tnow();
+#endif
+    if (!ok(lzss_copy_to_host(st, s.d_size, s.h_size, 16), "size to host")) return 0;
+#ifdef GLC_LZ_HOSTTRACE
+    fprintf(stderr, "wrapper slot %d: H2D %.0f us, kernels %.0f us, D2H cand %.0f us, D2H size %.0f us\n", index, t_1 - t_0, t_2 - t_1, t_3 - t_2, tnow() - t_3);
+#endif
+    {
+        std::lock_guard<std::mutex> lg(g.mu);
+        s.key = compressed_buffer; s.len = buf_length; s.valid = true;
+    }
     return 1;
 }
 
@@ -212,14 +258,17 @@ int onestream_finish_GPU(int index)
 int aftercompression_wrapper(unsigned char *buffer, int buf_length, unsigned char *bufferout, int *comp_length)
 {
     if (!buffer || !bufferout || !comp_length || !valid_len(buf_length)) return 0;
-    std::lock_guard<std::mutex> lk(g.mu);
-    init_locked();
     Slot *hit = nullptr;
-    for (int i = 0; i < NSLOTS; i++)
-        if (g.slot[i].valid && g.slot[i].key == bufferout && g.slot[i].len == buf_length) hit = &g.slot[i];
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        init_locked();
+        for (int i = 0; i < NSLOTS; i++)
+            if (g.slot[i].valid && g.slot[i].key == bufferout && g.slot[i].len == buf_length) { hit = &g.slot[i]; hit->valid = false; }
+    }
     if (!hit) {
         // candidates that did not come from a tracked call: pack them on the GPU now
         Slot &s = g.slot[NSLOTS];
+        std::lock_guard<std::mutex> lk(s.mu);
         if (!ensure_slot(s, buf_length)) return 0;
         uint8_t *d_cand = nullptr;
         if (!ok(hipMalloc((void **)&d_cand, (size_t)2 * buf_length), "cand upload")) return 0;
@@ -230,12 +279,18 @@ int aftercompression_wrapper(unsigned char *buffer, int buf_length, unsigned cha
                  && ok(hipStreamSynchronize(s.stream), "sync");
         (void)hipFree(d_cand);
         if (!good) return 0;
-        hit = &s;
-    } else if (!ok(hipStreamSynchronize(hit->stream), "sync")) return 0;
-    hit->valid = false;
+        const int size = *s.h_size;
+        if (size <= 0) return 0;                    // "compression took more": caller stores the buffer raw
+        memcpy(buffer, s.h_packed, (size_t)size);
+        *comp_length = size;
+        return 1;
+    }
+    std::lock_guard<std::mutex> lk(hit->mu);
+    if (!ok(hipStreamSynchronize(hit->stream), "sync")) return 0;
     const int size = *hit->h_size;
-    if (size <= 0) return 0;                        // "compression took more": caller stores the buffer raw
-    memcpy(buffer, hit->h_packed, (size_t)size);
+    if (size <= 0) return 0;                        // "compression took more": caller stores the buffer raw (untouched)
+    if (!ok(hipMemcpyAsync(buffer, hit->d_packed, (size_t)size, hipMemcpyDeviceToHost, hit->stream), "D2H packed") ||
+        !ok(hipStreamSynchronize(hit->stream), "sync")) return 0;
     *comp_length = size;
     return 1;
 }
@@ -251,6 +306,7 @@ int decompression_kernel_wrapper(unsigned char *buffer, int buf_length, int *dec
     if (!valid_len(orig) || pad < 0 || pad > orig || buf_length < 2 * (orig / GLC_LZSS_PACKET) + 6) return 0;
     std::lock_guard<std::mutex> lk(g.mu);
     init_locked();
+    std::lock_guard<std::mutex> ls(g.slot[NSLOTS].mu);        // (the scratch slot's stream: shared with the untracked packing path)
     if (g.dd_cap < orig) {
         if (g.dd_in) (void)hipFree(g.dd_in);
         if (g.dd_out) (void)hipFree(g.dd_out);
@@ -287,6 +343,7 @@ int culzss_compress(const unsigned char *in, int len, unsigned char *out, int *o
     std::lock_guard<std::mutex> lk(g.mu);
     init_locked();
     Slot &s = g.slot[NSLOTS];
+    std::lock_guard<std::mutex> ls(s.mu);
     if (!ensure_slot(s, len)) return 0;
     uint8_t *d_in = nullptr;
     if (!ok(hipMalloc((void **)&d_in, (size_t)len), "culzss_compress in")) return 0;

@@ -25,6 +25,8 @@ hipError_t lzss_encode(hipStream_t st, const uint8_t *d_in, int buf_length, int 
                        uint8_t *d_packed, int *d_sizes, void *d_work);
 hipError_t lzss_pack(hipStream_t st, const uint8_t *d_cand, int buf_length, int nbuf, uint8_t *d_packed,
                      int *d_sizes, void *d_work, const uint8_t *d_raw_in = nullptr);
+// device -> pinned (device-mapped) host memory by a kernel on the stream; both pointers 16-byte aligned
+hipError_t lzss_copy_to_host(hipStream_t st, const void *d_src, void *h_dst, size_t bytes);
 // d_err (optional): device int, bit 0 is raised when a stream is malformed (trailer / packet sizes out of range)
 hipError_t lzss_decode(hipStream_t st, const uint8_t *d_packed, const int *d_sizes, int buf_length, int nbuf,
                        uint8_t *d_out, int *d_err = nullptr);

@@ -63,6 +63,21 @@ def test_c_caller_culzss_pipeline_sequence(glc, tmp_path):
     assert r.stdout.count("packed_equal=1") == 4 and r.stdout.count("candidates_equal=1") == 4
 
 
+@pytest.mark.gpu
+def test_c_caller_culzss_ring_of_four_slots(glc, tmp_path):
+    """the reference's caller shape (culzss.c:85-176): four ring slots in flight -- from one thread, and from a producer, a
+    GPU thread and a CPU thread -- gives the bytes of one buffer at a time (tests/c_caller/culzss_ring_bench.c)"""
+    glc.lib()
+    exe = str(tmp_path / "culzss_ring_bench")
+    cmd = ["gcc", "-O2", "-std=gnu99", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_caller", "culzss_ring_bench.c"), "-o", exe,
+           "-L", PKG, "-lglc_amd", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "48", "12"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bytes_equal=1" in r.stdout, r.stdout + r.stderr
+
+
 def test_exchange_rig_compiles_with_gcc(glc, tmp_path):
     """include/glc_exchange.h needs neither hipcc nor the RCCL headers on the caller's side"""
     if shutil.which("gcc") is None:
