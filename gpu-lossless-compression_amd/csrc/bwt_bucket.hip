@@ -608,31 +608,6 @@ __global__ __launch_bounds__(FS_MAXNB) void k_fs_scan(const uint32_t *__restrict
     fbase[(size_t)b * FS_MAXNB + tid] = block_excl_add<FS_MAXNB>(f, s_tmp);
 }
 
-// Work-list space for a bucket's runs of equal codes (`tot` entries, > 0; called by every thread behind the barrier that
-// completed s_wl).  A bucket has wl_fixed entries of its own at bk * wl_fixed: nothing to ask anybody for, the count goes
-// to wl_bcnt with a plain store.  (One atomicAdd with return on a per-block counter was ~1.5 us of a workgroup's 7.6 us:
-// every bucket of an i.i.d. block has a handful of tied words, so every workgroup sat it out, and issuing it early
-// bought nothing -- the workgroup cannot end before it knows where its entries go.)  Only a bucket with more tied words
-// than that takes entries from the shared second half of the list, with the atomic; a full list flags the block.
-__device__ __forceinline__ uint32_t fs_wl_reserve(uint32_t tot, uint32_t *s_bcast, uint32_t b, uint32_t bk, uint32_t nbl,
-                                                  uint32_t tid, uint32_t wl_cap, uint32_t wl_fixed,
-                                                  uint32_t *__restrict__ wl_count, uint32_t *__restrict__ wl_bcnt,
-                                                  uint32_t *__restrict__ flag)
-{
-    if (tot <= wl_fixed) {                                     // (uniform)
-        if (tid == 0) wl_bcnt[(size_t)b * FS_MAXNB + bk] = tot;
-        return bk * wl_fixed;
-    }
-    const uint32_t shared0 = wl_fixed << nbl;                  // first entry of the shared part
-    if (tid == 0) {
-        uint32_t base = shared0 + atomicAdd(&wl_count[b], tot);
-        if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
-        *s_bcast = base;
-    }
-    __syncthreads();
-    return *s_bcast;
-}
-
 // ---------------------------------------------------------------------------
 // one workgroup sorts one bucket in LDS and writes its rows of the result.  Runs of equal codes (a few
 // per bucket on Zipf data) are not resolved here -- that needs the text, and a global-memory round trip on
@@ -648,8 +623,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
                                                     uint8_t *__restrict__ bwt_out, size_t bwt_stride,
                                                     int *__restrict__ d_index, uint32_t *__restrict__ sa_out,
                                                     size_t sa_stride, uint4 *__restrict__ wl, uint32_t wl_cap,
-                                                    uint32_t *__restrict__ wl_count, uint32_t *__restrict__ wl_bcnt,
-                                                    uint32_t wl_fixed)
+                                                    uint32_t *__restrict__ wl_count)
 {
     __shared__ uint64_t s_w[FS_FILLMAX + 4];                   // + 4 sentinels behind the last word
     __shared__ uint32_t s_cp[FS_BINS / 2 + 1];                 // bin counters, then bin starts (two 16-bit values per word), then BWT bytes
@@ -771,7 +745,8 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
     // rows R0 .. R0 + c of the block's BWT are staged so that aligned dwords of LDS are aligned dwords of the output
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
     const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
-    // 3. tied groups -> the block's work list, into the bucket's own entries (fs_wl_reserve)
+    // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup
+    //    (an atomic per group on a shared counter serialised the whole kernel: +2.4 ms per 256 blocks).
     bool any = false;
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
@@ -783,7 +758,14 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort(uint32_t n, uint32_t nbl, co
         }
     }
     if (__syncthreads_or((int)any)) {
-        const uint32_t base = fs_wl_reserve(s_wl, &s_deep, b, bk, nbl, tid, wl_cap, wl_fixed, wl_count, wl_bcnt, flag);
+        if (tid == 0) {
+            const uint32_t tot = s_wl;
+            uint32_t base = atomicAdd(&wl_count[b], tot);
+            if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
+            s_deep = base;
+        }
+        __syncthreads();
+        const uint32_t base = s_deep;
         uint4 *WL = wl + (size_t)b * wl_cap;
         if (base != 0xFFFFFFFFu) {
 #pragma unroll
@@ -830,8 +812,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
                                                         uint32_t *__restrict__ flag, uint8_t *__restrict__ bwt_out,
                                                         size_t bwt_stride, int *__restrict__ d_index, uint4 *__restrict__ wl,
                                                         uint32_t wl_cap, uint32_t *__restrict__ wl_count,
-                                                        const uint32_t *__restrict__ zero_bucket,
-                                                        uint32_t *__restrict__ wl_bcnt, uint32_t wl_fixed)
+                                                        const uint32_t *__restrict__ zero_bucket)
 {
     __shared__ uint64_t s_w[FS_FILLMAX + 4];                   // + 4 sentinels behind the last word
     __shared__ uint32_t s_cp[FS_BINS / 2 + 1];                 // bin counters, then bin starts (two 16-bit values per word), then BWT bytes
@@ -984,7 +965,10 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
     // rows R0 .. R0 + c of the block's BWT are staged so that aligned dwords of LDS are aligned dwords of the output
     uint8_t *O = bwt_out + (size_t)b * bwt_stride + R0;
     const uint32_t shift = (uint32_t)(reinterpret_cast<uintptr_t>(O) & 3u);
-    // 3. tied groups -> the block's work list, into the bucket's own entries (fs_wl_reserve: no atomic, nothing to wait for)
+    // 3. tied groups -> the block's work list.  Entries are reserved with ONE global atomic per workgroup.  (Round 5: the
+    //    ~1.5 us a workgroup sits out for its return are NOT on the kernel's critical path -- with entries of the bucket's own
+    //    and no atomic at all the kernel ran 3.50 against 3.47 ms per GiB, and k_fs_ties, which then has to walk 512 short
+    //    lists per block, 0.32 against 0.18.)
     bool any = false;
 #pragma unroll
     for (int r = 0; r < FSS_ITEMS; r++) {
@@ -996,7 +980,14 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
         }
     }
     if (__syncthreads_or((int)any)) {
-        const uint32_t base = fs_wl_reserve(s_wl, &s_deep, b, bk, nbl, tid, wl_cap, wl_fixed, wl_count, wl_bcnt, flag);
+        if (tid == 0) {
+            const uint32_t tot = s_wl;
+            uint32_t base = atomicAdd(&wl_count[b], tot);
+            if (base + tot > wl_cap) { atomicOr(&flag[b], 4u); base = 0xFFFFFFFFu; }   // list full: block flagged
+            s_deep = base;
+        }
+        __syncthreads();
+        const uint32_t base = s_deep;
         uint4 *WL = wl + (size_t)b * wl_cap;
         if (base != 0xFFFFFFFFu) {
 #pragma unroll
@@ -1033,18 +1024,18 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                  const uint4 *__restrict__ wl, uint32_t wl_cap,
-                                                 const uint32_t *__restrict__ wl_count, const uint32_t *__restrict__ wl_bcnt,
-                                                 uint32_t wl_fixed, uint32_t nb, uint32_t *__restrict__ flag,
+                                                 const uint32_t *__restrict__ wl_count, uint32_t *__restrict__ flag,
                                                  uint8_t *__restrict__ bwt_out, size_t bwt_stride,
                                                  int *__restrict__ d_index, uint32_t *__restrict__ sa_out, size_t sa_stride)
 {
     uint32_t gx, gy;
     xcd_order(gx, gy);                                         // a block's text in one L2 for the comparisons
     const uint32_t b = gy;
-    if (flag[b]) return;                                       // (flags of this pass are all set before it starts)
+    const uint32_t total = wl_count[b];
+    if (total == 0 || total > wl_cap || flag[b]) return;       // (flags of this pass are all set before it starts)
     const uint4 *WL = wl + (size_t)b * wl_cap;
     const uint8_t *T = text + (size_t)b * stride;
-    auto member = [&](uint32_t e) {
+    for (uint32_t e = gx * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const uint4 me = WL[e];
         const uint32_t gs = me.w, idx = me.x >> 8;
         uint32_t rank = 0;
@@ -1068,38 +1059,26 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
                 else rank += fs_suffix_less(T, n, oi[k], idx, &deep) ? 1u : 0u;
             }
         }
-        if (deep) { atomicOr(&flag[b], 2u); return; }
+        if (deep) { atomicOr(&flag[b], 2u); continue; }
         const uint32_t row = me.y + rank;
         if (bwt_out) bwt_out[(size_t)b * bwt_stride + row] = (uint8_t)me.x;
         if (sa_out) sa_out[(size_t)b * sa_stride + row] = idx;
         if (idx == 0 && d_index) d_index[b] = (int)row;
-    };
-    // the buckets' own entries: sixteen lanes per bucket (an i.i.d. block has ~8 tied words per bucket)
-    const uint32_t gl = threadIdx.x & 15u;
-    for (uint32_t bk = (gx * 256 + threadIdx.x) >> 4; bk < nb; bk += gridDim.x * 16) {
-        const uint32_t cnt = min(wl_bcnt[(size_t)b * FS_MAXNB + bk], wl_fixed);
-        for (uint32_t k = gl; k < cnt; k += 16) member(bk * wl_fixed + k);
     }
-    // ... and what buckets with more of them took from the shared part
-    const uint32_t shared0 = wl_fixed * nb, total = wl_count[b];
-    if (total > wl_cap - shared0) return;                      // (it overflowed: the block is flagged)
-    for (uint32_t e = gx * 256 + threadIdx.x; e < total; e += gridDim.x * 256) member(shared0 + e);
 }
 
 // everything the pass accumulates into, cleared by ONE launch (six hipMemsetAsync calls were six dispatches of ~2 us with
 // ~8 us between them: 90 us of a 1 MiB call that takes 400)
 __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__restrict__ hist, uint32_t *__restrict__ fill,
                                                   uint32_t *__restrict__ flag, uint32_t flag_value, uint32_t *__restrict__ wlcnt,
-                                                  uint32_t *__restrict__ dup, uint32_t *__restrict__ nflag,
-                                                  uint32_t *__restrict__ wlbcnt)
+                                                  uint32_t *__restrict__ dup, uint32_t *__restrict__ nflag)
 {
-    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + 2u * nf + 3u * nblk + 2u;
+    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + nf + 3u * nblk + 2u;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         if (i < nh) hist[i] = 0;
         else if (i < nh + nf) fill[i - nh] = 0;
-        else if (i < nh + 2u * nf) wlbcnt[i - nh - nf] = 0;
         else {
-            const uint32_t j = i - nh - 2u * nf;
+            const uint32_t j = i - nh - nf;
             if (j < nblk) flag[j] = flag_value;
             else if (j < 2 * nblk) wlcnt[j - nblk] = 0;
             else if (j < 3 * nblk) dup[j - 2 * nblk] = 0;
@@ -2007,12 +1986,11 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
     {
-        const uint32_t words = nblk * (256u + 2u * FS_MAXNB + 3u) + 2u, g = (words + 1023) / 1024;
+        const uint32_t words = nblk * (256u + FS_MAXNB + 3u) + 2u, g = (words + 1023) / 1024;
         // (skip_tier1: every block starts flagged -- no attempt, the sample sorter takes them all)
         hipLaunchKernelGGL(k_fs_clear, dim3(g < 2048 ? g : 2048), dim3(256), 0, st, nblk, s.fs_hist, s.fs_fill, s.fs_flag,
-                           s.skip_tier1 ? 1u : 0u, s.fs_wlcnt, s.fs_dup, s.fs_nflag, s.fs_wlbcnt);
+                           s.skip_tier1 ? 1u : 0u, s.fs_wlcnt, s.fs_dup, s.fs_nflag);
     }
-    const uint32_t wl_fixed = (s.fs_wl_cap / 2) >> nbl;     // work-list entries every bucket has of its own (fs_wl_reserve)
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
@@ -2061,16 +2039,16 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                                s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
                                bwt_out ? bwt_out + (size_t)b0 * bwt_stride : nullptr, bwt_stride, d_index ? d_index + b0 : nullptr,
                                sa_out ? sa_out + (size_t)b0 * s.nmax : nullptr, (size_t)s.nmax, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
-                               s.fs_wlcnt + b0, s.fs_wlbcnt + (size_t)b0 * FS_MAXNB, wl_fixed);
+                               s.fs_wlcnt + b0);
         else
             hipLaunchKernelGGL(k_fs_sort_bwt, dim3(nb, nbk), dim3(FSS_NT), 0, st, nbl, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
                                s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
                                bwt_out + (size_t)b0 * bwt_stride, bwt_stride, d_index + b0, s.fs_wl + (size_t)b0 * s.fs_wl_cap, s.fs_wl_cap,
-                               s.fs_wlcnt + b0, s.fs_zero + b0, s.fs_wlbcnt + (size_t)b0 * FS_MAXNB, wl_fixed);
+                               s.fs_wlcnt + b0, s.fs_zero + b0);
         if (pi >= 0) s.prof->end(pi, u, st);
     }
-    hipLaunchKernelGGL(k_fs_ties, dim3((nb + 15) / 16, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
-                       s.fs_wlbcnt, wl_fixed, nb, s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+    hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
+                       s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
                        s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
     return hipGetLastError();

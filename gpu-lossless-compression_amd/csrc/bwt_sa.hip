@@ -943,7 +943,6 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     s.fs_wl_cap = nmax / 8 < 1024 ? 1024 : nmax / 8;
     GLC_TRY(A((void **)&s.fs_wl, (size_t)rows * s.fs_wl_cap * 16));
     GLC_TRY(A((void **)&s.fs_wlcnt, (size_t)rows * 4));
-    GLC_TRY(A((void **)&s.fs_wlbcnt, (size_t)rows * FS_MAXNB * 4));
     // (posA/B, hdA/B, isa, sa, tile_hist, tile_state -- 24.6 MiB per 1 MiB block, used by the general sorter alone --
     //  are allocated by sa_general_reserve the first time a block gets that far)
     GLC_TRY(A((void **)&s.digit_base, (size_t)rows * RS_MAXPASS * SA_MAXRADIX * 4));
@@ -982,7 +981,7 @@ hipError_t sa_general_reserve(SaScratch &s, bool only_sa)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.ss_long, s.ss_long_count, s.ss_gtile, s.ss_cnt2, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.fs_wlbcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
+    void *ps[] = {s.keyA, s.ss_long, s.ss_long_count, s.ss_gtile, s.ss_cnt2, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);

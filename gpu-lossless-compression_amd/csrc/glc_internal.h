@@ -162,8 +162,7 @@ struct SaScratch {
     uint32_t  parity = 0;                        // set by the caller before sa_build_begin
     uint32_t *fs_nflag = nullptr;                // [4] blocks flagged by the bucket sorter; given up on by the sample sorter; listed for its second attempt
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
-    uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use in the shared part (the second half of a block's list)
-    uint32_t *fs_wlbcnt = nullptr;               // [rows][FS_MAXNB] entries in use in every bucket's own part (fs_wl_cap / 2 / buckets each)
+    uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
     uint32_t  fs_wl_cap = 0;
     uint32_t  last_flagged = 0;                  // blocks of the last sa_build the bucket sorter gave up on
     uint32_t  last_retried = 0;                  // ... the sample sorter took in a second attempt (a bucket past its slot in the first)
