@@ -73,6 +73,50 @@ constexpr uint32_t FSH_SLICE = 32768;
 // takes it.  A wrong guess costs time, never correctness (the other way round, the attempt flags the block as before).
 constexpr uint32_t FSH_SLOTS = 2048, FS_DUP_FLAG = 48;
 
+// {C, p} scaled to 2^32.  floor() on both keeps C[s] + p[s] <= C[s+1], which is what makes the code monotone.
+constexpr uint32_t FS_DONE = 8u;                    // flag value: the block is finished (a constant block: k_fs_tables wrote its rows)
+
+__global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ hist, uint32_t n,
+                                                   uint2 *__restrict__ tab, const uint32_t *__restrict__ dup,
+                                                   uint32_t *__restrict__ flag, const uint8_t *__restrict__ text, size_t stride,
+                                                   uint8_t *__restrict__ bwt_out, size_t bwt_stride, int *__restrict__ d_index,
+                                                   uint32_t *__restrict__ sa_out, size_t sa_stride)
+{
+    __shared__ uint32_t s_tmp[5];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t h = hist[(size_t)b * 256 + tid];
+    // A block of ONE symbol (zero pages, padding) has nothing to sort: SA = n-1 .. 0, every BWT byte is the symbol, the
+    // index row is n - 1.  Left to the tiers it is their worst case -- every suffix ties with every other for the whole
+    // block: bucket overflow, the sample sorter's depth cap, then ~20 prefix-doubling rounds of the general sorter (1.3 ms
+    // where a Zipf block takes 0.012).  FS_DONE overrides whatever the flag was (text-likeness, a caller's "sample sorter
+    // first"): every tier skips a flagged block, and k_fs_finish does not list this one for anybody.  Its rows are written
+    // right here, by this workgroup (a kernel of its own was one more launch in every call's chain).
+    const bool constant = __syncthreads_or((int)(h == n)) != 0;
+    if (tid == 0) {
+        if (constant) flag[b] = FS_DONE;
+        else if (dup[b] >= FS_DUP_FLAG) flag[b] = 1u;               // text-like (see k_fs_hist): straight to the sample sorter
+    }
+    if (constant) {
+        const uint32_t sym = text[(size_t)b * stride];
+        const uint32_t v = sym * 0x01010101u;
+        if (bwt_out) {
+            uint8_t *O = bwt_out + (size_t)b * bwt_stride;
+            const uint32_t head = min(n, (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 15u)) & 15u));
+            const uint32_t nvec = (n - head) / 16;
+            for (uint32_t i = tid; i < head; i += 256) O[i] = (uint8_t)sym;
+            for (uint32_t i = tid; i < nvec; i += 256) reinterpret_cast<uint4 *>(O + head)[i] = make_uint4(v, v, v, v);
+            for (uint32_t i = head + nvec * 16 + tid; i < n; i += 256) O[i] = (uint8_t)sym;
+        }
+        if (sa_out) for (uint32_t i = tid; i < n; i += 256) sa_out[(size_t)b * sa_stride + i] = n - 1 - i;
+        if (d_index && tid == 0) d_index[b] = (int)(n - 1);
+        return;                                                // (uniform; the table of a flagged block is never read)
+    }
+    const uint32_t c = block_excl_add<256>(h, s_tmp);
+    const uint64_t C32 = ((uint64_t)c << 32) / n, P32 = ((uint64_t)h << 32) / n;
+    tab[(size_t)b * 256 + tid] = make_uint2((uint32_t)(C32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : C32),
+                                            (uint32_t)(P32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : P32));
+}
+
 #ifndef GLC_FSH_COPIES
 #define GLC_FSH_COPIES 16
 #endif
@@ -136,49 +180,6 @@ __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ tex
     if (tid == 0 && s_dup) atomicAdd(&dup[b], s_dup);
 }
 
-// {C, p} scaled to 2^32.  floor() on both keeps C[s] + p[s] <= C[s+1], which is what makes the code monotone.
-constexpr uint32_t FS_DONE = 8u;                    // flag value: the block is finished (a constant block: k_fs_tables wrote its rows)
-
-__global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ hist, uint32_t n,
-                                                   uint2 *__restrict__ tab, const uint32_t *__restrict__ dup,
-                                                   uint32_t *__restrict__ flag, const uint8_t *__restrict__ text, size_t stride,
-                                                   uint8_t *__restrict__ bwt_out, size_t bwt_stride, int *__restrict__ d_index,
-                                                   uint32_t *__restrict__ sa_out, size_t sa_stride)
-{
-    __shared__ uint32_t s_tmp[5];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t h = hist[(size_t)b * 256 + tid];
-    // A block of ONE symbol (zero pages, padding) has nothing to sort: SA = n-1 .. 0, every BWT byte is the symbol, the
-    // index row is n - 1.  Left to the tiers it is their worst case -- every suffix ties with every other for the whole
-    // block: bucket overflow, the sample sorter's depth cap, then ~20 prefix-doubling rounds of the general sorter (1.3 ms
-    // where a Zipf block takes 0.012).  FS_DONE overrides whatever the flag was (text-likeness, a caller's "sample sorter
-    // first"): every tier skips a flagged block, and k_fs_finish does not list this one for anybody.  Its rows are written
-    // right here, by this workgroup (a kernel of its own was one more launch in every call's chain).
-    const bool constant = __syncthreads_or((int)(h == n)) != 0;
-    if (tid == 0) {
-        if (constant) flag[b] = FS_DONE;
-        else if (dup[b] >= FS_DUP_FLAG) flag[b] = 1u;          // text-like (see k_fs_hist): straight to the sample sorter
-    }
-    if (constant) {
-        const uint32_t sym = text[(size_t)b * stride];
-        const uint32_t v = sym * 0x01010101u;
-        if (bwt_out) {
-            uint8_t *O = bwt_out + (size_t)b * bwt_stride;
-            const uint32_t head = min(n, (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(O) & 15u)) & 15u));
-            const uint32_t nvec = (n - head) / 16;
-            for (uint32_t i = tid; i < head; i += 256) O[i] = (uint8_t)sym;
-            for (uint32_t i = tid; i < nvec; i += 256) reinterpret_cast<uint4 *>(O + head)[i] = make_uint4(v, v, v, v);
-            for (uint32_t i = head + nvec * 16 + tid; i < n; i += 256) O[i] = (uint8_t)sym;
-        }
-        if (sa_out) for (uint32_t i = tid; i < n; i += 256) sa_out[(size_t)b * sa_stride + i] = n - 1 - i;
-        if (d_index && tid == 0) d_index[b] = (int)(n - 1);
-        return;                                                // (uniform; the table of a flagged block is never read)
-    }
-    const uint32_t c = block_excl_add<256>(h, s_tmp);
-    const uint64_t C32 = ((uint64_t)c << 32) / n, P32 = ((uint64_t)h << 32) / n;
-    tab[(size_t)b * 256 + tid] = make_uint2((uint32_t)(C32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : C32),
-                                            (uint32_t)(P32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : P32));
-}
 
 // ---------------------------------------------------------------------------
 // suffix comparison in the text (runs of equal codes; the sample tier's splitters)
@@ -1067,13 +1068,42 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
     }
 }
 
+// blocks the fast path gave up on -> live counts for the general sorter
+// (`redo` is a per-call copy of the flags for the stages queued speculatively behind the sort: under stage
+//  pipelining the next call clears `flag` while they may still be reading)
+// nflag[0] = flagged blocks; nflag[3] = ticket of this launch's workgroups: the last one stores the count where the host reads
+// it (h_nflag: pinned, device-mapped) -- a copy command behind the pass was one more launch in every call
+__global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint32_t nblk, uint32_t *__restrict__ lcnt,
+                            uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo, uint32_t *__restrict__ keep,
+                            uint32_t *__restrict__ list, uint32_t *__restrict__ h_nflag)
+{
+    __shared__ uint32_t s_last;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) {
+        const uint32_t f = (flag[b] && flag[b] != FS_DONE) ? n : 0u;    // (FS_DONE: a constant block, finished by k_fs_tables)
+        lcnt[b] = f;
+        redo[b] = f;
+        keep[b] = f ? 0u : 1u;
+        if (f) list[atomicAdd(nflag, 1u)] = b;                 // (any order)
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&nflag[3], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        *reinterpret_cast<volatile uint32_t *>(h_nflag) = atomicAdd(nflag, 0u);
+        __threadfence_system();
+    }
+}
+
 // everything the pass accumulates into, cleared by ONE launch (six hipMemsetAsync calls were six dispatches of ~2 us with
 // ~8 us between them: 90 us of a 1 MiB call that takes 400)
 __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__restrict__ hist, uint32_t *__restrict__ fill,
                                                   uint32_t *__restrict__ flag, uint32_t flag_value, uint32_t *__restrict__ wlcnt,
                                                   uint32_t *__restrict__ dup, uint32_t *__restrict__ nflag)
 {
-    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + nf + 3u * nblk + 2u;
+    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + nf + 3u * nblk + 4u;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         if (i < nh) hist[i] = 0;
         else if (i < nh + nf) fill[i - nh] = 0;
@@ -1082,25 +1112,8 @@ __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__res
             if (j < nblk) flag[j] = flag_value;
             else if (j < 2 * nblk) wlcnt[j - nblk] = 0;
             else if (j < 3 * nblk) dup[j - 2 * nblk] = 0;
-            else nflag[j - 3 * nblk] = 0;
+            else nflag[j - 3 * nblk] = 0;                       // [0] flagged blocks, [1] [2] the sample sorter's, [3] k_fs_finish's ticket
         }
-    }
-}
-
-// blocks the fast path gave up on -> live counts for the general sorter
-// (`redo` is a per-call copy of the flags for the stages queued speculatively behind the sort: under stage
-//  pipelining the next call clears `flag` while they may still be reading)
-__global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint32_t nblk, uint32_t *__restrict__ lcnt,
-                            uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo, uint32_t *__restrict__ keep,
-                            uint32_t *__restrict__ list)
-{
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nblk) {
-        const uint32_t f = (flag[b] && flag[b] != FS_DONE) ? n : 0u;    // (FS_DONE: a constant block, finished by k_fs_tables)
-        lcnt[b] = f;
-        redo[b] = f;
-        keep[b] = f ? 0u : 1u;
-        if (f) list[atomicAdd(nflag, 1u)] = b;                 // (any order)
     }
 }
 
@@ -1986,11 +1999,12 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
     {
-        const uint32_t words = nblk * (256u + FS_MAXNB + 3u) + 2u, g = (words + 1023) / 1024;
+        const uint32_t words = nblk * (256u + FS_MAXNB + 3u) + 4u, g = (words + 1023) / 1024;
         // (skip_tier1: every block starts flagged -- no attempt, the sample sorter takes them all)
         hipLaunchKernelGGL(k_fs_clear, dim3(g < 2048 ? g : 2048), dim3(256), 0, st, nblk, s.fs_hist, s.fs_fill, s.fs_flag,
                            s.skip_tier1 ? 1u : 0u, s.fs_wlcnt, s.fs_dup, s.fs_nflag);
     }
+    uint32_t *h_nflag = s.h_max_cnt + 4;                       // pinned, device-mapped: written by the kernel that finishes the pass
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
     hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
@@ -2001,7 +2015,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     if (s.skip_tier1) {
         // most blocks of the plan's previous call were flagged: no attempt, every block goes to the sample sorter
         hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
-                           s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
+                           s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list, h_nflag);
         return hipGetLastError();
     }
     // Sub-waves (GLC_FS_SUBWAVE = blocks per sub-wave, 0 = the whole call at once): the 8-byte suffix words of a block make
@@ -2050,7 +2064,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
-                       s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list);
+                       s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list, h_nflag);
     return hipGetLastError();
 }
 

@@ -1175,7 +1175,8 @@ hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_strid
     if (!bwt_out) GLC_TRY(sa_general_reserve(s, true));
     s.skip_tier1 = s.sorter == 4;                            // the caller knows its data is text-like: no bucket-sorter attempt
     GLC_TRY(fs_build(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa));
-    GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 4, s.fs_nflag, 4, hipMemcpyDeviceToHost, st));
+    // (the flagged-block count is in s.h_max_cnt[4] when the pass's last kernel is through: it writes it there itself --
+    //  k_fs_finish / k_fs_ties -- where a copy command behind the pass was one more ~5 us link in a single call's chain)
     if (!s.ev_flag) GLC_TRY(hipEventCreateWithFlags(&s.ev_flag, hipEventDisableTiming));
     GLC_TRY(hipEventRecord(s.ev_flag, st));
     s.pending = true;

@@ -533,13 +533,21 @@ CUDPPResult glcPlanSetStream(CUDPPHandle planHandle, void *hipStream)
     return CUDPP_SUCCESS;
 }
 
+__global__ void k_status_fetch(uint32_t *__restrict__ d_status, uint32_t *__restrict__ h_status)
+{
+    *reinterpret_cast<volatile uint32_t *>(h_status) = *d_status;
+    *d_status = 0;
+}
+
 CUDPPResult glcPlanSynchronize(CUDPPHandle planHandle)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     if (p->config.algorithm == CUDPP_COMPRESS) static_cast<CompressPlan *>(p)->join_side();
-    hipError_t e = hipMemcpyAsync(p->h_status, p->d_status, 4, hipMemcpyDeviceToHost, p->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(p->d_status, 0, 4, p->stream);
+    // status word: fetched into pinned memory and cleared by ONE small kernel (a copy command + a fill command were two more
+    // ~5 us links in the chain a cudppCompress caller waits for)
+    hipLaunchKernelGGL(k_status_fetch, dim3(1), dim3(1), 0, p->stream, p->d_status, p->h_status);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
     if (e != hipSuccess) return CUDPP_ERROR_UNKNOWN;
     if (p->timing && p->ev_valid) {

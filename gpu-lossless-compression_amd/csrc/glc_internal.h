@@ -160,7 +160,7 @@ struct SaScratch {
     uint32_t *fs_dup = nullptr;                  // [rows] repeated 6-grams among the samples k_fs_hist looks at (text-likeness probe)
     uint32_t *fs_zero = nullptr;                 // [rows] bucket that holds the word of suffix 0 (k_fs_part -> k_fs_sort_bwt: the BWT index is looked for there only)
     uint32_t  parity = 0;                        // set by the caller before sa_build_begin
-    uint32_t *fs_nflag = nullptr;                // [4] blocks flagged by the bucket sorter; given up on by the sample sorter; listed for its second attempt
+    uint32_t *fs_nflag = nullptr;                // [4] blocks flagged by the bucket sorter; given up on by the sample sorter; listed for its second attempt; ticket of the finishing kernel
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
     uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
     uint32_t  fs_wl_cap = 0;
