@@ -762,6 +762,7 @@ def compact_line(res, details_path):
     if "output_layout" in line["config"]:
         line["config"]["output_layout"] = line["config"]["output_layout"].split(":")[0]
     line.update(pick(res, ["compression_ratio", "per_rank_GBps", "value_no_stage_overlap_GBps", "decode_GBps", "decode_one_plan_GBps",
+                           "decode_one_plan_stages_back_to_back_GBps",
                            "frac_of_hbm_read_roofline", "frac_of_hbm_roofline_algorithmic_1_plus_rho", "encode_hbm_bytes_per_input_byte",
                            "stream_read_ceiling_GBps", "parity", "roundtrip", "value_with_gather", "gather_ms", "rccl_ranks_seen"]))
     rf = res.get("roofline") or {}
@@ -1268,6 +1269,21 @@ def main():
     dec1 = sum(min(rows, nblocks - b0) for b0 in batches[:nrep]) * n / (time.perf_counter() - t0d) / 1e9
     dec_prof = plan.kernel_profiles()
     plan.enable_timing(0)
+    # ... and the same plan with its stage pipelining on (glcPlanSetPipelining: inverse BWT of call k on the plan's side stream
+    # under Huffman + inverse MTF of call k + 1): ONE plan, one caller thread -- the figure a single caller gets
+    plan.set_pipelining(True)
+    for b0 in batches[:nrep]:
+        dec_batch(plan, b0, min(rows, nblocks - b0), d_back1.data_ptr())
+    plan.synchronize()
+    t0p = time.perf_counter()
+    for b0 in batches[:nrep]:
+        dec_batch(plan, b0, min(rows, nblocks - b0), d_back1.data_ptr())
+    plan.synchronize()
+    dec1_pipe = sum(min(rows, nblocks - b0) for b0 in batches[:nrep]) * n / (time.perf_counter() - t0p) / 1e9
+    last_b0 = batches[:nrep][-1]
+    if not bool(torch.equal(d_back1[:min(rows, nblocks - last_b0) * n], d_in[last_b0 * n:(last_b0 + min(rows, nblocks - last_b0)) * n])):
+        raise RuntimeError("round trip failed in the pipelined one-plan decode")
+    plan.set_pipelining(False)
     del d_back1
     dec_elapsed = torch.tensor([td1 - td0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -1352,7 +1368,8 @@ def main():
         ttab = dict(ttab_all)
         ttab.setdefault("k_dec_huff", 0)
         dtab = kernel_table(dec_get, dec_alg, dec_pmc, issue, traffic_tab=ttab, blocks_in_traffic=tblocks_all, census=census, rho=rho)
-        decode_block = {"one_plan_GBps": round(dec1, 4), "pipelined_plans_GBps": round(decode_gbps, 4),
+        decode_block = {"one_plan_GBps": round(dec1_pipe, 4), "one_plan_stages_back_to_back_GBps": round(dec1, 4),
+                        "pipelined_plans_GBps": round(decode_gbps, 4),
                         "hbm_frac_algorithmic_rho_plus_1": round((1 + rho) * dec1 / HBM_PEAK_GBPS, 6),
                         "roofline": roofline_of(dtab, "one plan, stages back to back; frac = (rho + 1) x decoded bytes of a launch / its time / 8 TB/s (SURVEY.md 8(d)); "
                                                       "kernel_design_frac counts the kernel's own design traffic"),
@@ -1393,7 +1410,8 @@ def main():
             "compression_ratio": round(ratio, 4),
             "value_no_stage_overlap_GBps": round(no_overlap_gbps, 4) if no_overlap_gbps else (round(value, 4) if not use_pipe else None),
             "decode_GBps": round(decode_gbps, 4),
-            "decode_one_plan_GBps": round(dec1, 4),
+            "decode_one_plan_GBps": round(dec1_pipe, 4),
+            "decode_one_plan_stages_back_to_back_GBps": round(dec1, 4),
             "decode": decode_block,
             "roundtrip": "decode(encode(x)) == x on all %d blocks per GPU" % nblocks,
             "frac_of_hbm_read_roofline": round(value / world / HBM_PEAK_GBPS, 6),
