@@ -495,10 +495,12 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
         plan.synchronize()
         dt = time.perf_counter() - t0
         f1, f2 = plan.last_sort_stats()
+        nper = plan.last_sort_periodic()
         back = glc.decompress_batch(plan, outd, n, nd)
         torch.cuda.synchronize()
         out_res["deep_repeats"] = {"GBps": round(n * nd / dt / 1e9, 3), "ms_per_block": round(dt * 1e3 / nd, 3), "blocks": nd,
-                                   "blocks_left_by_sample_sorter": f2, "round_trip_ok": bool(torch.equal(back, d_deep)),
+                                   "blocks_left_by_sample_sorter": f2, "blocks_finished_by_periodic_tier": nper,
+                                   "blocks_resumed": plan.last_sort_resumed(), "round_trip_ok": bool(torch.equal(back, d_deep)),
                                    "what": "repeats deeper than the sample sorter's ~500-symbol cap (repeated 4 KiB page, one byte repeated up to the "
                                            "last position, two-byte period, text with a 2000-byte phrase every 16 KiB): the general sorter's cliff"}
     del d_deep, outd, back
@@ -781,7 +783,7 @@ def compact_line(res, details_path):
     if tl:
         line["text_like"] = {k: pick(tl[k], ["GBps", "ratio", "distinct_blocks", "blocks_left_by_sample_sorter", "round_trip_ok"]) for k in ("text", "log") if k in tl}
         if tl.get("deep_repeats"):
-            line["text_like"]["deep_repeats"] = pick(tl["deep_repeats"], ["GBps", "ms_per_block", "blocks", "blocks_left_by_sample_sorter", "round_trip_ok"])
+            line["text_like"]["deep_repeats"] = pick(tl["deep_repeats"], ["GBps", "ms_per_block", "blocks", "blocks_left_by_sample_sorter", "blocks_finished_by_periodic_tier", "round_trip_ok"])
         if tl.get("partly_deep"):
             line["text_like"]["partly_deep"] = pick(tl["partly_deep"], ["GBps", "blocks", "blocks_resumed", "GBps_general_sorter_from_scratch", "round_trip_ok"])
     cz = res.get("culzss") or {}

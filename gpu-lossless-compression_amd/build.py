@@ -18,7 +18,7 @@ _VARIANT = bool(os.environ.get("GLC_CXXFLAGS") or os.environ.get("GLC_LIB_OUT"))
 _TAG = hashlib.sha1(" ".join(os.environ.get("GLC_CXXFLAGS", "").split()).encode()).hexdigest()[:10]
 OBJ = os.path.join(HERE, "build_variant", _TAG) if _VARIANT else os.path.join(HERE, "build")
 LIB = os.environ.get("GLC_LIB_OUT") or os.path.join(HERE, "libglc_amd.so")
-SOURCES = ["cudpp_api.cpp", "bwt_sa.hip", "bwt_bucket.hip", "mtf.hip", "huffman.hip", "decode.hip", "culzss.hip",
+SOURCES = ["cudpp_api.cpp", "bwt_sa.hip", "bwt_bucket.hip", "bwt_periodic.hip", "mtf.hip", "huffman.hip", "decode.hip", "culzss.hip",
            "culzss_api.cpp", "hd_decode.hip", "probe.hip", "exchange.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"] + os.environ.get("GLC_CXXFLAGS", "").split()
 

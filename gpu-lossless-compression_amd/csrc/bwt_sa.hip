@@ -26,6 +26,7 @@
 // the same word), so a radix pass costs 8 B read (histogram) + 8 B read + 8 B
 // written per live suffix.
 #include "glc_device.h"
+#include <vector>
 #include "glc_internal.h"
 
 namespace glc {
@@ -981,7 +982,7 @@ hipError_t sa_general_reserve(SaScratch &s, bool only_sa)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.ss_long, s.ss_long_count, s.ss_gtile, s.ss_cnt2, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
+    void *ps[] = {s.keyA, s.ss_long, s.ss_long_count, s.ss_gtile, s.ss_cnt2, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.per_info, s.per_list, s.per_ok, s.per_count, s.per_base, s.per_text, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
@@ -1226,6 +1227,48 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
         }
         s.last_general = left;                                 // what the sample sorter (both attempts) gave up on
         s.last_resumed = 0;
+        s.last_periodic = 0;
+        if (left && s.periodic && bwt_out && d_index && n >= 16 * PER_PMAX && s.nmax >= PER_NU) {
+            // Blocks that are ONE periodic stretch (a page repeated, a short pattern, one byte up to a different last one):
+            // every suffix ties with the one a period further on for nearly the whole block -- ~18 doubling rounds over a
+            // million live suffixes.  Their suffix array has a closed form over the sorted rotations of the period and the
+            // few suffixes around the break (bwt_periodic.hip); only those -- a text of <= 5 p + 2 bytes per block -- are
+            // sorted, by the general sorter, whatever the block's size.
+            GLC_TRY(per_reserve(s));
+            GLC_TRY(per_detect(st, text, text_stride, n, nflag, s));
+            GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.per_count, 4, hipMemcpyDeviceToHost, st));
+            GLC_TRY(hipEventRecord(s.ev_flag, st));
+            GLC_TRY(hipEventSynchronize(s.ev_flag));
+            const uint32_t nper = s.h_max_cnt[6];
+            if (nper) {
+                // the longest text of representatives among the taken blocks (they are sorted as one batch of equal length)
+                std::vector<uint4> info(s.rows);
+                std::vector<uint32_t> lst(nper);
+                GLC_TRY(hipMemcpyAsync(info.data(), s.per_info, (size_t)s.rows * sizeof(uint4), hipMemcpyDeviceToHost, st));
+                GLC_TRY(hipMemcpyAsync(lst.data(), s.per_list, (size_t)nper * 4, hipMemcpyDeviceToHost, st));
+                GLC_TRY(hipStreamSynchronize(st));
+                uint32_t nu = 64;
+                for (uint32_t k = 0; k < nper; k++) {
+                    const uint4 in = info[lst[k]];
+                    const uint32_t t = n - in.y, m = t > in.x ? t : in.x, L = in.x * ((m + in.x - 1) / in.x);
+                    const uint32_t need = 2 * L + 2 * in.x + 2 + t + 16;   // (per_text_len, bwt_periodic.hip)
+                    if (need > nu) nu = need;
+                }
+                nu = (nu + 15u) & ~15u;
+                if (nu > PER_NU) nu = PER_NU;
+                GLC_TRY(per_text(st, text, text_stride, n, nper, nu, s));
+                GLC_TRY(sa_build_general(st, s.per_text, PER_NU, nu, nper, s, nullptr, 0, nullptr, nullptr, nullptr, nper));
+                GLC_TRY(per_expand(st, text, text_stride, n, nper, nu, s, bwt_out, bwt_stride, d_index));
+                GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.per_count + 1, 4, hipMemcpyDeviceToHost, st));
+                GLC_TRY(hipEventRecord(s.ev_flag, st));
+                GLC_TRY(hipEventSynchronize(s.ev_flag));
+                const uint32_t done = s.h_max_cnt[6];
+                s.last_periodic = done;
+                left -= done < left ? done : left;
+                s.h_max_cnt[7] = left;                         // the device-side count of blocks still given up on follows
+                GLC_TRY(hipMemcpyAsync(s.fs_nflag + 1, s.h_max_cnt + 7, 4, hipMemcpyHostToDevice, st));
+            }
+        }
         if (left && s.resume_min) {
             // Blocks whose only trouble was a repeat deeper than the cap (zero pages, a duplicated region, long periodic
             // stretches inside otherwise ordinary data): the sample sorter once more, in its TOLERANT form and writing the

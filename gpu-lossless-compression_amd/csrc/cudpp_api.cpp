@@ -598,9 +598,10 @@ CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode)
     if (!p || planHandle == CUDPP_INVALID_HANDLE) return CUDPP_ERROR_INVALID_HANDLE;
     SaScratch *s = sa_of(p);
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
-    if (mode < 0 || mode > 6) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
+    if (mode < 0 || mode > 7) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     s->sorter = mode >= 5 ? 0 : mode;
     s->resume_min = mode == 5 ? 0u : (mode == 6 ? 1u : 4u);
+    s->periodic = mode != 7 && mode != 5;                      // (5: "from scratch" for everything the sample sorter gives up on)
     return CUDPP_SUCCESS;
 }
 
@@ -637,6 +638,16 @@ CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out)
 }
 
 // out[0] = blocks of the plan's last call whose doubling rounds resumed from the sample sorter's tolerant form
+CUDPPResult glcPlanLastSortPeriodic(CUDPPHandle planHandle, unsigned int *out)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    out[0] = s->last_periodic;
+    return CUDPP_SUCCESS;
+}
+
 CUDPPResult glcPlanLastSortResumed(CUDPPHandle planHandle, unsigned int *out)
 {
     PlanBase *p = plan_from<PlanBase>(planHandle);

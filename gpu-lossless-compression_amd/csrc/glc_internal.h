@@ -20,6 +20,9 @@ constexpr uint32_t FS_CAP   = 4096;             // slot size in the word array
 constexpr uint32_t FS_FILLMAX = 4032;            // fullest bucket the in-LDS sort takes (a fuller one flags its block)
 constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^20 (256 buckets of 4096 words: k_fs_sort 1.62 vs 1.3 ms)
 constexpr uint32_t FS_MAXNB_LOG2 = 9;
+// periodic tier (bwt_periodic.hip): blocks that are one periodic stretch with a period of up to PER_PMAX symbols
+constexpr uint32_t PER_PMAX = 4096;
+constexpr uint32_t PER_NU   = 5 * PER_PMAX + 32;     // bytes of the text of representatives: 3 p + 1 | separator | <= 2 p | padding
 constexpr uint32_t FS_LCP_CAP = 512;             // suffix comparisons and the sample sorter's rounds give up behind this many symbols
 #ifndef GLC_SS_TOL_CAP
 #define GLC_SS_TOL_CAP 128
@@ -170,6 +173,14 @@ struct SaScratch {
     uint32_t  last_resumed = 0;                  // ... of which the doubling rounds RESUMED from the sample sorter's tolerant form
     uint32_t *ss_gtile = nullptr;                // [rows][ceil(nmax / 256)] group heads per tile of rows (k_grp_*)
     uint32_t *ss_cnt2 = nullptr;                 // [rows] n for the blocks the resumed doubling works on, else 0
+    // periodic tier: blocks every other tier gave up on that turn out to be ONE periodic stretch (allocated on first use)
+    bool      periodic = true;                   // glcPlanSetSorter 7 switches it off
+    uint4    *per_info = nullptr;                // [rows] {period, first break, exit smaller?, slot}
+    uint32_t *per_list = nullptr, *per_ok = nullptr;   // [rows] taken blocks by slot; whose rows were written
+    uint32_t *per_count = nullptr;               // [4] taken, finished
+    uint32_t *per_base = nullptr;                // [rows][PER_NU + 1] first row of every representative
+    uint8_t  *per_text = nullptr;                // [rows][PER_NU] the texts of representatives
+    uint32_t  last_periodic = 0;                 // blocks of the last sa_build this tier finished
     uint32_t  resume_min = 4;                    // fewest blocks given up on for depth that are worth the tolerant pass (0: never; sorter modes 5 / 6)
     bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
     // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
@@ -213,6 +224,16 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out, uint32_t attempt = 0);
 // blocks of the first attempt whose only trouble was a bucket past its slot -> listed behind ss_list, count in s.fs_nflag[2]
 hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to = 1);
+
+// periodic tier (bwt_periodic.hip); enqueue only.  per_detect lists the taken blocks of s.ss_list[0 .. nlisted) whose ss_flag is
+// raised (count -> s.per_count[0]); per_text writes their texts of representatives (nu bytes each, stride PER_NU); per_expand
+// turns the suffix arrays of those texts (s.sa, rows 0 .. nper) into the blocks' BWT rows and indices, clears ss_flag /
+// fs_lcnt of every block it finishes and counts them in s.per_count[1]
+hipError_t per_reserve(SaScratch &s);
+hipError_t per_detect(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nlisted, SaScratch &s);
+hipError_t per_text(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nper, uint32_t nu, SaScratch &s);
+hipError_t per_expand(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nper, uint32_t nu, SaScratch &s,
+                      uint8_t *bwt_out, size_t bwt_stride, int *d_index);
 
 // copy SA to the cudppSuffixArray layout (out[0]=n, out[1..n]=SA)
 hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *out);

@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanLastSortResumed", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcGenFloatPhilox", "glcPlanKernelProfileLost",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanLastSortResumed", "glcPlanLastSortPeriodic", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcGenFloatPhilox", "glcPlanKernelProfileLost",
     "glcCompressBatchCompact", "glcDecompressBatchCompact",
 ]
 CULZSS_SYMBOLS = [
@@ -106,6 +106,7 @@ def lib():
     L.glcPlanLastSortStatsEx.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanLastSortRetries.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanLastSortResumed.argtypes = [sz, C.POINTER(C.c_uint)]
+    L.glcPlanLastSortPeriodic.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanDebugSortFlags.argtypes = [sz, C.POINTER(C.c_uint), C.POINTER(C.c_uint), sz]
     L.glcPlanDebugBucketFill.argtypes = [sz, sz, C.POINTER(C.c_uint)]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
@@ -300,6 +301,12 @@ class Plan:
         """blocks of the last call whose prefix doubling resumed from the sample sorter's order (deep repeats inside them)"""
         a = (C.c_uint * 1)()
         _chk("glcPlanLastSortResumed", lib().glcPlanLastSortResumed(self.handle, a))
+        return a[0]
+
+    def last_sort_periodic(self):
+        """blocks of the last call finished by the periodic tier (one periodic stretch: closed form over the sorted rotations)"""
+        a = (C.c_uint * 1)()
+        _chk("glcPlanLastSortPeriodic", lib().glcPlanLastSortPeriodic(self.handle, a))
         return a[0]
 
     def enable_timing(self, mode=1):

@@ -255,7 +255,9 @@ CUDPPResult glcHuffmanEncodeBatch(CUDPPHandle planHandle, const unsigned char *d
  * sorter first, for a caller that knows its data is text-like (saves the bucket sorter's wasted attempt); 5: as 0, but
  * a block the sample sorter gives up on for depth always goes to the general sorter from scratch (0: when a call has four
  * or more such blocks, the sample sorter finishes what it can of them and the doubling rounds resume from there); 6: as 0,
- * resuming for a single such block too.  All
+ * resuming for a single such block too; 7: as 0 without the periodic tier (a block the sample sorter gives up on that is ONE
+ * periodic stretch -- a page repeated to the end, a short pattern, one byte up to a different last one -- gets its suffix
+ * array in closed form from the sorted rotations of its period: bwt_periodic.hip; 5 switches that off too).  All
  * produce the same bytes (the suffix array of a block is unique); the knob exists for tests and A/B timing. */
 CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode);
 /* number of blocks of the plan's last call the bucket sorter gave up on (0 for i.i.d.-like data) */
@@ -269,6 +271,8 @@ CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out);
  * prefix doubling RESUMED from its order -- the sample sorter run once more in a form that leaves suffixes agreeing in more
  * than ~512 symbols as they come, doubling from that depth over the rows that still tie -- instead of from scratch */
 CUDPPResult glcPlanLastSortResumed(CUDPPHandle planHandle, unsigned int *out);
+/* out[0] = how many of the blocks the sample sorter gave up on were finished by the periodic tier (see glcPlanSetSorter) */
+CUDPPResult glcPlanLastSortPeriodic(CUDPPHandle planHandle, unsigned int *out);
 /* diagnostics (tests, tools/exp): per-block give-up flags of the last sort (bucket sorter: 1 bucket overflow / text-like, 2 deep,
  * 4 work list full; sample sorter: 1 bucket overflow, 2 deep), numBlocks entries each, either pointer may be NULL; and the
  * 512 bucket fills of one block as the last bucketing pass left them.  Both wait for the plan's stream. */
