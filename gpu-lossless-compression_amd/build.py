@@ -37,12 +37,23 @@ def have_rccl():
     the whole compression path; the exchange entry points are then simply not exported (GLC_NO_RCCL=1 forces that)."""
     if os.environ.get("GLC_NO_RCCL") == "1":
         return False
-    return os.path.exists("/opt/rocm/include/rccl/rccl.h") and any(
-        os.path.exists(os.path.join(d, "librccl.so")) for d in ("/opt/rocm/lib", "/opt/rocm/lib64"))
+    root = rocm_root()
+    return os.path.exists(os.path.join(root, "include", "rccl", "rccl.h")) and any(
+        os.path.exists(os.path.join(root, d, "librccl.so")) for d in ("lib", "lib64"))
+
+
+def rocm_root():
+    """ROCM_PATH, else the prefix of $HIPCC (<root>/bin/hipcc), else /opt/rocm"""
+    if os.environ.get("ROCM_PATH"):
+        return os.environ["ROCM_PATH"]
+    h = os.environ.get("HIPCC")
+    if h and os.path.basename(os.path.dirname(os.path.abspath(h))) == "bin":
+        return os.path.dirname(os.path.dirname(os.path.abspath(h)))
+    return "/opt/rocm"
 
 
 def build(force=False, verbose=False):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hipcc = os.environ.get("HIPCC", os.path.join(rocm_root(), "bin", "hipcc"))
     rccl = have_rccl()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s)) and (rccl or s != "exchange.cpp")]
     os.makedirs(OBJ, exist_ok=True)
@@ -67,7 +78,7 @@ def build(force=False, verbose=False):
                 sys.stderr.write(r.stdout + r.stderr)
                 raise RuntimeError("hipcc failed compiling " + src)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + \
-          [os.path.join(OBJ, s + ".o") for s in srcs] + (["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"] if rccl else [])
+          [os.path.join(OBJ, s + ".o") for s in srcs] + (["-L" + os.path.join(rocm_root(), "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(rocm_root(), "lib")] if rccl else [])
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -206,7 +206,11 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
 {
     for (;;) {
         const uint32_t m = max(a, b) + k;
-        if (W16 && !tol && m + 20 <= n) {                      // (the tolerant form's ties must end where k_ss_sample's do: steps of 8)
+#ifndef GLC_TOL_STEP8
+        if (W16 && m + 20 <= n) {                              // (every tolerant comparison starts at k = 0 or 16: all of them end their ties at k = 144)
+#else
+        if (W16 && !tol && m + 20 <= n) {
+#endif
             const uint64_t va = fs_load_be64(T + a + k), vb = fs_load_be64(T + b + k);
             const uint64_t va2 = fs_load_be64(T + a + k + 8), vb2 = fs_load_be64(T + b + k + 8);
             if (va != vb) return va < vb;
@@ -1349,6 +1353,10 @@ constexpr uint32_t SS_MAXSTEP = FS_LCP_CAP / SS_STEP + 1;      // rounds of a ru
 constexpr uint32_t SS_TOL_MAXSTEP = SS_TOL_CAP / SS_STEP + 1;
 constexpr uint32_t SS_CAPPED = 255;
 static_assert(SS_MAXSTEP + 2 < SS_CAPPED, "the step field of a run descriptor holds the rounds and the marker");
+// the resumed doubling starts at depth SS_TOL_CAP: every place the tolerant form stops at (fs_suffix_less: k > SS_TOL_CAP in steps
+// of 8; the runs: SS_TOL_MAXSTEP rounds of SS_STEP symbols) must lie at or beyond it
+static_assert(SS_TOL_CAP % 8 == 0 && SS_TOL_CAP <= FS_LCP_CAP && SS_TOL_MAXSTEP * SS_STEP >= SS_TOL_CAP,
+              "GLC_SS_TOL_CAP: a multiple of 8, not beyond the give-up cap, reached by the tolerant rounds");
 
 // run descriptor of a position: start : 12 | end : 12 | rounds done : 8   (a decided position: end = start + 1)
 __device__ __forceinline__ uint32_t ss_run(uint32_t ss, uint32_t se, uint32_t st) { return ss | (se << 12) | (st << 24); }
@@ -1964,7 +1972,7 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
 // (want = 2: the blocks whose only trouble was a repeat deeper than the cap -- listed for the tolerant form)
 __global__ void k_ss_retry_list(uint32_t *__restrict__ flag, const uint32_t *__restrict__ list, uint32_t nflag,
                                 uint32_t *__restrict__ list2, uint32_t *__restrict__ count, uint32_t *__restrict__ fill,
-                                uint32_t want)
+                                uint32_t want, uint32_t mutate)
 {
     const uint32_t j = blockIdx.x;
     if (j >= nflag) return;
@@ -1972,6 +1980,7 @@ __global__ void k_ss_retry_list(uint32_t *__restrict__ flag, const uint32_t *__r
     if (flag[b] != want) return;                               // (uniform per workgroup)
     __shared__ uint32_t s_at;
     if (threadIdx.x == 0) s_at = atomicAdd(count, 1u);
+    if (!mutate) return;                                       // (count only: flags and fills stay what the diagnostics report)
     for (uint32_t i = threadIdx.x; i < FS_MAXNB; i += blockDim.x) fill[(size_t)b * FS_MAXNB + i] = 0;
     __syncthreads();
     if (threadIdx.x == 0) { list2[s_at] = b; flag[b] = 0; }
@@ -2074,7 +2083,7 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
     // attempt 0: the blocks k_fs_finish listed in ss_list; attempt 1: the ones k_ss_retry_list listed behind them (a bucket
     // past its slot: other samples); attempt 2: the ones listed behind those (a repeat deeper than the cap), in the TOLERANT
-    // form -- suffixes that agree in more than FS_LCP_CAP + 8 bytes are left in the order of their positions (comparisons)
+    // form -- suffixes that agree in more than SS_TOL_CAP + 8 bytes are left in the order of their positions (comparisons)
     // or as they are (runs), nothing is given up on for depth: the result is the suffixes ordered by their first
     // FS_LCP_CAP symbols, for the prefix-doubling rounds to finish (sa_build_finish)
     const uint32_t *list = s.ss_list + (size_t)attempt * s.rows;
@@ -2117,11 +2126,11 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 
 // lists the blocks of the first attempt (`from` = 0) that deserve another one, behind the list of attempt `to` - 1: to = 1,
 // flag == 1 (a bucket past its slot); to = 2, flag == 2 (a repeat deeper than the cap).  Their number -> s.fs_nflag[2]
-hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to)
+hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to, bool count_only)
 {
     GLC_TRY(hipMemsetAsync(s.fs_nflag + 2, 0, 4, st));
     hipLaunchKernelGGL(k_ss_retry_list, dim3(nflag), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, s.ss_list + (size_t)to * s.rows,
-                       s.fs_nflag + 2, s.fs_fill, to);
+                       s.fs_nflag + 2, s.fs_fill, to, count_only ? 0u : 1u);
     return hipGetLastError();
 }
 

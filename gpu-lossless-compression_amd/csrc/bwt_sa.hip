@@ -1275,7 +1275,9 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
             // suffix array -- everything it can order it orders, suffixes that agree in more than the cap stay as they come
             // -- then prefix doubling from that depth on, over the groups of rows that still share the cap (a few thousand
             // suffixes of such a block for ~11 rounds, where the general sorter from scratch takes a million through ~20).
-            GLC_TRY(ss_retry_prepare(st, nflag, s, 2));
+            // counted first, without touching anything: below resume_min the blocks go on as they are (their flags and fills
+            // stay what glcPlanDebugSortFlags / BucketFill report)
+            GLC_TRY(ss_retry_prepare(st, nflag, s, 2, true));
             GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.fs_nflag + 2, 4, hipMemcpyDeviceToHost, st));
             GLC_TRY(hipEventRecord(s.ev_flag, st));
             GLC_TRY(hipEventSynchronize(s.ev_flag));
@@ -1283,6 +1285,7 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
             // (a few blocks: the extra pass and its launches cost what the shorter doubling saves -- 2.6 against 2.2-2.7 ms for
             //  one block, 3.5 against 4.4 for eight)
             if (deep2 >= s.resume_min) {
+                GLC_TRY(ss_retry_prepare(st, nflag, s, 2));    // listed, flags and fills cleared for the tolerant pass
                 GLC_TRY(sa_general_reserve(s, false));
                 s.h_max_cnt[7] = left - deep2;                 // the others stay given up on; this attempt adds its own
                 GLC_TRY(hipMemcpyAsync(s.fs_nflag + 1, s.h_max_cnt + 7, 4, hipMemcpyHostToDevice, st));

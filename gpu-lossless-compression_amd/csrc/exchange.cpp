@@ -182,8 +182,12 @@ CUDPPResult glcGatherCountsBegin(glcComm_t c, unsigned long long numBlocks, unsi
 {
     if (!c) return CUDPP_ERROR_INVALID_HANDLE;
     if (!ticket) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
-    const unsigned slot = c->next % GLC_COUNT_SLOTS;
-    if (c->busy[slot]) return CUDPP_ERROR_INSUFFICIENT_RESOURCES;      // GLC_COUNT_SLOTS exchanges begun and not ended
+    // any free slot (tickets may be ended out of order: the ticket names the slot).  All ranks begin and end their
+    // exchanges in the same order, so they fail here together or not at all.
+    unsigned slot = GLC_COUNT_SLOTS;
+    for (unsigned k = 0; k < GLC_COUNT_SLOTS && slot == GLC_COUNT_SLOTS; k++)
+        if (!c->busy[(c->next + k) % GLC_COUNT_SLOTS]) slot = (c->next + k) % GLC_COUNT_SLOTS;
+    if (slot == GLC_COUNT_SLOTS) return CUDPP_ERROR_INSUFFICIENT_RESOURCES;   // GLC_COUNT_SLOTS exchanges begun and not ended
     hipStream_t st = (hipStream_t)hipStream;
     unsigned long long *d = c->d_counts + slot * c->slot_words();
     hipLaunchKernelGGL(k_set_counts, dim3(1), dim3(1), 0, st, d, numBlocks, numWords, d_numWords);
@@ -212,9 +216,9 @@ CUDPPResult glcGatherCountsEnd(glcComm_t c, int ticket, unsigned long long *h_co
 {
     if (!c) return CUDPP_ERROR_INVALID_HANDLE;
     if (ticket < 0 || ticket >= GLC_COUNT_SLOTS || !c->busy[ticket] || !h_counts) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
-    c->busy[ticket] = false;
     GLC_HIP(hipEventSynchronize(c->done[ticket]));                   // waits for THIS exchange only, not for the stream
     memcpy(h_counts, c->h_counts + (size_t)ticket * 2 * (size_t)c->nranks, sizeof(unsigned long long) * 2 * (size_t)c->nranks);
+    c->busy[ticket] = false;                                         // (only now: the slot's buffers are read out)
     return CUDPP_SUCCESS;
 }
 

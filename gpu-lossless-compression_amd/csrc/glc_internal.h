@@ -223,7 +223,8 @@ uint32_t   fs_bucket_log2(uint32_t n);
 hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nflag, SaScratch &s,
                     uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *sa_out, uint32_t attempt = 0);
 // blocks of the first attempt whose only trouble was a bucket past its slot -> listed behind ss_list, count in s.fs_nflag[2]
-hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to = 1);
+// (count_only: nothing is listed or cleared -- how many there are decides whether the attempt is worth making)
+hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to = 1, bool count_only = false);
 
 // periodic tier (bwt_periodic.hip); enqueue only.  per_detect lists the taken blocks of s.ss_list[0 .. nlisted) whose ss_flag is
 // raised (count -> s.per_count[0]); per_text writes their texts of representatives (nu bytes each, stride PER_NU); per_expand

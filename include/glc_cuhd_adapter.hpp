@@ -44,7 +44,11 @@ class DecoderMemory {
         const std::size_t need = glcHdWorkBytes(units);
         if (need > bytes_) {
             if (ptr_) {
-                if (hipStreamSynchronize(stream) != hipSuccess) throw std::runtime_error("glc::cuhd::DecoderMemory: hipStreamSynchronize failed");
+                // a stream handle that has been destroyed since (the per-stream cache below keeps its buffer): nothing of it can
+                // still be running, so the buffer is free to go
+                const hipError_t e = hipStreamSynchronize(stream);
+                if (e == hipErrorInvalidHandle || e == hipErrorContextIsDestroyed || e == hipErrorInvalidResourceHandle) (void)hipGetLastError();
+                else if (e != hipSuccess) throw std::runtime_error("glc::cuhd::DecoderMemory: hipStreamSynchronize failed");
                 (void)hipFree(ptr_);
             }
             ptr_ = nullptr; bytes_ = 0;
@@ -73,13 +77,33 @@ class CUHDGPUDecoder {
             if (aux) w = aux->reserve(input_size, stream);     // the caller's decoder memory, as in the reference
         }
         if (!w) {
-            static thread_local std::unordered_map<hipStream_t, DecoderMemory> work;   // one per (thread, stream)
+            // one per (thread, stream); bounded: a caller that keeps creating streams gets the cache emptied at 16 entries
+            // (every buffer is released behind a wait for its stream) instead of one work buffer per handle ever seen.
+            // release_work_buffers() empties it on request.
+            auto &work = cache();
+            if (work.size() >= 16 && work.find(stream) == work.end()) release_work_buffers();
             w = work[stream].reserve(input_size, stream);
         }
         const int ok = glcHdDecodeDeviceTableOnDevice(reinterpret_cast<const unsigned int *>(input->get()), input_size,
                                                       reinterpret_cast<const unsigned char *>(table->get()),
                                                       reinterpret_cast<unsigned char *>(output->get()), output_size, w, stream);
         if (!ok) throw std::runtime_error("glc::cuhd::CUHDGPUDecoder::decode: glcHdDecodeDeviceTableOnDevice failed");
+    }
+    // frees the calling thread's cached work buffers (each behind a wait for the stream it was used on)
+    static void release_work_buffers()
+    {
+        auto &work = cache();
+        for (auto &kv : work) {
+            const hipError_t e = hipStreamSynchronize(kv.first);
+            if (e != hipSuccess) (void)hipGetLastError();      // (a destroyed stream: nothing of it is running)
+        }
+        work.clear();
+    }
+  private:
+    static std::unordered_map<hipStream_t, DecoderMemory> &cache()
+    {
+        static thread_local std::unordered_map<hipStream_t, DecoderMemory> work;
+        return work;
     }
 };
 
