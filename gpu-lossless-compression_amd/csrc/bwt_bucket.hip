@@ -445,6 +445,10 @@ constexpr int FSP2_T = GLC_FSP2_T;
 #ifndef GLC_FSP2_NT
 #define GLC_FSP2_NT 512
 #endif
+#ifndef GLC_FSP2_TILE
+#define GLC_FSP2_TILE 4096
+#endif
+constexpr int FSP2_TILE = GLC_FSP2_TILE;                       // suffixes per tile of k_fs_part2
 constexpr int FSP2_NT = GLC_FSP2_NT;                           // threads per workgroup; a thread takes 4096 / FSP2_NT consecutive suffixes
 
 __device__ __forceinline__ void lds_only_barrier()
@@ -458,11 +462,12 @@ template <int NT, int ITEMS, int WPE>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_fs_part2(const uint8_t *__restrict__ text, size_t stride, uint32_t n, uint32_t nbl,
                                                      const uint2 *__restrict__ tab, uint64_t *__restrict__ keys, size_t kstride,
                                                      uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
-                                                     uint32_t *__restrict__ zero_bucket)
+                                                     uint32_t *__restrict__ zero_bucket, uint32_t tiles_per_wg)
 {
+    constexpr uint32_t TILE = NT * ITEMS;                      // suffixes per tile
     __shared__ uint32_t s_cnt[FS_MAXNB];
     __shared__ uint16_t s_start[FS_MAXNB], s_gbase[FS_MAXNB];
-    __shared__ uint64_t s_w[FSP_TILE];
+    __shared__ uint64_t s_w[NT * ITEMS];
     __shared__ uint2 s_tab[256];
     __shared__ uint32_t s_tmp[NT / 64 + 1];
     __shared__ uint32_t s_flagged;
@@ -470,45 +475,44 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
     uint32_t bx, by;
     xcd_order(bx, by);                                         // a block's tiles on ONE XCD, back to back
     const uint32_t b = by, tid = threadIdx.x;
-    const uint32_t ntiles = (n + FSP_TILE - 1) / FSP_TILE, tile0 = bx * FSP2_T;
+    const uint32_t ntiles = (n + TILE - 1) / TILE, tile0 = bx * tiles_per_wg;
     if (tile0 >= ntiles) return;
     const uint8_t *T = text + (size_t)b * stride;
     if (tid == 0) s_flagged = flag[b];                         // flagged up front as text-like, or by a tile that ran before
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
     // text of a tile as the dwords of T[base - 1 ...] (unaligned 4-byte loads: global memory takes any alignment): dword
     // q = r NT + tid of the 4112 staged bytes.  Only for inner tiles; the first and the last tile of a block take the byte loop.
-    static_assert(NT * ITEMS == FSP_TILE, "a tile is 4096 suffixes");
-    constexpr int NSTG = ((FSP_TILE + 16) / 4 + NT - 1) / NT;      // staged dwords per thread
+    constexpr int NSTG = ((TILE + 16) / 4 + NT - 1) / NT;      // staged dwords per thread
     uint32_t stg[NSTG] = {};
-    auto inner = [&](uint32_t tile) { const uint32_t base = tile * FSP_TILE; return base > 0 && base + FSP_TILE + 16 <= n; };
+    auto inner = [&](uint32_t tile) { const uint32_t base = tile * TILE; return base > 0 && base + TILE + 16 <= n; };
     auto request = [&](uint32_t tile) {
-        const uint8_t *D = T + (size_t)tile * FSP_TILE - 1;
+        const uint8_t *D = T + (size_t)tile * TILE - 1;
 #pragma unroll
         for (int r = 0; r < NSTG; r++) {
             const uint32_t q = r * NT + tid;
-            const uint32_t qq = q < (FSP_TILE + 16) / 4 ? q : 0u;   // (every load is issued: a conditional one may sink to its use)
+            const uint32_t qq = q < (TILE + 16) / 4 ? q : 0u;   // (every load is issued: a conditional one may sink to its use)
             uint32_t v;
             __builtin_memcpy(&v, D + 4 * (size_t)qq, 4);
             stg[r] = v;
         }
     };
-    const uint32_t tend = min(ntiles, tile0 + FSP2_T);
+    const uint32_t tend = min(ntiles, tile0 + tiles_per_wg);
     bool have = false;                                         // stg holds the text of the tile about to be processed
     if (inner(tile0)) { request(tile0); have = true; }
     uint64_t *K = keys + (size_t)b * kstride;
 #pragma clang loop unroll(disable)
     for (uint32_t tile = tile0; tile < tend; tile++) {
-        const uint32_t base = tile * FSP_TILE;
-        const bool edge = base + FSP_TILE + 16 > n;
+        const uint32_t base = tile * TILE;
+        const bool edge = base + TILE + 16 > n;
         if (tid < FS_MAXNB) s_cnt[tid] = 0;
         if (have) {
 #pragma unroll
             for (int r = 0; r < NSTG; r++) {
                 const uint32_t q = r * NT + tid;
-                if (q < (FSP_TILE + 16) / 4) reinterpret_cast<uint32_t *>(s_txt)[q] = stg[r];
+                if (q < (TILE + 16) / 4) reinterpret_cast<uint32_t *>(s_txt)[q] = stg[r];
             }
         } else {
-            for (uint32_t k = tid; k < FSP_TILE + 16; k += NT) {
+            for (uint32_t k = tid; k < TILE + 16; k += NT) {
                 const int64_t g = (int64_t)base - 1 + k;
                 s_txt[k] = g < 0 ? T[n - 1] : (g < (int64_t)n ? T[g] : (uint8_t)0);
             }
@@ -546,11 +550,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             uint32_t y = e[j + 5].x;
 #pragma unroll
             for (int d = 4; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
+#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & 4)                  // timing experiment: no codes
+            const uint64_t X = (uint64_t)((gi0 + j) * 2654435761u) << 32 | by4[0];
+#else
             const uint64_t X = ((uint64_t)e[j].x << 32) + (uint64_t)e[j].y * y;
+#endif
             const uint32_t gi = gi0 + j;
             w[j] = (X & ~FS_LOW_MASK) | ((uint64_t)gi << 8) | FS_BYTE(j);
             const uint32_t bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
+#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & 1)                  // timing experiment: no rank atomic in LDS
+            br[j] = (bk << 16) | ((tid + j) & 7u);
+#else
             br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
+#endif
             if (j == 0 && gi == 0) zero_bucket[b] = bk;        // where the word of suffix 0 goes: k_fs_sort_bwt looks for the BWT index there only
         }
 #undef FS_BYTE
@@ -567,9 +579,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             if (tid < FS_MAXNB) s_start[tid] = (uint16_t)start;
         }
         lds_only_barrier();                                    // (the staged text and the table reads are done: s_w takes the words)
+#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & (2 | 8))            // timing experiment: no scatter (2: and no read back below; 16: only no read back)
+        if (w[0] == 0x1234567ull) s_w[tid] = w[1] ^ w[2] ^ w[3] ^ w[ITEMS - 1] ^ br[0] ^ br[1] ^ br[2] ^ br[3] ^ br[ITEMS - 1];
+#else
 #pragma unroll
         for (int j = 0; j < ITEMS; j++)
+#ifdef GLC_EXP_PART2
+            if (gi0 + j < n) s_w[((uint32_t)s_start[br[j] >> 16] + (br[j] & 0xFFFFu)) & (TILE - 1)] = w[j];
+#else
             if (gi0 + j < n) s_w[s_start[br[j] >> 16] + (br[j] & 0xFFFFu)] = w[j];
+#endif
+#endif
         if (c && g + c > FS_FILLMAX) { atomicOr(&flag[b], 1u); s_flagged = 1; }
         if (tid < FS_MAXNB) s_gbase[tid] = (uint16_t)(g < FS_CAP ? g : FS_CAP);
         if (next_inner) {                                      // the next tile's text has arrived before this tile's stores are issued
@@ -578,11 +598,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         }
         have = next_inner;
         lds_only_barrier();
-        const uint32_t tile_n = min((uint32_t)FSP_TILE, n - base);
+        const uint32_t tile_n = min((uint32_t)TILE, n - base);
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
             const uint32_t p = r * NT + tid;
+#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & (2 | 16))
+            if (p == 0xFFFFFFFFu) {
+#else
             if (p < tile_n) {
+#endif
                 const uint64_t ww = s_w[p];
                 const uint32_t d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
                 const uint32_t off = (uint32_t)s_gbase[d] + (p - (uint32_t)s_start[d]);
@@ -2039,11 +2063,21 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         const double u = (double)n * nbk;
         pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
         static const bool old_part = getenv("GLC_FS_PART_OLD") != nullptr;      // A/B: one tile per workgroup
-        if (!old_part)
-            hipLaunchKernelGGL((k_fs_part2<FSP2_NT, FSP_TILE / FSP2_NT, GLC_FSP2_WAVES>), dim3(((n + FSP_TILE - 1) / FSP_TILE + FSP2_T - 1) / FSP2_T, nbk), dim3(FSP2_NT), 0, st,
+        if (!old_part) {
+            // tiles per workgroup: 8 for batches, 4 for a few blocks (more workgroups for a block on its own).  Round 5, bench.py
+            // `value` on one box, 1024-block batches, stage overlap on: 4 / 8 / 12 / 16 / 24 / 32 / 64 tiles -> 93.1 / 95.1 / 94.7 /
+            // 95.1 / 95.6 / 93.8 / 87-94 GB/s (16 and 24 fall into two modes from run to run: 94.3-96.5); the kernel itself 3.0 ->
+            // 2.9 ms per GiB.  Tiles of 8192 suffixes (1024 threads x 8, 64 KB of LDS, one workgroup per CU: runs of ~128 bytes, half
+            // the global atomics) run 2.7 ms -- and give the same `value` as 4 tiles of 4096: a 1024-thread workgroup needs half a CU
+            // free AT ONCE, which the MTF and Huffman kernels of the batch before, sharing the chip under stage overlap, rarely leave.
+            static const int per_env = getenv("GLC_FSP2_PER") ? atoi(getenv("GLC_FSP2_PER")) : 0;    // A/B: tiles per workgroup
+            const uint32_t tiles = (n + FSP2_TILE - 1) / FSP2_TILE;
+            const uint32_t per = per_env > 0 ? (uint32_t)per_env : (nbk >= 16 ? 2 * FSP2_T : FSP2_T);
+            hipLaunchKernelGGL((k_fs_part2<FSP2_NT, FSP2_TILE / FSP2_NT, GLC_FSP2_WAVES>), dim3((tiles + per - 1) / per, nbk), dim3(FSP2_NT), 0, st,
                                text + (size_t)b0 * text_stride, text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256,
                                s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
-                               s.fs_zero + b0);
+                               s.fs_zero + b0, per);
+        }
         else
         hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nbk), dim3(FSP_NT), 0, st, text + (size_t)b0 * text_stride,
                            text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256, s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride,
