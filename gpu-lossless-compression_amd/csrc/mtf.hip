@@ -242,7 +242,13 @@ __global__ __launch_bounds__(MSC_WAVES * 64) void k_mtf_scan_lists(uint8_t *__re
 //     per batch; the kernel runs at >90 % of both the VALU issue rate and the LDS
 //     instruction rate, so every instruction of either kind shows.)
 constexpr int MTF_ROWS = 4;                                 // chunks per wave (one per 16-lane DPP row)
-constexpr int MTF_NWORDS = 80;                              // bitmap words per chunk: 68 used, 5 per lane of the row
+// The killed-timestamp bitmap covers ONE SEGMENT of MTF_SEG positions (+ the 256 virtual timestamps of the list the segment
+// starts from): 1280 bits = 20 words, two per lane of the row.  At a segment's end the live timestamps -- one per symbol -- are
+// RE-BASED: a symbol's timestamp becomes the number of live timestamps below it (its place from the back of the MTF list), the
+// bitmap starts empty again.  (Until round 5 the bitmap covered the whole chunk, 4352 bits, five words per lane: its per-batch
+// recount was the largest single piece of the kernel, 0.65 of 3.48 ms per GiB with the recount simply left out.)
+constexpr int MTF_NWORDS = 32;                              // bitmap words per row: 20 used, 2 per lane
+constexpr uint32_t MTF_SEG = 1024;                          // positions per segment
 #ifndef GLC_MTF_QUARTERS_MAX
 #define GLC_MTF_QUARTERS_MAX 2048
 #endif
@@ -266,10 +272,11 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
     // bitmap words, do not meet in the same LDS banks
     __shared__ uint32_t s_hist[WITH_HIST ? MTF_WAVES * MTF_ROWS : 1][128 + 8];   // 16-bit counters: rank r in word r & 127, half r >> 7
     __shared__ uint32_t s_tab[MTF_WAVES * MTF_ROWS][256 + 8];                    // per symbol: last occurrence + 256 << 16 | lanes of the batch holding it
-    __shared__ unsigned long long s_bm[MTF_WAVES * MTF_ROWS][MTF_NWORDS + 4];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bm[MTF_WAVES * MTF_ROWS][MTF_NWORDS + 2];
     // prefix counts of bitmap word 5 q + k at entry 8 q + k: a lane's five counts are one aligned 16-byte store (packed
     // ten bytes apart they were an unaligned 8-byte store, which alone cost a quarter of the kernel)
-    __shared__ __attribute__((aligned(16))) uint16_t s_cum[MTF_WAVES * MTF_ROWS][16 * 8 + 16];
+    // prefix counts: entry w = killed timestamps in the words below word w (a lane's two entries are one dword store)
+    __shared__ __attribute__((aligned(16))) uint16_t s_cum[MTF_WAVES * MTF_ROWS][MTF_NWORDS + 8];
     // QUARTERS: start lists of the four quarters, and the scratch of the recency list + fold that make them
     __shared__ __attribute__((aligned(16))) uint8_t s_qstart[QUARTERS ? MTF_WAVES : 1][MTF_ROWS][256];
     __shared__ __attribute__((aligned(16))) uint8_t s_qlist[QUARTERS ? MTF_WAVES : 1][256], s_qinp[QUARTERS ? MTF_WAVES : 1][MTF_INP];
@@ -363,96 +370,113 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
         const uint32_t q[4] = {lw.x, lw.y, lw.z, lw.w};
 #pragma unroll
         for (int j = 0; j < 16; j++) tab[(q[j >> 2] >> (8 * (j & 3))) & 0xFF] = (255u - (16 * lr + j)) << 16;   // time -1-q, biased by 256
-#pragma unroll
-        for (int k = 0; k < 5; k++) { bm[5 * lr + k] = 0; cum[8 * lr + k] = 0; }
+        bm[2 * lr] = 0; bm[2 * lr + 1] = 0;
+        reinterpret_cast<uint32_t *>(cum)[lr] = 0;
         if (WITH_HIST) for (int i = lr; i < 128; i += 16) s_hist[slot][i] = 0;
         __builtin_amdgcn_wave_barrier();
     }
     const uint32_t mybit = 1u << lr, below = mybit - 1u;
     uint32_t sym_next = src[lr < C ? lr : 0u];
-    for (uint32_t base = 0; base < Cmax; base += 16) {
-        const uint32_t i = base + lr;
-        const bool valid = i < C;
-        const uint32_t sym = sym_next;
-        sym_next = src[i + 16 < C ? i + 16 : 0u];                                // in flight during this batch
-        // lanes of this row holding the same symbol: every lane ORs its bit into the symbol's entry, then reads it
-        // back (LDS operations of a wave execute in order; OR is commutative, so no lane order is relied on)
-        if (valid) atomicOr(&tab[sym], mybit);
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t e = tab[sym];
-        const uint32_t before = e & below;
-        const bool hasprev = before != 0;
-        const uint32_t p = 31u - (uint32_t)__builtin_clz(before | 1u);           // previous lane of the row with my symbol
-        const bool last_in_batch = ((e & 0xFFFFu) >> lr) == 1u;
-        // biased timestamp of the previous occurrence: Pb = P + 257 > 0
-        const uint32_t Pb = hasprev ? base + p + 257u : (e >> 16) + 1u;
-        // T = #{k < lr : P[k] < P[lr]}: lane lr meets P[lr-1], ... P[0] through DPP row_shr:1..15; each step is
-        // (shifted P) - P with the borrow added up, and the 15 - lr steps that have no source lane read 0 < Pb
-        uint32_t G = 0, t0;
+    // seg0 = first position of the current segment (QUARTERS: a row is one segment long)
+    for (uint32_t seg0 = 0; seg0 < Cmax; seg0 += MTF_SEG) {
+        if (seg0) {
+            // ---- re-base: the live timestamp of symbol c, t, becomes (live timestamps below t) = t - (killed below t) ----
+            // (every lane takes 16 symbols of its row's table; the prefix counts are those of the segment's last batch)
+#pragma unroll 4
+            for (int k = 0; k < 16; k++) {
+                const uint32_t c = 16u * (uint32_t)k + lr;         // (lane-consecutive symbols: consecutive banks)
+                const uint32_t t = tab[c] >> 16, wd = t >> 6;
+                const uint32_t kb = cum[wd] + (uint32_t)__popcll(bm[wd] << (63u - (t & 63u)));   // (bit t itself is live: not set)
+                tab[c] = (t - kb) << 16;
+            }
+            __builtin_amdgcn_wave_barrier();
+            bm[2 * lr] = 0; bm[2 * lr + 1] = 0;
+            reinterpret_cast<uint32_t *>(cum)[lr] = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t seg_end = min(Cmax, seg0 + MTF_SEG);
+        for (uint32_t base = seg0; base < seg_end; base += 16) {
+            const uint32_t i = base + lr, lb = base - seg0;          // lb: the batch's first position inside the segment
+            const bool valid = i < C;
+            const uint32_t sym = sym_next;
+            sym_next = src[i + 16 < C ? i + 16 : 0u];                // in flight during this batch
+            // lanes of this row holding the same symbol: every lane ORs its bit into the symbol's entry, then reads it
+            // back (LDS operations of a wave execute in order; OR is commutative, so no lane order is relied on)
+            if (valid) atomicOr(&tab[sym], mybit);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t e = tab[sym];
+            const uint32_t before = e & below;
+            const bool hasprev = before != 0;
+            const uint32_t p = 31u - (uint32_t)__builtin_clz(before | 1u);   // previous lane of the row with my symbol
+            const bool last_in_batch = ((e & 0xFFFFu) >> lr) == 1u;
+            // biased timestamp of the previous occurrence: Pb = (bit index in the segment's bitmap) + 1 > 0
+            const uint32_t Pb = hasprev ? lb + p + 257u : (e >> 16) + 1u;
+            // T = #{k < lr : P[k] < P[lr]}: lane lr meets P[lr-1], ... P[0] through DPP row_shr:1..15; each step is
+            // (shifted P) - P with the borrow added up, and the 15 - lr steps that have no source lane read 0 < Pb
+            uint32_t G = 0, t0;
 #define GLC_SLIDE(K)                                                                                                \
-        "v_sub_co_u32_dpp %1, vcc, %2, %2 row_shr:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
-        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+            "v_sub_co_u32_dpp %1, vcc, %2, %2 row_shr:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
+            "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
 #if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 2                       // timing experiment: no in-batch count
-        t0 = Pb; G = t0 & 7u;
+            t0 = Pb; G = t0 & 7u;
 #else
-        asm volatile(GLC_SLIDE(1) GLC_SLIDE(2) GLC_SLIDE(3) GLC_SLIDE(4) GLC_SLIDE(5) GLC_SLIDE(6) GLC_SLIDE(7) GLC_SLIDE(8)
-                     GLC_SLIDE(9) GLC_SLIDE(10) GLC_SLIDE(11) GLC_SLIDE(12) GLC_SLIDE(13) GLC_SLIDE(14) GLC_SLIDE(15)
-                     : "+v"(G), "=&v"(t0) : "v"(Pb) : "vcc");
+            asm volatile(GLC_SLIDE(1) GLC_SLIDE(2) GLC_SLIDE(3) GLC_SLIDE(4) GLC_SLIDE(5) GLC_SLIDE(6) GLC_SLIDE(7) GLC_SLIDE(8)
+                         GLC_SLIDE(9) GLC_SLIDE(10) GLC_SLIDE(11) GLC_SLIDE(12) GLC_SLIDE(13) GLC_SLIDE(14) GLC_SLIDE(15)
+                         : "+v"(G), "=&v"(t0) : "v"(Pb) : "vcc");
 #endif
 #undef GLC_SLIDE
-        const uint32_t T = G + lr - 15u;
-        const uint32_t bitx = Pb - 1u;                                           // P + 256: index into the killed-timestamp bitmap
-        uint32_t o;
+            const uint32_t T = G + lr - 15u;
+            const uint32_t bitx = Pb - 1u;                           // index into the killed-timestamp bitmap
+            uint32_t o;
 #if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 4                       // timing experiment: no look at the bitmap
-        if (true) o = T - (p + 1u);
+            if (true) o = T - (p + 1u);
 #else
-        if (hasprev) o = T - (p + 1u);
+            if (hasprev) o = T - (p + 1u);
 #endif
-        else {
-            // killed timestamps below bit r of word wd: bit r itself (the timestamp of MY previous occurrence) is still alive
-            // -- this position kills it further down -- so "bits 0 .. r" counts the same and is one shift (the mask
-            // (1 << r) - 1 is a 64-bit shift, a 64-bit subtraction and two ANDs); wd / 5 for wd < 70 with a 24-bit multiply
-            // (a full 32-bit v_mul_lo_u32 issues at a quarter of the rate)
-            const uint32_t wd = bitx >> 6, r = bitx & 63;
-            const uint32_t kb = cum[wd + 3u * (__umul24(wd, 205u) >> 10)] + (uint32_t)__popcll(bm[wd] << (63u - r));
-            o = T + kb + 255u - bitx;                 // T + kb - (P + 1): virtual P adds the -1-P start-list symbols ahead of x
-        }
-        __builtin_amdgcn_wave_barrier();
-        {   // timestamps of this batch killed inside the batch = the lanes that are not the last of their symbol: one
-            // 16-bit store per row (nothing else can have touched that field yet) instead of same-word atomics
-            const uint64_t nl = __ballot(valid && !last_in_batch);
-            const uint32_t half = (row & 2) ? (uint32_t)(nl >> 32) : (uint32_t)nl;
-            if (lr == 0) reinterpret_cast<uint16_t *>(bm)[(base + 256u) >> 4] = (uint16_t)(half >> (16 * (row & 1)));
-        }
-        if (valid) {
+            else {
+                // killed timestamps below bit r of word wd: bit r itself (the timestamp of MY previous occurrence) is still
+                // alive -- this position kills it further down -- so "bits 0 .. r" counts the same and is one shift
+                const uint32_t wd = bitx >> 6, r = bitx & 63;
+                const uint32_t kb = cum[wd] + (uint32_t)__popcll(bm[wd] << (63u - r));
+                o = T + kb + 255u - bitx;             // T + kb - (P + 1): the virtual timestamps add the 256 list entries
+            }
+            __builtin_amdgcn_wave_barrier();
+            {   // timestamps of this batch killed inside the batch = the lanes that are not the last of their symbol: one
+                // 16-bit store per row (nothing else can have touched that field yet) instead of same-word atomics
+                const uint64_t nl = __ballot(valid && !last_in_batch);
+                const uint32_t half = (row & 2) ? (uint32_t)(nl >> 32) : (uint32_t)nl;
+                if (lr == 0) reinterpret_cast<uint16_t *>(bm)[(lb + 256u) >> 4] = (uint16_t)(half >> (16 * (row & 1)));
+            }
+            if (valid) {
 #if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 3                       // timing experiment: (nearly) no output
-            if (o == 0x12345u)
+                if (o == 0x12345u)
 #endif
-            dst[i] = (uint8_t)o;
-            if (WITH_HIST) atomicAdd(&s_hist[slot][o & 127], 1u << ((o >> 3) & 16));
+                dst[i] = (uint8_t)o;
+                if (WITH_HIST) atomicAdd(&s_hist[slot][o & 127], 1u << ((o >> 3) & 16));
 #if !(defined(GLC_EXP_MTF) && GLC_EXP_MTF == 5)                    // (timing experiment 5: nothing is killed)
-            if (!hasprev) atomicOr(&bm[bitx >> 6], 1ull << (bitx & 63));                       // timestamp P is killed by i
+                if (!hasprev) atomicOr(&bm[bitx >> 6], 1ull << (bitx & 63));                   // timestamp P is killed by i
 #endif
-            if (last_in_batch) tab[sym] = (i + 256u) << 16;                      // new last occurrence, lane bits cleared
-        }
-        __builtin_amdgcn_wave_barrier();
-        // prefix counts of the killed-timestamp bitmap: 5 words per lane, scan across the row
+                if (last_in_batch) tab[sym] = (lb + lr + 256u) << 16;        // new last occurrence, lane bits cleared
+            }
+            __builtin_amdgcn_wave_barrier();
+            // prefix counts of the killed-timestamp bitmap: 2 words per lane, scan across the row
 #if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 1                       // timing experiment: no recount
-        if (base == 0xFFFFFFF0u)
+            if (base == 0xFFFFFFF0u)
 #endif
-        {
-            uint32_t c[5], s = 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++) { c[k] = (uint32_t)__popcll(bm[5 * lr + k]); s += c[k]; }
-            uint32_t inc = s;
-            inc += GLC_DPP(inc, 0x111, 0xf);
-            inc += GLC_DPP(inc, 0x112, 0xf);
-            inc += GLC_DPP(inc, 0x114, 0xf);
-            inc += GLC_DPP(inc, 0x118, 0xf);
-            const uint32_t r0 = inc - s, r1 = r0 + c[0], r2 = r1 + c[1], r3 = r2 + c[2], r4 = r3 + c[3];
-            *reinterpret_cast<uint4 *>(cum + 8 * lr) = make_uint4(r0 | (r1 << 16), r2 | (r3 << 16), r4, 0u);
+            {
+                const uint4 v = *reinterpret_cast<const uint4 *>(bm + 2 * lr);
+                const uint32_t c0 = (uint32_t)__builtin_popcount(v.x) + (uint32_t)__builtin_popcount(v.y);
+                const uint32_t sum = c0 + (uint32_t)__builtin_popcount(v.z) + (uint32_t)__builtin_popcount(v.w);
+                uint32_t inc = sum;
+                inc += GLC_DPP(inc, 0x111, 0xf);
+                inc += GLC_DPP(inc, 0x112, 0xf);
+                inc += GLC_DPP(inc, 0x114, 0xf);
+                inc += GLC_DPP(inc, 0x118, 0xf);
+                const uint32_t r0 = inc - sum;
+                reinterpret_cast<uint32_t *>(cum)[lr] = r0 | ((r0 + c0) << 16);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
     if (WITH_HIST && QUARTERS) {
         __builtin_amdgcn_wave_barrier();
