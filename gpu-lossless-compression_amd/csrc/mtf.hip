@@ -454,7 +454,9 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
                 dst[i] = (uint8_t)o;
                 if (WITH_HIST) atomicAdd(&s_hist[slot][o & 127], 1u << ((o >> 3) & 16));
 #if !(defined(GLC_EXP_MTF) && GLC_EXP_MTF == 5)                    // (timing experiment 5: nothing is killed)
-                if (!hasprev) atomicOr(&bm[bitx >> 6], 1ull << (bitx & 63));                   // timestamp P is killed by i
+                // timestamp P is killed by i: a DWORD atomic (a 64-bit ds_or with its 64-bit shift: 2.72 -> 2.54 ms per GiB without it;
+                // prefix counts per dword instead of per 64-bit word, measured too, were slower: 2.66)
+                if (!hasprev) atomicOr(&reinterpret_cast<uint32_t *>(bm)[bitx >> 5], 1u << (bitx & 31));
 #endif
                 if (last_in_batch) tab[sym] = (lb + lr + 256u) << 16;        // new last occurrence, lane bits cleared
             }
