@@ -80,21 +80,37 @@ __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ 
                                                    uint2 *__restrict__ tab, const uint32_t *__restrict__ dup,
                                                    uint32_t *__restrict__ flag, const uint8_t *__restrict__ text, size_t stride,
                                                    uint8_t *__restrict__ bwt_out, size_t bwt_stride, int *__restrict__ d_index,
-                                                   uint32_t *__restrict__ sa_out, size_t sa_stride)
+                                                   uint32_t *__restrict__ sa_out, size_t sa_stride, uint32_t step)
 {
     __shared__ uint32_t s_tmp[5];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t h = hist[(size_t)b * 256 + tid];
+    const uint32_t hraw = hist[(size_t)b * 256 + tid];
+    // step > 1: the counts are those of every step-th 32 KB slice of the block (k_fs_hist).  The code is monotone whatever the
+    // table is as long as C[s] + p[s] <= C[s + 1] holds for every symbol THAT OCCURS; a SAMPLE'S statistics cut the block into
+    // buckets as evenly as the block's own, within the sampling noise.  Every symbol gets one count on top of the sample's
+    // (0.1 % of the code space): a symbol the sample missed keeps a positive width and its place in the order -- with width 0
+    // the symbols above the sample's last one would sit at C = 2^32, clamped BELOW the end of that last symbol's interval
+    // (fuzz seed 2: a block whose sampled slices held two symbols, 79 196 bytes of 254 others in between).
+    const uint32_t h = hraw + (step > 1 ? 1u : 0u);
+    uint32_t ns = 0;
+    const uint32_t c = block_excl_add<256>(h, s_tmp, &ns);
     // A block of ONE symbol (zero pages, padding) has nothing to sort: SA = n-1 .. 0, every BWT byte is the symbol, the
     // index row is n - 1.  Left to the tiers it is their worst case -- every suffix ties with every other for the whole
     // block: bucket overflow, the sample sorter's depth cap, then ~20 prefix-doubling rounds of the general sorter (1.3 ms
     // where a Zipf block takes 0.012).  FS_DONE overrides whatever the flag was (text-likeness, a caller's "sample sorter
     // first"): every tier skips a flagged block, and k_fs_finish does not list this one for anybody.  Its rows are written
     // right here, by this workgroup (a kernel of its own was one more launch in every call's chain).
-    const bool constant = __syncthreads_or((int)(h == n)) != 0;
+    bool constant = __syncthreads_or((int)(hraw == ns - (step > 1 ? 256u : 0u))) != 0;
+    if (constant && step > 1) {                                // (uniform) one symbol in the SAMPLE: look at the whole block
+        const uint8_t *T = text + (size_t)b * stride;
+        const uint32_t sym = T[0];
+        bool other = false;
+        for (uint32_t i = tid; i < n && !other; i += 256) other = T[i] != sym;
+        constant = __syncthreads_or((int)other) == 0;
+    }
     if (tid == 0) {
         if (constant) flag[b] = FS_DONE;
-        else if (dup[b] >= FS_DUP_FLAG) flag[b] = 1u;               // text-like (see k_fs_hist): straight to the sample sorter
+        else if (dup[b] >= (FS_DUP_FLAG + step - 1) / step) flag[b] = 1u;   // text-like (see k_fs_hist): straight to the sample sorter
     }
     if (constant) {
         const uint32_t sym = text[(size_t)b * stride];
@@ -111,8 +127,7 @@ __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ 
         if (d_index && tid == 0) d_index[b] = (int)(n - 1);
         return;                                                // (uniform; the table of a flagged block is never read)
     }
-    const uint32_t c = block_excl_add<256>(h, s_tmp);
-    const uint64_t C32 = ((uint64_t)c << 32) / n, P32 = ((uint64_t)h << 32) / n;
+    const uint64_t C32 = ((uint64_t)c << 32) / ns, P32 = ((uint64_t)h << 32) / ns;
     tab[(size_t)b * 256 + tid] = make_uint2((uint32_t)(C32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : C32),
                                             (uint32_t)(P32 > 0xFFFFFFFFull ? 0xFFFFFFFFull : P32));
 }
@@ -122,13 +137,13 @@ __global__ __launch_bounds__(256) void k_fs_tables(const uint32_t *__restrict__ 
 #endif
 constexpr int FSH_COPIES = GLC_FSH_COPIES;             // LDS copies of the histogram (same-symbol atomics of a wave spread over them)
 __global__ __launch_bounds__(256) void k_fs_hist(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
-                                                 uint32_t *__restrict__ hist, uint32_t *__restrict__ dup)
+                                                 uint32_t *__restrict__ hist, uint32_t *__restrict__ dup, uint32_t step)
 {
     __shared__ uint32_t s_h[FSH_COPIES * 257];
     __shared__ uint32_t s_fp[FSH_SLOTS];
     __shared__ uint32_t s_dup;
     const uint32_t b = blockIdx.y, tid = threadIdx.x;
-    const uint32_t lo = blockIdx.x * FSH_SLICE;
+    const uint32_t lo = blockIdx.x * step * FSH_SLICE;        // (step > 1: every step-th slice -- see k_fs_tables)
     if (lo >= n) return;
     const uint32_t hi = min(n, lo + FSH_SLICE);
     for (uint32_t i = tid; i < FSH_COPIES * 257; i += 256) s_h[i] = 0;
@@ -2040,11 +2055,16 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     uint32_t *h_nflag = s.h_max_cnt + 4;                       // pinned, device-mapped: written by the kernel that finishes the pass
     const double units = (double)n * nblk;
     int pi = s.prof ? s.prof->begin(PROF_FS_HIST, st) : -1;
-    hipLaunchKernelGGL(k_fs_hist, dim3((n + FSH_SLICE - 1) / FSH_SLICE, nblk), dim3(256), 0, st, text, text_stride, n,
-                       s.fs_hist, s.fs_dup);
+    // statistics from every 4th 32 KB slice of a block of 512 KiB or more (the pass reads a quarter of the input: 0.27 -> 0.07 ms
+    // per GiB; GLC_FSH_STEP=1: all of it)
+    static const int step_env = getenv("GLC_FSH_STEP") ? atoi(getenv("GLC_FSH_STEP")) : 0;
+    const uint32_t nslices = (n + FSH_SLICE - 1) / FSH_SLICE;
+    const uint32_t hstep = step_env > 0 ? (uint32_t)step_env : (nslices >= 16 ? 4u : 1u);
+    hipLaunchKernelGGL(k_fs_hist, dim3((nslices + hstep - 1) / hstep, nblk), dim3(256), 0, st, text, text_stride, n,
+                       s.fs_hist, s.fs_dup, hstep);
     if (pi >= 0) s.prof->end(pi, units, st);
     hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab, s.fs_dup, s.fs_flag, text, text_stride,
-                       bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+                       bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, hstep);
     if (s.skip_tier1) {
         // most blocks of the plan's previous call were flagged: no attempt, every block goes to the sample sorter
         hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
