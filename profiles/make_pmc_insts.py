@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 UNITS = float(256 << 20)          # the counters were collected on launches over 256 blocks of 1 MiB
 
-SHORT = {"k_fs_part": "k_fs_part2(", "k_fs_sort": "k_fs_sort_bwt(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
+SHORT = {"k_fs_part": "k_fs_part2<", "k_fs_sort": "k_fs_sort_bwt(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
          "k_mtf_encode": "k_mtf_encode<", "k_huff_pack": "k_huff_pack(", "k_huff_build": "k_huff_build<",
          "k_mtf_chunk_lists": "k_mtf_chunk_lists(", "k_mtf_scan_lists": "k_mtf_scan_lists<",
          "k_ibwt_walk": "k_ibwt_walk<", "k_imtf_pos": "k_imtf_pos_deque(", "k_dec_huff_lanes": "k_dec_huff_lanes(",

@@ -68,7 +68,7 @@ def main():
     o8 = find("k_rs_onesweep<8, false") or find("k_rs_onesweep<8")
     # per-launch HBM bytes of the kernels bench.py profiles live (its `roofline.traffic` reads this table), and the
     # whole encode's HBM bytes per input byte (every glc:: kernel of one 256-block batch / 256 MiB)
-    short = {"k_fs_part": "k_fs_part2(", "k_fs_sort": "k_fs_sort_bwt(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
+    short = {"k_fs_part": "k_fs_part2<", "k_fs_sort": "k_fs_sort_bwt(", "k_fs_hist": "k_fs_hist(", "k_fs_ties": "k_fs_ties(",
              "k_mtf_encode": "k_mtf_encode<", "k_huff_pack": "k_huff_pack(", "k_huff_build": "k_huff_build<",
              "k_mtf_chunk_lists": "k_mtf_chunk_lists(", "k_mtf_scan_lists": "k_mtf_scan_lists<",
              "k_rs_onesweep<8,false>": "k_rs_onesweep<8, false",
