@@ -1066,6 +1066,10 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
 // 8 bytes at a time) and writes its row.  Equal codes do not certify equal symbols: the comparison starts at
 // the first symbol.
 // ---------------------------------------------------------------------------
+#ifndef GLC_FST_W
+#define GLC_FST_W 4
+#endif
+constexpr int FST_W = GLC_FST_W;                              // k_fs_ties: members of a run met at a time
 __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                  const uint4 *__restrict__ wl, uint32_t wl_cap,
                                                  const uint32_t *__restrict__ wl_count, uint32_t *__restrict__ flag,
@@ -1089,15 +1093,15 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
         // that agrees in those 8 bytes, or sits at the end of the block, takes the byte-exact loop
         const bool fast_me = idx + 12 <= n;
         const uint64_t mine = fast_me ? fs_load_be64(T + idx) : 0ull;
-        for (uint32_t f0 = me.z; f0 < me.z + gs && !deep; f0 += 4) {
-            uint32_t oi[4];
-            uint64_t ov[4];
+        for (uint32_t f0 = me.z; f0 < me.z + gs && !deep; f0 += FST_W) {
+            uint32_t oi[FST_W];
+            uint64_t ov[FST_W];
 #pragma unroll
-            for (int k = 0; k < 4; k++) oi[k] = f0 + k < me.z + gs ? WL[f0 + k].x >> 8 : idx;
+            for (int k = 0; k < FST_W; k++) oi[k] = f0 + k < me.z + gs ? WL[f0 + k].x >> 8 : idx;
 #pragma unroll
-            for (int k = 0; k < 4; k++) ov[k] = (oi[k] != idx && fast_me && oi[k] + 12 <= n) ? fs_load_be64(T + oi[k]) : mine;
+            for (int k = 0; k < FST_W; k++) ov[k] = (oi[k] != idx && fast_me && oi[k] + 12 <= n) ? fs_load_be64(T + oi[k]) : mine;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < FST_W; k++) {
                 if (oi[k] == idx) continue;                    // myself, or past the end of the run
                 if (fast_me && oi[k] + 12 <= n && ov[k] != mine) rank += ov[k] < mine ? 1u : 0u;
                 else rank += fs_suffix_less(T, n, oi[k], idx, &deep) ? 1u : 0u;
@@ -2084,7 +2088,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
         static const bool old_part = getenv("GLC_FS_PART_OLD") != nullptr;      // A/B: one tile per workgroup
         if (!old_part) {
-            // tiles per workgroup: 8 for batches, 4 for a few blocks (more workgroups for a block on its own).  Round 5, bench.py
+            // tiles per workgroup: 8 for batches, 4 for a few blocks, 1 for one to three (more workgroups for a block on its own).  Round 5, bench.py
             // `value` on one box, 1024-block batches, stage overlap on: 4 / 8 / 12 / 16 / 24 / 32 / 64 tiles -> 93.1 / 95.1 / 94.7 /
             // 95.1 / 95.6 / 93.8 / 87-94 GB/s (16 and 24 fall into two modes from run to run: 94.3-96.5); the kernel itself 3.0 ->
             // 2.9 ms per GiB.  Tiles of 8192 suffixes (1024 threads x 8, 64 KB of LDS, one workgroup per CU: runs of ~128 bytes, half
@@ -2092,7 +2096,9 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
             // free AT ONCE, which the MTF and Huffman kernels of the batch before, sharing the chip under stage overlap, rarely leave.
             static const int per_env = getenv("GLC_FSP2_PER") ? atoi(getenv("GLC_FSP2_PER")) : 0;    // A/B: tiles per workgroup
             const uint32_t tiles = (n + FSP2_TILE - 1) / FSP2_TILE;
-            const uint32_t per = per_env > 0 ? (uint32_t)per_env : (nbk >= 16 ? 2 * FSP2_T : FSP2_T);
+            // (a call of one to three blocks: ONE tile per workgroup -- 256 workgroups for a block on its own: 17.3 -> 12.0 us of
+            //  a single cudppCompress call's chain, 0.190 -> 0.182 ms per call)
+            const uint32_t per = per_env > 0 ? (uint32_t)per_env : (nbk >= 16 ? 2 * FSP2_T : (nbk >= 4 ? FSP2_T : 1u));
             hipLaunchKernelGGL((k_fs_part2<FSP2_NT, FSP2_TILE / FSP2_NT, GLC_FSP2_WAVES>), dim3((tiles + per - 1) / per, nbk), dim3(FSP2_NT), 0, st,
                                text + (size_t)b0 * text_stride, text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256,
                                s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
@@ -2124,7 +2130,8 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                                s.fs_wlcnt + b0, s.fs_zero + b0);
         if (pi >= 0) s.prof->end(pi, u, st);
     }
-    hipLaunchKernelGGL(k_fs_ties, dim3(24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
+    static const int tg_env = getenv("GLC_FST_GRID") ? atoi(getenv("GLC_FST_GRID")) : 0;     // A/B: workgroups per block of k_fs_ties
+    hipLaunchKernelGGL(k_fs_ties, dim3(tg_env > 0 ? tg_env : 24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
                        s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list, h_nflag);
