@@ -867,6 +867,11 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
     uint32_t gx, gy;
     xcd_order(gx, gy);
     const uint32_t b = gy, bk = gx, tid = threadIdx.x;
+    // A block flagged BEFORE this kernel started -- text-like (k_fs_tables), a bucket past its slot (k_fs_part2), constant -- is
+    // another sorter's: its 512 workgroups leave on a scalar load, before the table of counters is cleared and three rounds of
+    // words are asked for (0.25 ms per batch of 256 text blocks were spent leaving).  Bits 1 and 8 only: nobody sets those while
+    // this kernel runs, so every wave of the workgroup sees the same (what k_fs_sort_bwt itself sets, 2 and 4, goes through s_deep)
+    if (scalar_load_u32(flag + b) & (1u | FS_DONE)) return;
     if (tid == 0) { s_deep = flag[b]; s_wl = 0; }              // (one read: another bucket may flag the block meanwhile)
     for (uint32_t i = tid; i < FS_BINS / 2; i += FSS_NT) s_cp[i] = 0;
     const uint64_t *K = keys + (size_t)b * kstride + (size_t)bk * FS_CAP;

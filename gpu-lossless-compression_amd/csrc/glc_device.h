@@ -129,6 +129,19 @@ __device__ __forceinline__ uint32_t block_excl_max(uint32_t x, uint32_t *s_tmp)
 
 // XCD-aware order of a (x, y) grid: physical workgroup p runs on XCD p & 7; the logical workgroups are dealt out so that
 // every XCD takes one contiguous run of them (everything of a block on one XCD: what its workgroups share stays in one L2)
+// a dword every lane of the workgroup wants, through the scalar cache (a fraction of a vector load's latency, and a hit for
+// every later workgroup of the CU that asks for the same word).  Only for words nobody writes while this kernel runs: the scalar
+// cache is not coherent with stores of other workgroups.
+__device__ __forceinline__ uint32_t scalar_load_u32(const uint32_t *p)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(sa) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ void xcd_order(uint32_t &bx, uint32_t &by)
 {
     const uint32_t nx = gridDim.x, total = nx * gridDim.y, p = blockIdx.y * nx + blockIdx.x;
