@@ -614,6 +614,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         have = next_inner;
         lds_only_barrier();
         const uint32_t tile_n = min((uint32_t)TILE, n - base);
+#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & 32)                 // timing experiment: TWO words per store (16 bytes, half the store instructions; the layout is not a sort's)
+#pragma unroll
+        for (int r = 0; r < ITEMS / 2; r++) {
+            const uint32_t p = 2 * (r * NT + tid);
+            if (p < tile_n) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(&s_w[p]);
+                const uint32_t d = nbl ? (q.y >> (32 - nbl)) : 0u;
+                const uint32_t off = ((uint32_t)s_gbase[d] + (p - (uint32_t)s_start[d])) & ~1u;
+                if (off < FS_CAP) *reinterpret_cast<uint4 *>(&K[(size_t)d * FS_CAP + off]) = q;
+            }
+        }
+        if (false)
+#endif
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
             const uint32_t p = r * NT + tid;
