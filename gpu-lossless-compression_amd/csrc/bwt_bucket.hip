@@ -2106,21 +2106,38 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
         pi = s.prof ? s.prof->begin(PROF_FS_PART, st) : -1;
         static const bool old_part = getenv("GLC_FS_PART_OLD") != nullptr;      // A/B: one tile per workgroup
         if (!old_part) {
-            // tiles per workgroup: 8 for batches, 4 for a few blocks, 1 for one to three (more workgroups for a block on its own).  Round 5, bench.py
+            // tiles of 4096 suffixes, per workgroup: 8 for batches, 4 for a few blocks, 1 for one to three (more workgroups for a block on its own).  Round 5, bench.py
             // `value` on one box, 1024-block batches, stage overlap on: 4 / 8 / 12 / 16 / 24 / 32 / 64 tiles -> 93.1 / 95.1 / 94.7 /
             // 95.1 / 95.6 / 93.8 / 87-94 GB/s (16 and 24 fall into two modes from run to run: 94.3-96.5); the kernel itself 3.0 ->
             // 2.9 ms per GiB.  Tiles of 8192 suffixes (1024 threads x 8, 64 KB of LDS, one workgroup per CU: runs of ~128 bytes, half
             // the global atomics) run 2.7 ms -- and give the same `value` as 4 tiles of 4096: a 1024-thread workgroup needs half a CU
             // free AT ONCE, which the MTF and Huffman kernels of the batch before, sharing the chip under stage overlap, rarely leave.
             static const int per_env = getenv("GLC_FSP2_PER") ? atoi(getenv("GLC_FSP2_PER")) : 0;    // A/B: tiles per workgroup
-            const uint32_t tiles = (n + FSP2_TILE - 1) / FSP2_TILE;
-            // (a call of one to three blocks: ONE tile per workgroup -- 256 workgroups for a block on its own: 17.3 -> 12.0 us of
-            //  a single cudppCompress call's chain, 0.190 -> 0.182 ms per call)
-            const uint32_t per = per_env > 0 ? (uint32_t)per_env : (nbk >= 16 ? 2 * FSP2_T : (nbk >= 4 ? FSP2_T : 1u));
-            hipLaunchKernelGGL((k_fs_part2<FSP2_NT, FSP2_TILE / FSP2_NT, GLC_FSP2_WAVES>), dim3((tiles + per - 1) / per, nbk), dim3(FSP2_NT), 0, st,
-                               text + (size_t)b0 * text_stride, text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256,
-                               s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
-                               s.fs_zero + b0, per);
+            static const bool small_tiles = getenv("GLC_FSP2_SMALL") != nullptr;                     // A/B: 4096-suffix tiles for batches too
+            // Batches of 16 blocks or more: tiles of 8192 suffixes, 1024 threads (runs of ~128 bytes leave for a bucket's slot, half the
+            // global atomics; 64 KB of LDS, two workgroups per CU), 16 tiles per workgroup.  Until the MTF kernel was re-based this
+            // shape ran 2.7 ms and gave the same `value` (the stages of the batch before rarely left half a CU free at once); since:
+            // alternating on one box, 6 steps: 100.2 / 101.7 / 102.0 GB/s as it was, 102.3 / 102.9 / 103.0 so (8 tiles per workgroup:
+            // 102.3 / 102.5 / 102.7); stages back to back 97.8-99.8 -> 101.2-101.7; the kernel 2.91-3.10 -> 2.67-2.73 ms per GiB.
+            // (512 threads x 16 suffixes for the same tile: 3.3 ms.)
+            if (nbk >= 16 && !small_tiles) {
+                constexpr int BT = 8192, BN = 1024;
+                const uint32_t tiles = (n + BT - 1) / BT;
+                const uint32_t per = per_env > 0 ? (uint32_t)per_env : 16u;
+                hipLaunchKernelGGL((k_fs_part2<BN, BT / BN, 4>), dim3((tiles + per - 1) / per, nbk), dim3(BN), 0, st,
+                                   text + (size_t)b0 * text_stride, text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256,
+                                   s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
+                                   s.fs_zero + b0, per);
+            } else {
+                const uint32_t tiles = (n + FSP2_TILE - 1) / FSP2_TILE;
+                // (a call of one to three blocks: ONE tile per workgroup -- 256 workgroups for a block on its own: 17.3 -> 12.0 us of
+                //  a single cudppCompress call's chain, 0.190 -> 0.182 ms per call)
+                const uint32_t per = per_env > 0 ? (uint32_t)per_env : (nbk >= 16 ? 2 * FSP2_T : (nbk >= 4 ? FSP2_T : 1u));
+                hipLaunchKernelGGL((k_fs_part2<FSP2_NT, FSP2_TILE / FSP2_NT, GLC_FSP2_WAVES>), dim3((tiles + per - 1) / per, nbk), dim3(FSP2_NT), 0, st,
+                                   text + (size_t)b0 * text_stride, text_stride, n, nbl, s.fs_tab + (size_t)b0 * 256,
+                                   s.keyA + (size_t)b0 * s.fs_kstride, s.fs_kstride, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0,
+                                   s.fs_zero + b0, per);
+            }
         }
         else
         hipLaunchKernelGGL(k_fs_part<false>, dim3((n + FSP_TILE - 1) / FSP_TILE, nbk), dim3(FSP_NT), 0, st, text + (size_t)b0 * text_stride,
