@@ -2121,7 +2121,10 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
             // 102.3 / 102.5 / 102.7); stages back to back 97.8-99.8 -> 101.2-101.7; the kernel 2.91-3.10 -> 2.67-2.73 ms per GiB.
             // (512 threads x 16 suffixes for the same tile: 3.3 ms.)
             if (nbk >= 16 && !small_tiles) {
-                constexpr int BT = 8192, BN = 1024;
+#ifndef GLC_FSP2_BT
+#define GLC_FSP2_BT 8192
+#endif
+                constexpr int BT = GLC_FSP2_BT, BN = 1024;
                 const uint32_t tiles = (n + BT - 1) / BT;
                 const uint32_t per = per_env > 0 ? (uint32_t)per_env : 16u;
                 hipLaunchKernelGGL((k_fs_part2<BN, BT / BN, 4>), dim3((tiles + per - 1) / per, nbk), dim3(BN), 0, st,
