@@ -1787,8 +1787,30 @@ constexpr int SSW_PER_BUCKET = 4;                              // one-wave workg
 template <bool TOL>
 __device__ __forceinline__ bool ss_undecided_t(uint32_t g) { return ((g >> 12) & 0xFFFu) - (g & 0xFFFu) > 1 && (!TOL || (g >> 24) != SS_CAPPED); }
 
+// 16 bytes at any address as two big-endian numbers: ONE unaligned 16-byte load
+__device__ __forceinline__ void fs_load_be128(const uint8_t *p, uint64_t &hi, uint64_t &lo)
+{
+    uint64_t x[2];
+    __builtin_memcpy(x, p, 16);
+    hi = __builtin_bswap64(x[0]);
+    lo = __builtin_bswap64(x[1]);
+}
+
+// A round here takes 14 text bytes (two steps of the run descriptors' unit) from ONE 16-byte gather per member: the kernel is
+// bound by the number of scattered accesses a CU takes (~6 cycles per lane access out of L2: 12 rounds x 62 members per wave
+// of the 7-byte form account for two thirds of its time), and a gather of 16 bytes costs what one of 8 does.  The key is
+// [bytes 0 .. 7 | bytes 8 .. 13, 0, window slot]: unique, so a member's new place is ONE count of smaller keys (a 128-bit
+// comparison per key read, where the 7-byte form made two 64-bit ones), and the runs of the next round are found AFTER the
+// count: every place learns which slot's member comes to it (a byte per place), a place whose member's 14 bytes differ from
+// its left neighbour's starts a run, and four ballots of those flags give every place its run's first and last place -- no
+// counters, no scan.  Keys and words stay at their slots in LDS for the round (5.4 KB per wave); the window's words and run
+// descriptors live in registers, four places per lane.  A round with a member whose 16 bytes reach the end of the text takes
+// ONE step with the 9-bit digits that tell "ended" from a zero byte (63 bits + the slot).
+#ifndef GLC_SSW_WAVES
+#define GLC_SSW_WAVES 7
+#endif
 template <bool TOL>
-__global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+__global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                       const uint64_t *__restrict__ keys, size_t kstride,
                                                       const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
                                                       uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
@@ -1798,10 +1820,9 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
 {
     constexpr bool tol = TOL;
     auto ss_undecided = [](uint32_t g) { return ss_undecided_t<TOL>(g); };
-    __shared__ uint64_t s_kw[SS_WIN];                          // keys of the window
-    __shared__ uint32_t s_vw[SS_WIN];                          // index << 8 | BWT byte
-    __shared__ uint32_t s_sw[SS_WIN];                          // run descriptors (bucket positions)
-    __shared__ uint32_t s_cw[SS_WIN];                          // members of the run that starts at a window slot
+    __shared__ ulonglong2 s_kw[SS_WIN];                        // keys of the window's members {hi, lo}, at their slots
+    __shared__ uint32_t s_vw[SS_WIN];                          // ... and their words (index << 8 | BWT byte)
+    __shared__ uint8_t s_inv[SS_WIN];                          // the slot whose member comes to a place
     __shared__ uint32_t s_bound[SS_SHARES + 1];
     uint32_t gx, gy;
     xcd_order(gx, gy);
@@ -1823,8 +1844,6 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
     }
     __builtin_amdgcn_wave_barrier();
     SS_CLK(0);                                                 // prologue + share bounds
-    uint64_t *KW = s_kw;
-    uint32_t *VW = s_vw, *SW = s_sw;
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
     uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
     for (uint32_t ch = w0; ch < SS_SHARES; ch += SSW_PER_BUCKET) {
@@ -1835,7 +1854,6 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
             // window [pos, W): the runs that start in it and end within SS_WIN positions
             const uint32_t lim = min(B, pos + SS_WIN);
             uint32_t g4[4], x4[4], W = lim;
-            bool und = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t p = pos + lane + 64 * j;
@@ -1863,49 +1881,49 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                 pos = se;
                 continue;
             }
-            und = false;
+            bool und = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t p = pos + lane + 64 * j;
-                if (p < W) { VW[p - pos] = x4[j]; SW[p - pos] = g4[j]; und |= ss_undecided(g4[j]); }
+                if (p >= W) g4[j] = ss_run(0, 1, 0);                               // not of this window: a place on its own
+                und |= p < W && ss_undecided(g4[j]);
             }
-            __builtin_amdgcn_wave_barrier();
             // ---- window [pos, W): rounds in registers until every position is decided ----
             uint32_t rounds_here = 0;
+            const uint64_t le = (2ull << lane) - 1ull;         // lanes 0 .. lane
             while (__ballot(und) != 0) {
-                uint64_t key[4];
-                uint32_t v4[4], at[4];
-                bool dp = false, tail = false;
+                uint32_t at[4];
+                bool dp = false, tail = false, mv[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t p = pos + lane + 64 * j;
-                    key[j] = 0; v4[j] = 0; at[j] = 0;
+                    at[j] = 0; mv[j] = false;
                     if (p < W) {
                         const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
                         if (ss_undecided(g4[j]) && st > (tol ? SS_TOL_MAXSTEP : SS_MAXSTEP)) {
-                            if (tol) { g4[j] = ss_run(ss, se, SS_CAPPED); SW[p - pos] = g4[j]; }   // left as it is (all its members do this)
+                            if (tol) g4[j] = ss_run(ss, se, SS_CAPPED);          // left as it is (all its members do this)
                             else dp = true;
                         }
                         if (ss_undecided(g4[j])) {
-                            v4[j] = VW[p - pos];
-                            at[j] = (v4[j] >> 8) + l0 + SS_STEP * st;
-                            tail |= at[j] + 8 > n;                 // its 7 bytes (or the 8-byte load) reach the end of the text
+                            mv[j] = true;
+                            at[j] = (x4[j] >> 8) + l0 + SS_STEP * st;
+                            tail |= at[j] + 16 > n;                // the 16-byte load reaches the end of the text
                         }
                     }
                 }
                 if (__ballot(dp) != 0) { deep = true; break; }
-                // (a window this deep: another wave may have given the block up meanwhile -- a run 75 rounds deep costs
+                // (a window this deep: another wave may have given the block up meanwhile -- a run 75 steps deep costs
                 //  ~0.4 ms and a block with a duplicated region has thousands of them; without this look every wave went
                 //  through its own before the kernel ended, 6 ms per 64 such blocks)
                 if (!tol && (++rounds_here & 7u) == 0 && __hip_atomic_load(&flag[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-                uint32_t np[4];
+                const bool digits = __ballot(tail) != 0;       // (wave-uniform) one step of 9-bit digits instead of two of bytes
+                const uint32_t step = digits ? 1u : 2u;
                 SS_CLK(2);                                     // round set up
 #ifdef GLC_SS_CLOCKS
                 {
                     uint32_t tr = 0, und_n = 0;
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t p = pos + lane + 64 * j;
-                        const uint32_t L = p < W ? ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) : 0u;
+                        const uint32_t L = mv[j] ? ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) : 0u;
                         tr += wave_max(L > 1 ? L : 0u);
                         und_n += (uint32_t)__popcll(__ballot(L > 1));
                     }
@@ -1913,112 +1931,97 @@ __global__ __launch_bounds__(64, 8) void k_ss_windows(const uint8_t *__restrict_
                                      atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][27], (unsigned long long)und_n); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][28], (unsigned long long)(W - pos)); }
                 }
 #endif
-                if (__ballot(tail) == 0) {
-                    // the usual round: keys that cannot be equal (ss_raw7), two counts per member
+                // keys and words of the members, at their slots
+                {
+                    uint64_t kh[4], kl[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t p = pos + lane + 64 * j;
-                        if (p < W) {
-                            s_cw[p - pos] = 0;
-                            if (ss_undecided(g4[j])) {
-                                key[j] = ss_raw7(T, n, at[j]) | (uint64_t)(p - pos);
-                                KW[p - pos] = key[j];
-                            }
+                        kh[j] = 0; kl[j] = 0;
+                        if (mv[j]) {
+                            if (!digits) fs_load_be128(T + at[j], kh[j], kl[j]);
+                            else kh[j] = ss_sym_key(ss_sym_load(T, n, at[j]));
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    SS_CLK(3);                                 // text gathered
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t p = pos + lane + 64 * j;
-                        np[j] = 0xFFFFFFFFu;
-                        if (p < W) {
-                            const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
-                            if (ss_undecided(g4[j])) {
-                                const uint64_t klow = key[j] & ~0xFFull;
-                                uint32_t below = 0, below_run = 0;
-#pragma unroll 4
-                                for (uint32_t q = ss; q < se; q++) {
-                                    const uint64_t kq = KW[q - pos];
-                                    below += kq < key[j]; below_run += kq < klow;
-                                }
-                                np[j] = ss + below;
-                                g4[j] = (ss + below_run) | (st + 1) << 24;      // new run start + step; the end follows from the count
-                            }
+                        const uint32_t sl = lane + 64 * j;
+                        if (mv[j]) {
+                            s_kw[sl] = make_ulonglong2(kh[j], digits ? (uint64_t)sl : ((kl[j] & ~0xFFFFull) | sl));
+                            s_vw[sl] = x4[j];
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    SS_CLK(4);                                 // counted
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (np[j] != 0xFFFFFFFFu) {
-                            VW[np[j] - pos] = v4[j]; SW[np[j] - pos] = g4[j];
-                            atomicAdd(&s_cw[(g4[j] & 0xFFFu) - pos], 1u);
-                        }
-                } else {
-                    // a member's bytes reach the end of the text (the last suffixes of a block): the 9-bit digits that tell
-                    // "ended" from a zero byte, equal keys counted apart
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t p = pos + lane + 64 * j;
-                        if (p < W && ss_undecided(g4[j])) {
-                            key[j] = ss_sym_key(ss_sym_load(T, n, at[j]));
-                            KW[p - pos] = key[j];
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t p = pos + lane + 64 * j;
-                        np[j] = 0xFFFFFFFFu;
-                        if (p < W) {
-                            const uint32_t ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu, st = g4[j] >> 24;
-                            if (ss_undecided(g4[j])) {
-                                uint32_t less = 0, eqt = 0, eqb = 0;
-                                for (uint32_t q = ss; q < se; q++) {
-                                    const uint64_t kq = KW[q - pos];
-                                    less += kq < key[j]; eqt += kq == key[j]; eqb += (kq == key[j]) & (q < p);
-                                }
-                                np[j] = ss + less + eqb;
-                                g4[j] = ss_run(ss + less, ss + less + eqt, st + 1);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (np[j] != 0xFFFFFFFFu) { VW[np[j] - pos] = v4[j]; SW[np[j] - pos] = g4[j]; }
                 }
                 __builtin_amdgcn_wave_barrier();
+                SS_CLK(3);                                     // text gathered
+                // a member's new place = the smaller keys of its run; the place learns which slot comes to it
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (mv[j]) {
+                        const uint32_t sl = lane + 64 * j, ss = g4[j] & 0xFFFu, se = (g4[j] >> 12) & 0xFFFu;
+                        const ulonglong2 k = s_kw[sl];
+                        uint32_t below = 0;
+                        // (three 64-bit compares + two scalar mask operations per key; as the borrow of a 128-bit subtraction -- four
+                        //  32-bit steps and the add, no scalar work -- the batch of 256 text blocks ran 14.3 against 13.5 ms)
+#pragma unroll 4
+                        for (uint32_t q = ss; q < se; q++) {
+                            const ulonglong2 kq = s_kw[q - pos];
+                            below += ((kq.x < k.x) | ((kq.x == k.x) & (kq.y < k.y))) ? 1u : 0u;
+                        }
+                        s_inv[ss + below - pos] = (uint8_t)sl;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                SS_CLK(4);                                     // counted
+                // a place starts a run if it is the old run's first or its 14 bytes (its digits) differ from its left neighbour's
+                uint64_t hb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t sl = lane + 64 * j;
+                    bool head = true;
+                    if (mv[j]) {
+                        const uint32_t i1 = s_inv[sl];
+                        x4[j] = s_vw[i1];
+                        if (pos + sl != (g4[j] & 0xFFFu)) {
+                            const ulonglong2 k1 = s_kw[i1], k0 = s_kw[s_inv[sl - 1]];
+                            head = (k1.x != k0.x) | (((k1.y ^ k0.y) >> 8) != 0);
+                        }
+                    }
+                    hb[j] = __ballot(head);
+                }
+                // run of a place: from the last head at or below it to the next head above it (uniform where a 64-lane group has none)
+                uint32_t prevh[4], nexth[4];
+                prevh[0] = 0;
+#pragma unroll
+                for (int j = 1; j < 4; j++) prevh[j] = hb[j - 1] ? 64u * (j - 1) + 63u - (uint32_t)__builtin_clzll(hb[j - 1]) : prevh[j - 1];
+                nexth[3] = SS_WIN;
+#pragma unroll
+                for (int j = 2; j >= 0; j--) nexth[j] = hb[j + 1] ? 64u * (j + 1) + (uint32_t)__builtin_ctzll(hb[j + 1]) : nexth[j + 1];
                 und = false;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t p = pos + lane + 64 * j;
-                    if (p < W) {
-                        g4[j] = SW[p - pos];
-                        if (((g4[j] >> 12) & 0xFFFu) == 0) {          // written by the usual round: (start, step) -> (start, end, step)
-                            const uint32_t ss = g4[j] & 0xFFFu;
-                            g4[j] = ss_run(ss, ss + s_cw[ss - pos], g4[j] >> 24);
-                            SW[p - pos] = g4[j];
-                        }
+                    if (mv[j]) {
+                        const uint64_t lo_m = hb[j] & le, hi_m = hb[j] & ~le;
+                        const uint32_t rs = lo_m ? 64u * j + 63u - (uint32_t)__builtin_clzll(lo_m) : prevh[j];
+                        const uint32_t re = hi_m ? 64u * j + (uint32_t)__builtin_ctzll(hi_m) : nexth[j];
+                        g4[j] = ss_run(pos + rs, pos + re, (g4[j] >> 24) + step);
                         und |= ss_undecided(g4[j]);
                     }
                 }
-                SS_CLK(5);                                     // moved, runs re-read
+                __builtin_amdgcn_wave_barrier();
+                SS_CLK(5);                                     // moved, runs found
             }
+            if (deep) break;
             // rows R0 + pos .. R0 + W
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t p = pos + lane + 64 * j;
                 if (p < W) {
-                    const uint32_t v = VW[p - pos], idx = v >> 8;
+                    const uint32_t v = x4[j], idx = v >> 8;
                     if (O) O[p] = (uint8_t)v;
                     if (SAo) SAo[p] = idx;
                     if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
             SS_CLK(6);                                         // rows written
             pos = W;
         }
