@@ -1396,7 +1396,7 @@ constexpr uint32_t SS_NPL = GLC_SS_NPL, SS_NPIV0 = 64 * SS_NPL; // first cut: 25
 // slots and k_ss_windows took 8.0 ms per 256 text blocks; 32 / 16 / 8 / 4 shares: 6.6 / 5.8 / 5.4 / 5.3 ms.
 constexpr uint32_t SS_SHARES = 8;
 constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
-constexpr uint32_t SSL_SMALL = 1024;                           // k_ss_long: members of a "small" long bin
+constexpr uint32_t SSL_SMALL = GLC_SSL_SMALL;                           // k_ss_long: members of a "small" long bin
 // (SS_LONG, glc_internal.h: runs longer than that are cut with pivots by k_ss_long; shorter ones are counted out in the windows)
 // k_ss_windows' form of a round's key: the SS_STEP = 7 text bytes themselves in the top 56 bits (0 past the end of
 // the text) and the window slot in the low 8, so that no two keys of a window are equal: a position's new place is
@@ -2211,7 +2211,7 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_ss_cut<SSS_NT>, dim3(nb, nflag), dim3(SSS_NT), 0, st, text, text_stride, n, nbl, s.keyA, s.fs_kstride,
                        s.fs_fill, s.ss_flag, list, s.ss_l0, s.ss_long, long_cap, s.ss_long_count);
     // the long bins: as many workgroups as fit the GPU (LDS: 17 KB / 65.5 KB each), the list's entries strided over them
-    hipLaunchKernelGGL((k_ss_long<SSL_SMALL, 64, false>), dim3(256 * 9), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+    hipLaunchKernelGGL((k_ss_long<SSL_SMALL, 64, false>), dim3(256 * (163840 / (16 * SSL_SMALL + 1200))), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                        s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count, tol);
     hipLaunchKernelGGL((k_ss_long<FS_FILLMAX, 256, true>), dim3(256 * 2), dim3(256), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                        s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count, tol);

@@ -32,7 +32,10 @@ constexpr uint32_t SS_TOL_CAP = GLC_SS_TOL_CAP;  // ... and in the sample sorter
 #define GLC_SS_LONG 256
 #endif
 constexpr uint32_t SS_LONG = GLC_SS_LONG;        // sample sorter: a run of more positions is cut with pivots (k_ss_long), a shorter one counted out (k_ss_windows)
-constexpr uint32_t SSL_PER_BUCKET = FS_FILLMAX / (SS_LONG + 1), SSL_BIG_PER_BUCKET = 3;   // most bins of > SS_LONG / > 1024 members a bucket of <= 4032 can have
+#ifndef GLC_SSL_SMALL
+#define GLC_SSL_SMALL 1024
+#endif
+constexpr uint32_t SSL_PER_BUCKET = FS_FILLMAX / (SS_LONG + 1), SSL_BIG_PER_BUCKET = FS_FILLMAX / (GLC_SSL_SMALL + 1);   // most bins of > SS_LONG / > 1024 members a bucket of <= 4032 can have
 static_assert(SSL_PER_BUCKET < 64, "k_ss_cut lists a bucket's long bins with one wave");
 
 // status bits accumulated on the device (PlanBase::d_status)
