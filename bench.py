@@ -1261,31 +1261,33 @@ def main():
     # one plan, stages back to back: the decoder as a single caller sees it
     for pl in plans:
         pl.set_pipelining(False)
-    d_back1 = torch.empty(rows * n, dtype=torch.uint8, device=dev)
+    # (1024-block calls, whatever the encoder's batches are: the decoder's per-kernel table and its pipelined mode -- four calls,
+    #  each one's inverse BWT under the next one's Huffman + inverse MTF -- are quoted on them since round 3)
+    drows = min(rows, 1024)
+    dbatches = list(range(0, nblocks, drows))[:4]
+    d_back1 = torch.empty(drows * n, dtype=torch.uint8, device=dev)
     plan.synchronize()
     plan.enable_timing(3)                                     # per-kernel hipEvent pairs for the decoder's roofline block
     t0d = time.perf_counter()
-    nrep = min(4, len(batches))
-    for b0 in batches[:nrep]:
-        nb = min(rows, nblocks - b0)
-        dec_batch(plan, b0, nb, d_back1.data_ptr())
+    for b0 in dbatches:
+        dec_batch(plan, b0, min(drows, nblocks - b0), d_back1.data_ptr())
     plan.synchronize()
-    dec1 = sum(min(rows, nblocks - b0) for b0 in batches[:nrep]) * n / (time.perf_counter() - t0d) / 1e9
+    dec1 = sum(min(drows, nblocks - b0) for b0 in dbatches) * n / (time.perf_counter() - t0d) / 1e9
     dec_prof = plan.kernel_profiles()
     plan.enable_timing(0)
     # ... and the same plan with its stage pipelining on (glcPlanSetPipelining: inverse BWT of call k on the plan's side stream
     # under Huffman + inverse MTF of call k + 1): ONE plan, one caller thread -- the figure a single caller gets
     plan.set_pipelining(True)
-    for b0 in batches[:nrep]:
-        dec_batch(plan, b0, min(rows, nblocks - b0), d_back1.data_ptr())
+    for b0 in dbatches:
+        dec_batch(plan, b0, min(drows, nblocks - b0), d_back1.data_ptr())
     plan.synchronize()
     t0p = time.perf_counter()
-    for b0 in batches[:nrep]:
-        dec_batch(plan, b0, min(rows, nblocks - b0), d_back1.data_ptr())
+    for b0 in dbatches:
+        dec_batch(plan, b0, min(drows, nblocks - b0), d_back1.data_ptr())
     plan.synchronize()
-    dec1_pipe = sum(min(rows, nblocks - b0) for b0 in batches[:nrep]) * n / (time.perf_counter() - t0p) / 1e9
-    last_b0 = batches[:nrep][-1]
-    if not bool(torch.equal(d_back1[:min(rows, nblocks - last_b0) * n], d_in[last_b0 * n:(last_b0 + min(rows, nblocks - last_b0)) * n])):
+    dec1_pipe = sum(min(drows, nblocks - b0) for b0 in dbatches) * n / (time.perf_counter() - t0p) / 1e9
+    last_b0 = dbatches[-1]
+    if not bool(torch.equal(d_back1[:min(drows, nblocks - last_b0) * n], d_in[last_b0 * n:(last_b0 + min(drows, nblocks - last_b0)) * n])):
         raise RuntimeError("round trip failed in the pipelined one-plan decode")
     plan.set_pipelining(False)
     del d_back1
