@@ -40,6 +40,15 @@
 
 namespace glc {
 
+#ifndef GLC_FS_DEPTH
+#define GLC_FS_DEPTH 8
+#endif
+constexpr int      FS_DEPTH  = GLC_FS_DEPTH;        // symbols the arithmetic code of a suffix is made of (see fs_code_at)
+#ifndef GLC_SS_DEPTH
+#define GLC_SS_DEPTH GLC_FS_DEPTH
+#endif
+constexpr int      SS_DEPTH  = GLC_SS_DEPTH;        // ... in the sample sorter's own words (k_ss_sample's samples and k_fs_part<true> must agree; the tiers need not)
+static_assert(FS_DEPTH >= 2 && FS_DEPTH <= 8 && SS_DEPTH >= 2 && SS_DEPTH <= 8, "a thread's 8 codes take their symbols from its 16 staged bytes");
 constexpr int      FSP_NT    = 512;                 // k_fs_part: threads
 constexpr int      FSP_ITEMS = 8;
 constexpr int      FSP_TILE  = FSP_NT * FSP_ITEMS;  // suffixes per tile
@@ -291,7 +300,7 @@ __device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t
 }
 
 template <bool SPLIT>
-__global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+__global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_fs_part(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                     uint32_t nbl, const uint2 *__restrict__ tab,
                                                     uint64_t *__restrict__ keys, size_t kstride,
                                                     uint32_t *__restrict__ fill, uint32_t *__restrict__ flag,
@@ -371,9 +380,10 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     const uint2 qa = *reinterpret_cast<const uint2 *>(s_txt + k0), qb = *reinterpret_cast<const uint2 *>(s_txt + k0 + 8);
     const uint32_t by4[4] = {qa.x, qa.y, qb.x, qb.y};
 #define FS_BYTE(j) ((by4[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
-    uint2 e[FSP_ITEMS + 5];                                    // table entries of the 13 symbols the 8 codes share
+    constexpr int DEPTH = SPLIT ? SS_DEPTH : FS_DEPTH;
+    uint2 e[FSP_ITEMS + DEPTH - 1];                            // table entries of the symbols the 8 codes share
 #pragma unroll
-    for (int k = 0; k < FSP_ITEMS + 5; k++) {
+    for (int k = 0; k < FSP_ITEMS + DEPTH - 1; k++) {
         const uint2 t = s_tab[FS_BYTE(1 + k)];
         e[k] = (edge && gi0 + k >= n) ? make_uint2(0u, 0u) : t;
     }
@@ -381,9 +391,9 @@ __global__ __launch_bounds__(FSP_NT) void k_fs_part(const uint8_t *__restrict__ 
     uint32_t br[FSP_ITEMS];                                    // bucket << 16 | rank inside (tile, bucket)
 #pragma unroll
     for (int j = 0; j < FSP_ITEMS; j++) {
-        uint32_t y = e[j + 5].x;
+        uint32_t y = e[j + DEPTH - 1].x;
 #pragma unroll
-        for (int d = 4; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
+        for (int d = DEPTH - 2; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
         const uint64_t X = ((uint64_t)e[j].x << 32) + (uint64_t)e[j].y * y;
         const uint32_t gi = gi0 + j;
         w[j] = (X & ~FS_LOW_MASK) | ((uint64_t)gi << 8) | FS_BYTE(j);
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         if (s_flagged) return;
         // thread = 8 consecutive suffixes gi0 .. gi0+7; byte j of its 16 staged bytes is T[gi0 - 1 + j]
         const uint32_t k0 = tid * ITEMS, gi0 = base + k0;
-        constexpr int NBY = (ITEMS + 6 + 3) / 4;              // dwords that hold the thread's ITEMS + 6 staged bytes (k0 is a multiple of ITEMS)
+        constexpr int NBY = (ITEMS + FS_DEPTH + 3) / 4;       // dwords that hold the thread's ITEMS + FS_DEPTH staged bytes (k0 is a multiple of ITEMS)
         uint32_t by4[NBY];
         if (ITEMS % 8 == 0) {
 #pragma unroll
@@ -552,9 +562,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             for (int q = 0; q < NBY; q++) by4[q] = *reinterpret_cast<const uint32_t *>(s_txt + k0 + 4 * q);
         }
 #define FS_BYTE(j) ((by4[(j) >> 2] >> (8 * ((j) & 3))) & 0xFFu)
-        uint2 e[ITEMS + 5];                                // table entries of the 13 symbols the 8 codes share
+        uint2 e[ITEMS + FS_DEPTH - 1];                     // table entries of the symbols the 8 codes share
 #pragma unroll
-        for (int k = 0; k < ITEMS + 5; k++) {
+        for (int k = 0; k < ITEMS + FS_DEPTH - 1; k++) {
             const uint2 t = s_tab[FS_BYTE(1 + k)];
             e[k] = (edge && gi0 + k >= n) ? make_uint2(0u, 0u) : t;
         }
@@ -562,9 +572,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         uint32_t br[ITEMS];                                // bucket << 16 | rank inside (tile, bucket)
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
-            uint32_t y = e[j + 5].x;
+            uint32_t y = e[j + FS_DEPTH - 1].x;
 #pragma unroll
-            for (int d = 4; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
+            for (int d = FS_DEPTH - 2; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
 #if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & 4)                  // timing experiment: no codes
             const uint64_t X = (uint64_t)((gi0 + j) * 2654435761u) << 32 | by4[0];
 #else
@@ -1211,12 +1221,12 @@ constexpr uint32_t SS_L0_CAP = 1024;                           // longest splitt
 
 __device__ __forceinline__ uint64_t fs_code_at(const uint2 *tab, const uint8_t *T, uint32_t n, uint32_t i)
 {
-    uint2 e[6];
+    uint2 e[SS_DEPTH];
 #pragma unroll
-    for (int k = 0; k < 6; k++) e[k] = i + k < n ? tab[T[i + k]] : make_uint2(0u, 0u);
-    uint32_t y = e[5].x;
+    for (int k = 0; k < SS_DEPTH; k++) e[k] = i + k < n ? tab[T[i + k]] : make_uint2(0u, 0u);
+    uint32_t y = e[SS_DEPTH - 1].x;
 #pragma unroll
-    for (int d = 4; d >= 1; d--) y = e[d].x + __umulhi(e[d].y, y);
+    for (int d = SS_DEPTH - 2; d >= 1; d--) y = e[d].x + __umulhi(e[d].y, y);
     return ((uint64_t)e[0].x << 32) + (uint64_t)e[0].y * y;
 }
 
