@@ -55,6 +55,10 @@ constexpr int      FSP_TILE  = FSP_NT * FSP_ITEMS;  // suffixes per tile
 constexpr int      FSS_NT    = 512;                 // k_fs_sort: threads
 constexpr int      FSS_ITEMS = FS_CAP / FSS_NT;     // slots per thread
 constexpr uint32_t FS_BIN_BITS = 12, FS_BINS = 1u << FS_BIN_BITS;
+#ifndef GLC_FSS_LOOK
+#define GLC_FSS_LOOK 4
+#endif
+constexpr uint32_t FSS_LOOK = GLC_FSS_LOOK;         // k_fs_sort_bwt's rank step: words from a bin's start compared in straight-line code
 constexpr uint32_t FS_MAX_GROUP = 512;              // longest run of equal codes ranked by direct count
 constexpr uint64_t FS_LOW_MASK = (1ull << 28) - 1;  // [index : 20 | bwt : 8]
 constexpr uint32_t SS_CELLS = 4096;                 // sample tier: cells of the code space (leading 12 bits) that index the splitters
@@ -881,7 +885,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
                                                         uint32_t wl_cap, uint32_t *__restrict__ wl_count,
                                                         const uint32_t *__restrict__ zero_bucket)
 {
-    __shared__ uint64_t s_w[FS_FILLMAX + 4];                   // + 4 sentinels behind the last word
+    __shared__ uint64_t s_w[FS_FILLMAX + FSS_LOOK];            // + sentinels behind the last word
     __shared__ uint32_t s_cp[FS_BINS / 2 + 1];                 // bin counters, then bin starts (two 16-bit values per word), then BWT bytes
     __shared__ uint32_t s_tmp[FSS_NT / 64 + 1];
     __shared__ uint32_t s_deep, s_wl;
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
 #pragma unroll
     for (int r = FSS_SPEC + 1; r < FSS_ITEMS; r++)
         if ((uint32_t)r <= full) w[r] = K[(r - 1) * FSS_NT + tid];
-    if (tid < 4 && cc) s_w[cc + tid] = ~0ull;                  // what the rank step reads past the last bin compares as larger
+    if (tid < FSS_LOOK && cc) s_w[cc + tid] = ~0ull;                  // what the rank step reads past the last bin compares as larger
     __syncthreads();
     if (s_deep || cc == 0) return;                             // flagged: the block is another sorter's
 #if defined(GLC_EXP_SORT) && GLC_EXP_SORT == 3                     // timing experiment: the loads alone
@@ -998,13 +1002,13 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
             uint32_t less = 0, eqt = 0;
             const uint32_t *B = reinterpret_cast<const uint32_t *>(s_w) + 2 * gs + 1;
 #pragma unroll
-            for (uint32_t t = 0; t < 4; t++) {
+            for (uint32_t t = 0; t < FSS_LOOK; t++) {
                 const uint32_t kq = B[2 * t];
                 less += kq < key ? 1u : 0u;
                 eqt += kq == key ? 1u : 0u;
             }
             uint32_t at = gs + less;
-            const bool rare = (ge - gs > 4) | (eqt > 1);
+            const bool rare = (ge - gs > FSS_LOOK) | (eqt > 1);
             if (__builtin_amdgcn_ballot_w64(rare) != 0) {      // (wave-uniform)
                 if (rare) {
                     if (ge - gs > FS_MAX_GROUP) { s_deep = 1; at = 0xFFFFFFFFu; }
