@@ -8,9 +8,12 @@
 // Blocks it cannot finish are flagged and go on to the second tier in this file, a string sample sort for text-like
 // data (k_ss_*, further down); what that cannot finish either goes through the general sorter in bwt_sa.hip.
 //
-// Idea.  A suffix is mapped to X = the arithmetic code of its first 6 symbols under the block's own
+// Idea.  A suffix is mapped to X = the arithmetic code of its first FS_DEPTH = 8 symbols under the block's own
 // order-0 symbol statistics:
-//      y5 = C[s5];   y_d = C[s_d] + floor(p[s_d] * y_{d+1} / 2^32)  (d = 4..1);   X = C[s0] * 2^32 + p[s0] * y1
+//      y7 = C[s7];   y_d = C[s_d] + floor(p[s_d] * y_{d+1} / 2^32)  (d = 6..1);   X = C[s0] * 2^32 + p[s0] * y1
+// (Six symbols until round 5: the word keeps 36 bits of X, ~six Zipf symbols' worth -- but the pairs that share six symbols are
+//  the FREQUENT prefixes, whose interval in 36 bits is wide enough for a 7th and an 8th symbol to be told apart: equal codes went
+//  from 0.4 % to 0.03 % of a block, and with them most of what k_fs_sort_bwt's rare path and k_fs_ties cost.)
 // (C = exclusive cumulative frequency, p = frequency, both scaled to 2^32; symbols past the end of the
 // block contribute C = p = 0).  Two properties carry the whole design:
 //   * X is monotone: suffix a < suffix b lexicographically  =>  X(a) <= X(b)   (each step maps the
