@@ -57,7 +57,10 @@ constexpr int      FSP_ITEMS = 8;
 constexpr int      FSP_TILE  = FSP_NT * FSP_ITEMS;  // suffixes per tile
 constexpr int      FSS_NT    = 512;                 // k_fs_sort: threads
 constexpr int      FSS_ITEMS = FS_CAP / FSS_NT;     // slots per thread
-constexpr uint32_t FS_BIN_BITS = 12, FS_BINS = 1u << FS_BIN_BITS;
+#ifndef GLC_FS_BIN_BITS
+#define GLC_FS_BIN_BITS 12
+#endif
+constexpr uint32_t FS_BIN_BITS = GLC_FS_BIN_BITS, FS_BINS = 1u << FS_BIN_BITS;
 #ifndef GLC_FSS_LOOK
 #define GLC_FSS_LOOK 4
 #endif
