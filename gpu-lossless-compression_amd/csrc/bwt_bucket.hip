@@ -1895,7 +1895,7 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
                 for (uint32_t p = pos + lane; p < se; p += 64) {
                     const uint32_t v = (uint32_t)K[p] & (uint32_t)FS_LOW_MASK, idx = v >> 8;
                     if (O) O[p] = (uint8_t)v;
-                    if (SAo) SAo[p] = idx;
+                    if (SAo) SAo[p] = idx | SA_CAND;
                     if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
                 }
                 pos = se;
@@ -2038,7 +2038,14 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
                 if (p < W) {
                     const uint32_t v = x4[j], idx = v >> 8;
                     if (O) O[p] = (uint8_t)v;
-                    if (SAo) SAo[p] = idx;
+                    // (tolerant form: the rows k_grp_flags has to look at -- a bucket's first row, whose suffix may tie with the last
+                    //  of the bucket before, and every row that may still have been in a run at depth SS_TOL_CAP: members of a run left
+                    //  as it is, but also suffixes told apart beyond the cap -- they may tie with a SPLITTER, and those ties were placed
+                    //  by position, on either side of it.  A place decided under the label `st` parted from its neighbours before depth
+                    //  l0 + 7 (st + 1): a round here advances the label with the decision, but a member alone in a bin BETWEEN two pivots
+                    //  of k_ss_cut / k_ss_long keeps the run's label and differs somewhere in the NEXT seven symbols -- the hunt that
+                    //  found it: two suffixes 131 and 132 symbols from the end of a block, cut apart at label 18 in some runs.)
+                    if (SAo) SAo[p] = idx | ((tol && (p == 0 || l0 + SS_STEP * ((g4[j] >> 24) + 1) >= SS_TOL_CAP)) ? SA_CAND : 0u);
                     if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
                 }
             }

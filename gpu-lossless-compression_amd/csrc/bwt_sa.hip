@@ -814,6 +814,9 @@ __global__ void k_sa_export(const uint32_t *__restrict__ sa, uint32_t n, uint32_
 // [group number : 44 | suffix : 20] in row order; everything else -- ISA, the compacted list of the unresolved, BWT
 // bytes, index -- comes out of the general sorter's own first round (k_sa_rank1<true>, MODE_ISA) over these words.
 // ---------------------------------------------------------------------------
+#ifdef GLC_DEBUG_CAND
+__device__ uint32_t g_cand_dbg[64];
+#endif
 constexpr uint32_t GRP_NT = 256;
 constexpr uint32_t GRP_SAME = 0x80000000u;                     // marks a row that continues its predecessor's group, in s.sa for a moment
 
@@ -831,9 +834,30 @@ __global__ __launch_bounds__(GRP_NT) void k_grp_flags(const uint8_t *__restrict_
     if (r < n) {
         const uint32_t cur = SA[r];
         bool same = false;
-        if (r > 0) {
+        // Only the rows the sample sorter marked can continue a group (SA_CAND: members of a run it left as it was, and the
+        // first row of a bucket); every other row it told from the row before by fewer than `cap` symbols.  (Looking at every
+        // row -- two scattered 8-byte loads at least -- was 1.35 ms per 64 blocks, a tenth of the resumed path.)
+#ifdef GLC_DEBUG_CAND
+        if (r > 0 && !(cur & SA_CAND)) {                       // the check: would the full comparison have called this row a continuation?
+            const uint32_t a = SA[r - 1] & ~(GRP_SAME | SA_CAND), c = cur & ~(GRP_SAME | SA_CAND);
+            if (max(a, c) + cap <= n) {
+                bool sm = true;
+                for (uint32_t k = 0; k < cap; k += 8) {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, T + a + k, 8);
+                    __builtin_memcpy(&y, T + c + k, 8);
+                    if (x != y) { sm = false; break; }
+                }
+                if (sm) {
+                    const uint32_t at = atomicAdd(&g_cand_dbg[0], 1u);
+                    if (at < 15) { g_cand_dbg[1 + 4 * at] = b; g_cand_dbg[2 + 4 * at] = r; g_cand_dbg[3 + 4 * at] = a; g_cand_dbg[4 + 4 * at] = c; }
+                }
+            }
+        }
+#endif
+        if (r > 0 && (cur & SA_CAND)) {
             const uint32_t prev = SA[r - 1];                   // (a neighbour may have set the mark in it already)
-            const uint32_t a = prev & ~GRP_SAME, c = cur & ~GRP_SAME;
+            const uint32_t a = prev & ~(GRP_SAME | SA_CAND), c = cur & ~(GRP_SAME | SA_CAND);
             if (max(a, c) + cap <= n) {                        // a suffix shorter than the cap shares less than the cap with anybody
                 same = true;
                 for (uint32_t k = 0; k < cap; k += 8) {
@@ -895,8 +919,8 @@ __global__ __launch_bounds__(GRP_NT) void k_grp_keys(uint32_t n, uint32_t *__res
     for (uint32_t w = 0; w < (tid >> 6); w++) gid += s_c[w];
     gid += (uint32_t)__popcll(bal & ((2ull << (tid & 63)) - 1ull));       // ... and up to this row: the row's group, counted from 1
     if (r < n) {
-        SA[r] = v & ~GRP_SAME;
-        key[(size_t)b * nmax + r] = ((uint64_t)gid << VAL_BITS) | (uint64_t)(v & ~GRP_SAME);
+        SA[r] = v & ~(GRP_SAME | SA_CAND);
+        key[(size_t)b * nmax + r] = ((uint64_t)gid << VAL_BITS) | (uint64_t)(v & ~(GRP_SAME | SA_CAND));
     }
     if (blockIdx.x == 0 && tid == 0) cnt[b] = n;
 }
@@ -1340,3 +1364,12 @@ hipError_t sa_export(hipStream_t st, const uint32_t *sa, uint32_t n, uint32_t *o
 }
 
 } // namespace glc
+#ifdef GLC_DEBUG_CAND
+extern "C" int glcDebugCand(unsigned int *out64, int reset)
+{
+    static unsigned int z[64];
+    if (out64 && hipMemcpyFromSymbol(out64, HIP_SYMBOL(glc::g_cand_dbg), 256) != hipSuccess) return 0;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(glc::g_cand_dbg), z, 256) != hipSuccess) return 0;
+    return 1;
+}
+#endif

@@ -28,6 +28,8 @@ constexpr uint32_t FS_LCP_CAP = 512;             // suffix comparisons and the s
 #define GLC_SS_TOL_CAP 128
 #endif
 constexpr uint32_t SS_TOL_CAP = GLC_SS_TOL_CAP;  // ... and in the sample sorter's tolerant form STOP behind this many: prefix doubling takes over from there (a multiple of 8)
+constexpr uint32_t SA_CAND = 0x40000000u;         // tolerant form, in the rows of s.sa: this row may share SS_TOL_CAP symbols with the row before it (it was still in a
+                                                  // run at that depth, or it is a bucket's first row); every other row was told from its neighbours by fewer
 #ifndef GLC_SS_LONG
 #define GLC_SS_LONG 256
 #endif
