@@ -275,16 +275,16 @@ __device__ __forceinline__ bool fs_suffix_less(const uint8_t *T, uint32_t n, uin
 // of suffixes under one code).  sp16[k] / wtxt[8 .. 16): the NEXT 8 bytes, the word's still in the staged tile -- log lines
 // share more than 8 bytes with the splitters around them all the time ("2026-09-28T12:3", " host-17 svc-"), and every such
 // tie was a walk through the text by one lane with its wave waiting: 2.1 of the kernel's 3.3 ms per 256 log blocks.
-__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t *sp8, const uint64_t *sp16, const uint16_t *cell,
+// `pending` (k_fs_part<true>'s first go over a thread's words): where the search would have to WALK through the text -- word and
+// splitter agree in code and in 16 text bytes: one lane in twenty on text, and its wave waits a chain of scattered loads for it,
+// eight times per tile -- it stops instead and hands back its interval (*pending = 1 << 31 | hi << 10 | lo); the walks of a
+// tile are then taken together, a lane each (ss_search from that interval on, pending = nullptr).
+__device__ __forceinline__ uint32_t ss_search(const uint64_t *sp, const uint64_t *sp8, const uint64_t *sp16, uint32_t lo, uint32_t hi,
                                               uint64_t w, uint64_t w8, const uint8_t *wtxt, const uint8_t *T, uint32_t n,
-                                              bool *deep, bool tol)
+                                              bool *deep, bool tol, uint32_t *pending)
 {
     const uint64_t cw = w >> 28;
     const uint32_t iw = (uint32_t)(w >> 8) & 0xFFFFFu;
-    // the splitters whose code starts with the same 12 bits are the only ones to look at (cell[x] = first splitter,
-    // counted from 1, whose leading 12 code bits are >= x): mostly none or one
-    const uint32_t x = (uint32_t)(cw >> 24);
-    uint32_t lo = (uint32_t)cell[x] - 1u, hi = cell[x + 1];    // the answer is in [lo, hi): splitter[lo] <= w < splitter[hi]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         const uint64_t sw = sp[mid], cs = sw >> 28;
@@ -301,12 +301,26 @@ __device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t
                 for (int t = 8; t < 16; t++) w16 = (w16 << 8) | wtxt[t];
                 const uint64_t s16 = sp16[mid];
                 if (s16 != w16) le = s16 < w16;
-                else le = !fs_suffix_less<true>(T, n, iw, is, deep, 16, tol);
+                else {
+                    if (pending) { *pending = 0x80000000u | (hi << 10) | lo; return lo; }
+                    le = !fs_suffix_less<true>(T, n, iw, is, deep, 16, tol);
+                }
             }
         }
         if (le) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+__device__ __forceinline__ uint32_t ss_bucket(const uint64_t *sp, const uint64_t *sp8, const uint64_t *sp16, const uint16_t *cell,
+                                              uint64_t w, uint64_t w8, const uint8_t *wtxt, const uint8_t *T, uint32_t n,
+                                              bool *deep, bool tol, uint32_t *pending = nullptr)
+{
+    // the splitters whose code starts with the same 12 bits are the only ones to look at (cell[x] = first splitter,
+    // counted from 1, whose leading 12 code bits are >= x): mostly none or one
+    const uint32_t x = (uint32_t)(w >> 52);
+    const uint32_t lo = (uint32_t)cell[x] - 1u, hi = cell[x + 1];    // the answer is in [lo, hi): splitter[lo] <= w < splitter[hi]
+    return ss_search(sp, sp8, sp16, lo, hi, w, w8, wtxt, T, n, deep, tol, pending);
 }
 
 template <bool SPLIT>
@@ -323,6 +337,10 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     __shared__ uint64_t s_w[FSP_TILE];
     __shared__ uint32_t s_tmp[FSP_NT / 64 + 1];
     __shared__ uint16_t s_bk[SPLIT ? FSP_TILE : 1];            // (SPLIT) bucket of the word at a position: not in the word's top bits there
+    constexpr uint32_t NDEF = SPLIT ? 512 : 1;                 // (SPLIT) searches of a tile that stopped before a walk through the text
+    __shared__ uint64_t s_dw[NDEF];                            // ... their words
+    __shared__ uint32_t s_dl[NDEF];                            // ... tile position : 12 | hi : 10 | lo : 10, then bucket << 16 | rank
+    __shared__ uint32_t s_dn;
     __shared__ uint32_t s_flagged;
     // the symbol table and the staged text are dead before the first word is bucketed: they live inside s_w
     // (38 KB instead of 44 KB of LDS: 4 workgroups per CU instead of 3)
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     // SPLIT: given up while sampling, no splitters to search; otherwise: flagged up front as text-like (k_fs_tables), or
     // by a tile of this launch whose bucket overflowed -- the block is another sorter's either way.  One read by one
     // thread (other tiles of this launch may flag the block meanwhile), looked at behind the staging barrier below.
-    if (tid == 0) s_flagged = flag[b];
+    if (tid == 0) { s_flagged = flag[b]; s_dn = 0; }
     const uint8_t *T = text + (size_t)b * stride;
     uint64_t *s_split = s_w + 1024;                            // (SPLIT) behind the table and the staged text, dead with them
     uint16_t *s_cell = reinterpret_cast<uint16_t *>(s_w + 1024 + FS_MAXNB);
@@ -415,13 +433,47 @@ __global__ __launch_bounds__(FSP_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
             const uint32_t d0 = (o0 & 3) ? __builtin_amdgcn_alignbyte(by4[(o0 >> 2) + 1], by4[o0 >> 2], o0 & 3) : by4[o0 >> 2];
             const uint32_t d1 = (o1 & 3) ? __builtin_amdgcn_alignbyte(by4[min((o1 >> 2) + 1, 3u)], by4[o1 >> 2], o1 & 3) : by4[o1 >> 2];
             const uint64_t w8 = ((uint64_t)__builtin_bswap32(d0) << 32) | __builtin_bswap32(d1);
-            bk = gi < n ? ss_bucket(s_split, s_split8, s_split16, s_cell, w[j], w8, s_txt + k0 + j + 1, T, n, &deep, tol) : 0u;
+            uint32_t pend = 0;
+            bk = gi < n ? ss_bucket(s_split, s_split8, s_split16, s_cell, w[j], w8, s_txt + k0 + j + 1, T, n, &deep, tol, &pend) : 0u;
             if (deep && !tol) atomicOr(&flag[b], 2u);
+            if (pend) {
+                const uint32_t at = atomicAdd(&s_dn, 1u);
+                if (at < NDEF) {
+                    s_dw[at] = w[j];
+                    s_dl[at] = ((k0 + j) << 20) | (pend & 0xFFFFFu);
+                    br[j] = 0x80000000u | at;                  // (the bucket and the rank come with the tile's walks, below)
+                    continue;
+                }
+                // (no room on the list: walked here and now)
+                bk = ss_search(s_split, s_split8, s_split16, pend & 0x3FFu, (pend >> 10) & 0x3FFu, w[j], w8, s_txt + k0 + j + 1, T, n, &deep, tol, nullptr);
+                if (deep && !tol) atomicOr(&flag[b], 2u);
+            }
         } else bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
         br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
         if (!SPLIT && j == 0 && gi == 0) zero_bucket[b] = bk;  // where the word of suffix 0 goes: k_fs_sort_bwt looks for the BWT index there only
     }
 #undef FS_BYTE
+    if (SPLIT) {
+        // the tile's walks, a lane each
+        __syncthreads();
+        const uint32_t nd = min(s_dn, NDEF);
+        for (uint32_t e = tid; e < nd; e += FSP_NT) {
+            const uint32_t dl = s_dl[e], k = dl >> 20;
+            const uint64_t ww = s_dw[e];
+            const uint8_t *wt = s_txt + k + 1;                 // the suffix's first 16 text bytes, still staged
+            uint64_t w8 = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) w8 = (w8 << 8) | wt[t];
+            bool deep = false;
+            const uint32_t bk = ss_search(s_split, s_split8, s_split16, dl & 0x3FFu, (dl >> 10) & 0x3FFu, ww, w8, wt, T, n, &deep, tol, nullptr);
+            if (deep && !tol) atomicOr(&flag[b], 2u);
+            s_dl[e] = (bk << 16) | atomicAdd(&s_cnt[bk], 1u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FSP_ITEMS; j++)
+            if (br[j] & 0x80000000u) br[j] = s_dl[br[j] & 0x7FFFFFFFu];
+    }
     __syncthreads();
     {
         const uint32_t c = tid < FS_MAXNB ? s_cnt[tid] : 0u;
