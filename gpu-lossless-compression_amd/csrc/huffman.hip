@@ -193,7 +193,20 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
     const uint32_t b = blockIdx.y, tid = threadIdx.x;
     if (only && !only[b]) return;
     if (blockIdx.x * HP_SUBS * HUFF_BLOCK >= n) return;
-    for (uint32_t i = tid; i < 257; i += 256) s_cl[i] = make_uint2(codes[(size_t)b * 257 + i], lens[(size_t)b * 257 + i]);
+    bool mylong = false;
+    for (uint32_t i = tid; i < 257; i += 256) {
+        const uint2 cl1 = make_uint2(codes[(size_t)b * 257 + i], lens[(size_t)b * 257 + i]);
+        s_cl[i] = cl1;
+        mylong |= cl1.y > 14;
+    }
+    // No code of the block longer than 14 bits (Zipf bytes: 5 .. 13): two symbols' codes make ONE of up to 28 bits before the merge,
+    // which then takes 8 steps instead of 16 (GLC_HP_NO_PAIRS: A/B)
+#ifdef GLC_HP_NO_PAIRS
+    const bool pairs = false;
+    (void)mylong;
+#else
+    const bool pairs = __syncthreads_or((int)mylong) == 0;     // (uniform)
+#endif
     const uint64_t base = block_off ? block_off[b] : 0ull;
     for (uint32_t sub = blockIdx.x * HP_SUBS; sub < (blockIdx.x + 1) * HP_SUBS; sub++) {
         const uint32_t lo = sub * HUFF_BLOCK;
@@ -233,6 +246,21 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
         // needed a variable-length mask and a branch per symbol: ~25 VALU per symbol against ~12.  Every symbol ORing its own
         // code into the two words it spans -- no "full" test at all -- measured 0.72 against 0.71 ms per GiB: not this.)
         uint32_t wi = start >> 5, fill = start & 31, hi = 0;
+        if (pairs) {
+#pragma unroll
+            for (int j = 0; j < SPT; j += 2) {
+                const uint32_t ln = cl[j].y + cl[j + 1].y;         // <= 28
+                const uint32_t cd = (cl[j].x << cl[j + 1].y) | cl[j + 1].x;
+                const uint64_t V = (uint64_t)cd << ((64u - fill - ln) & 63u);
+                hi |= (uint32_t)(V >> 32);
+                const uint32_t nf = fill + ln;
+                const bool full = nf >= 32;
+                if (full) atomicOr(&s_words[wi], hi);
+                wi += full ? 1u : 0u;
+                hi = full ? (uint32_t)V : hi;
+                fill = nf & 31u;
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             const uint32_t ln = cl[j].y;                       // 0 (and code 0) past the end of the block: a no-op
@@ -244,6 +272,7 @@ __global__ __launch_bounds__(256) void k_huff_pack(const uint8_t *__restrict__ m
             wi += full ? 1u : 0u;
             hi = full ? (uint32_t)V : hi;
             fill = nf & 31u;
+        }
         }
         if (fill > 0 && mybits > 0) atomicOr(&s_words[wi], hi);
         __syncthreads();
