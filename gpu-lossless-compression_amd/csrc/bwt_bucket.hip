@@ -1463,10 +1463,15 @@ constexpr uint32_t SS_NPIV = 64, SS_NBIN = 2 * SS_NPIV + 1;
 #define GLC_SS_NPL 4
 #endif
 constexpr uint32_t SS_NPL = GLC_SS_NPL, SS_NPIV0 = 64 * SS_NPL; // first cut: 256 pivots
-// shares of a bucket's positions handed out to the waves (two per wave).  A share is what a wave cuts into windows, so it
-// should hold at least one full window: with 64 shares of ~32 positions each window filled an eighth of the wave's 256
-// slots and k_ss_windows took 8.0 ms per 256 text blocks; 32 / 16 / 8 / 4 shares: 6.6 / 5.8 / 5.4 / 5.3 ms.
-constexpr uint32_t SS_SHARES = 8;
+// shares of a bucket's positions handed out to the waves (one per wave).  A share is what a wave cuts into windows, so it
+// should hold several full windows: with 64 shares of ~32 positions each window filled an eighth of the wave's 256
+// slots and k_ss_windows took 8.0 ms per 256 text blocks; 32 / 16 / 8 / 4 shares: 6.6 / 5.8 / 5.4 / 5.3 ms (7-byte rounds).
+// With the 14-byte rounds (shares x waves per bucket, whole text256 encode): 16x4 13.84 ms, 8x4 13.43, 8x2 13.51, 8x8 13.50,
+// 4x4 13.28, 4x2 13.27, 2x2 13.20, 3x3 13.16 (profiles/r05_dissect.md).
+#ifndef GLC_SS_SHARES
+#define GLC_SS_SHARES 3
+#endif
+constexpr uint32_t SS_SHARES = GLC_SS_SHARES;
 constexpr uint32_t SS_WIN = 256;                               // positions a wave finishes at a time (4 per lane)
 constexpr uint32_t SSL_SMALL = GLC_SSL_SMALL;                           // k_ss_long: members of a "small" long bin
 // (SS_LONG, glc_internal.h: runs longer than that are cut with pivots by k_ss_long; shorter ones are counted out in the windows)
@@ -1853,7 +1858,10 @@ __global__ __launch_bounds__(NT) void k_ss_long(const uint8_t *__restrict__ text
     }
 }
 
-constexpr int SSW_PER_BUCKET = 4;                              // one-wave workgroups per bucket; wave w takes shares w, w + 4, ...
+#ifndef GLC_SSW_PER_BUCKET
+#define GLC_SSW_PER_BUCKET 3
+#endif
+constexpr int SSW_PER_BUCKET = GLC_SSW_PER_BUCKET;             // one-wave workgroups per bucket; wave w takes shares w, w + SSW_PER_BUCKET, ...
 
 // a run descriptor whose positions still have to be ordered: more than one member, and not left as it is (SS_CAPPED)
 template <bool TOL>
