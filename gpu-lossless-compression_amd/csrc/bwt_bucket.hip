@@ -230,6 +230,15 @@ __device__ __forceinline__ uint64_t fs_load_be64(const uint8_t *p)
     return __builtin_bswap64(x);
 }
 
+// 16 bytes at any address as two big-endian numbers: ONE unaligned 16-byte load
+__device__ __forceinline__ void fs_load_be128(const uint8_t *p, uint64_t &hi, uint64_t &lo)
+{
+    uint64_t x[2];
+    __builtin_memcpy(x, p, 16);
+    hi = __builtin_bswap64(x[0]);
+    lo = __builtin_bswap64(x[1]);
+}
+
 // suffix a < suffix b ?  (a != b; the shorter of two suffixes that agree to the end of one is the smaller)
 // tol (the sample sorter's second form, for blocks with repeats deeper than its cap: see ss_build): two suffixes that
 // agree in their first SS_TOL_CAP + 8 bytes are ordered by their POSITIONS -- a total order that every comparison of the
@@ -1267,8 +1276,8 @@ __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__res
 // Same words, same slots, same outputs as the first tier; only very deep repeats are left to the general sorter.
 #ifdef GLC_SS_CLOCKS
 // experiment builds only (tools/exp/ss_clocks.py): s_memrealtime ticks (100 MHz) per phase, summed over thread 0 of every
-// workgroup of k_ss_cut ([0, 8)) and over every wave of k_ss_windows ([16, 24)); [8] / [24] count them
-__device__ unsigned long long g_ss_clk[256][32];           // 256 copies: the adds of a million workgroups do not queue on 32 addresses
+// workgroup of k_ss_cut ([0, 8)) and of k_ss_sample ([32, 40)) and over every wave of k_ss_windows ([16, 24)); [8] / [24] / [40] count them
+__device__ unsigned long long g_ss_clk[256][48];           // 256 copies: the adds of a million workgroups do not queue on 32 addresses
 #define SS_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); clk_[k] += t_ - clk_t_; clk_t_ = t_; } } while (0)
 #define SS_CLK_BEGIN() unsigned long long clk_[8] = {}, clk_t_ = __builtin_amdgcn_s_memrealtime()
 #define SS_CLK_END(base) do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) if (clk_[k_]) atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + k_], clk_[k_]); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + 8], 1ull); } } while (0)
@@ -1280,12 +1289,25 @@ __device__ unsigned long long g_ss_clk[256][32];           // 256 copies: the ad
 constexpr int SSA_NT = 1024;                                   // k_ss_sample: threads
 constexpr uint32_t SS_PER_BUCKET = 32, SS_MAXS = FS_MAXNB * SS_PER_BUCKET;
 constexpr uint32_t SS_L0_CAP = 1024;                           // longest splitter prefix skipped at once
+#ifndef GLC_SSA_SLOTS
+#define GLC_SSA_SLOTS 4
+#endif
+constexpr int SSA_SLOTS = GLC_SSA_SLOTS;                       // k_ss_sample: members of a long run of equal codes a lane holds
+constexpr uint32_t SSA_LONG_CAP = 64u * SSA_SLOTS;             // ... the longest run ordered that way
+constexpr uint32_t SSA_SLAB = 32, SSA_WIN = 120;               // ... runs that start in SSA_SLAB places and end within SSA_WIN are ordered together
 
 __device__ __forceinline__ uint64_t fs_code_at(const uint2 *tab, const uint8_t *T, uint32_t n, uint32_t i)
 {
     uint2 e[SS_DEPTH];
+    if (SS_DEPTH <= 8 && i + 8 <= n) {                         // (one load for the symbols)
+        uint64_t x;
+        __builtin_memcpy(&x, T + i, 8);
 #pragma unroll
-    for (int k = 0; k < SS_DEPTH; k++) e[k] = i + k < n ? tab[T[i + k]] : make_uint2(0u, 0u);
+        for (int k = 0; k < SS_DEPTH; k++) e[k] = tab[(x >> (8 * k)) & 0xFFu];
+    } else {
+#pragma unroll
+        for (int k = 0; k < SS_DEPTH; k++) e[k] = i + k < n ? tab[T[i + k]] : make_uint2(0u, 0u);
+    }
     uint32_t y = e[SS_DEPTH - 1].x;
 #pragma unroll
     for (int d = SS_DEPTH - 2; d >= 1; d--) y = e[d].x + __umulhi(e[d].y, y);
@@ -1314,8 +1336,9 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
 {
     constexpr bool tol = TOL;
     __shared__ uint64_t s_s[SS_MAXS];                          // 128 KB: one workgroup per CU
-    __shared__ uint2 s_tab[256];
-    __shared__ uint32_t s_deep, s_ties;
+    __shared__ ulonglong2 s_k[SSA_NT / 64][SSA_WIN];           // step (b): a wave's keys; before that, the code table
+    uint2 *s_tab = reinterpret_cast<uint2 *>(&s_k[0][0]);
+    __shared__ uint32_t s_deep, s_ties, s_work, s_big;
     const uint32_t b = list[blockIdx.x], tid = threadIdx.x, nb = 1u << nbl;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t S = min(nb * SS_PER_BUCKET, n);
@@ -1323,6 +1346,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     while (S2 < S) S2 <<= 1;
     if (tid < 256) s_tab[tid] = tab[(size_t)b * 256 + tid];
     if (tid == 0) { s_deep = 0; s_ties = 0; }
+    SS_CLK_BEGIN();
     __syncthreads();
     for (uint32_t j = tid; j < S2; j += SSA_NT) {
         uint64_t w = ~0ull;
@@ -1342,9 +1366,292 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         s_s[j] = w;
     }
     __syncthreads();
+    SS_CLK(0);                                                 // samples drawn
+#ifndef GLC_SSA_NETWORK_ONLY
+    // (a) the words as plain integers: (code, position).  No text is read: a stage is LDS traffic only.
+    for (uint32_t k = 2; k <= S2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < S2 / 2; t += SSA_NT) {
+                const uint32_t low = t & (j - 1), i = ((t - low) << 1) + low, q = i + j;
+                const uint64_t a = s_s[i], c = s_s[q];
+                if (((i & k) == 0) ? c < a : a < c) { s_s[i] = c; s_s[q] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    SS_CLK(1);                                                 // integer sort
+    // (b) runs of equal codes are ordered by the text, wave by wave.  A wave takes the runs that START in a slab of 32 places, all
+    // of them at once (a run at a time was a chain of ~150 memory round trips per wave), as one window of up to 120 places; at the
+    // start the sub-runs [a, b) are the runs and every member stands at its place.  A round gathers 16 text bytes per member still
+    // tied, puts the keys at the members' places in LDS (16 B x 120 per wave: what is left beside the samples), and every member
+    // walks over the other places of its sub-run -- all members at once, as many steps as the longest sub-run of the window is
+    // long: keys below it, keys equal, equal ones standing before it -> its new sub-run and place, where it then moves (its
+    // position goes through the same LDS).  These are fs_suffix_less's 16-byte steps, so the order is the network's order; a
+    // window with a tied member whose next 16 bytes come within 4 of the end of the text (where fs_suffix_less changes its step)
+    // is ranked pair by pair with fs_suffix_less itself.  A run that does not end inside its window is ordered on its own if it
+    // has up to 256 members (they stay in their lanes, four to a lane, and are counted member by member: key broadcast with
+    // v_readlane, three ballots per slot); a longer one (one code on 1.5 % of the samples: not text) sends the block to the
+    // network with the text comparisons in it, which works from any order -- decided before any of this work is done.
+    if (tid == 0) { s_work = 0; s_big = 0; }
+    __syncthreads();
+    {
+        bool big = false;
+        for (uint32_t j = tid; j + SSA_LONG_CAP < S; j += SSA_NT) big |= (s_s[j] >> 28) == (s_s[j + SSA_LONG_CAP] >> 28);
+        if (big) s_big = 1;
+    }
+    __syncthreads();
+    if (s_big == 0) {
+        const uint32_t lane = tid & 63u;
+        const uint64_t upto = ~0ull >> (63u - lane);           // bits <= lane
+        volatile uint32_t *vdeep = &s_deep;
+        ulonglong2 *s_kw = s_k[tid >> 6];                      // this wave's keys, at their members' places
+        uint2 *s_xw = reinterpret_cast<uint2 *>(s_kw);         // ... and, between two rounds, {position, sub-run} on the move
+        bool anydeep = false;
+        for (;;) {
+            uint32_t slab = 0;
+            if (lane == 0) slab = atomicAdd(&s_work, 1u);
+            slab = (uint32_t)__builtin_amdgcn_readfirstlane((int)slab);
+            const uint32_t w0 = slab * SSA_SLAB;
+            if (w0 >= S || (!tol && *vdeep)) break;
+            uint64_t wm[2], bd[2];
+            uint32_t idx[2], ab[2], run0[2];
+            bool in[2], unf[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                const uint32_t t = 64u * sl + lane, q = w0 + t;
+                const bool valid = t < SSA_WIN;
+                wm[sl] = valid && q < S ? s_s[q] : ~0ull;
+                const uint64_t before = valid && q > 0 && q <= S ? s_s[q - 1] >> 28 : ~0ull;
+                bd[sl] = __ballot(valid && (q >= S || q == 0 || before != (wm[sl] >> 28)));
+                idx[sl] = (uint32_t)(wm[sl] >> 8) & 0xFFFFFu;
+            }
+            const uint32_t qe = w0 + SSA_WIN;                  // the place behind the window: does a run go on there?
+            const bool open_end = qe < S && (s_s[qe] >> 28) == (s_s[qe - 1] >> 28);
+            uint32_t long_head = 0xFFFFu;
+#pragma unroll
+            for (int sl = 0; sl < 2; sl++) {
+                const uint32_t t = 64u * sl + lane, q = w0 + t;
+                uint32_t head = 0xFFFFu, end = 0xFFFFu;        // (places in the window; 0xFFFF: outside it)
+                const uint64_t hb = bd[sl] & upto, eb = bd[sl] & ~upto;
+                if (hb) head = 64u * sl + 63u - (uint32_t)__builtin_clzll(hb);
+                else if (sl == 1 && bd[0]) head = 63u - (uint32_t)__builtin_clzll(bd[0]);
+                if (eb) end = 64u * sl + (uint32_t)__builtin_ctzll(eb);
+                else if (sl == 0 && bd[1]) end = 64u + (uint32_t)__builtin_ctzll(bd[1]);
+                else if (!open_end) end = SSA_WIN;
+                const bool mine = t < SSA_WIN && q < S && head < SSA_SLAB;     // its run starts in this slab
+                const uint64_t lost = __ballot(mine && end == 0xFFFFu);
+                if (lost) long_head = (uint32_t)__builtin_amdgcn_readlane((int)head, __builtin_ctzll(lost));
+                in[sl] = mine && end != 0xFFFFu && end - head > 1;
+                unf[sl] = in[sl];
+                ab[sl] = head | (end << 16);
+                run0[sl] = ab[sl];
+            }
+            if (__any(in[0] || in[1])) {
+                uint32_t d = 0;
+                bool pairwise = false;
+                for (;;) {
+                    bool sh = false;
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) sh |= unf[sl] && idx[sl] + d + 20 > n;
+                    if (!__any(unf[0] || unf[1])) break;
+                    if (__any(sh)) { pairwise = true; break; }
+                    if (!tol && (d > FS_LCP_CAP || *vdeep)) { anydeep = true; break; }
+                    const bool by_place = tol && d > SS_TOL_CAP;   // tied up to the cap: by position (fs_suffix_less's rule)
+                    uint64_t kh[2], kl[2];
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) {
+                        kh[sl] = 0; kl[sl] = 0;
+                        if (by_place) kl[sl] = idx[sl];
+                        else if (unf[sl]) fs_load_be128(T + idx[sl] + d, kh[sl], kl[sl]);
+                        if (unf[sl]) s_kw[64u * sl + lane] = make_ulonglong2(kh[sl], kl[sl]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    uint32_t cl[2] = {0, 0}, ce[2] = {0, 0}, ct[2] = {0, 0};
+                    for (uint32_t dl = 1;; dl++) {
+                        bool act[2];
+#pragma unroll
+                        for (int sl = 0; sl < 2; sl++) act[sl] = unf[sl] && dl < (ab[sl] >> 16) - (ab[sl] & 0xFFFFu);
+                        if (!__any(act[0] || act[1])) break;
+#pragma unroll
+                        for (int sl = 0; sl < 2; sl++) {
+                            if (!act[sl]) continue;
+                            const uint32_t t = 64u * sl + lane, A = ab[sl] & 0xFFFFu, B = ab[sl] >> 16;
+                            uint32_t peer = t + dl;
+                            if (peer >= B) peer -= B - A;
+                            const ulonglong2 k = s_kw[peer];
+                            const bool eq = k.x == kh[sl] && k.y == kl[sl];
+                            cl[sl] += (k.x < kh[sl] || (k.x == kh[sl] && k.y < kl[sl])) ? 1u : 0u;
+                            ce[sl] += eq ? 1u : 0u;
+                            ct[sl] += (eq && peer < t) ? 1u : 0u;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++)
+                        if (unf[sl]) {
+                            const uint32_t A = (ab[sl] & 0xFFFFu) + cl[sl];
+                            s_xw[A + ct[sl]] = make_uint2(idx[sl], A | ((A + ce[sl] + 1u) << 16));
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++)
+                        if (unf[sl]) {
+                            const uint2 x = s_xw[64u * sl + lane];
+                            idx[sl] = x.x; ab[sl] = x.y;
+                            unf[sl] = (x.y >> 16) - (x.y & 0xFFFFu) > 1;
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (by_place) break;
+                    d += 16;
+                }
+                if (pairwise) {
+                    uint32_t cnt[2] = {0, 0};
+                    for (uint32_t j = 0; j < SSA_WIN; j++) {
+                        const int lj = (int)(j & 63u);
+                        const uint32_t ixj = (uint32_t)(j < 64 ? __builtin_amdgcn_readlane((int)idx[0], lj) : __builtin_amdgcn_readlane((int)idx[1], lj));
+                        const uint32_t rj = (uint32_t)(j < 64 ? __builtin_amdgcn_readlane((int)run0[0], lj) : __builtin_amdgcn_readlane((int)run0[1], lj));
+                        const uint32_t pj = (uint32_t)(j < 64 ? __builtin_amdgcn_readlane((int)(in[0] ? 1u : 0u), lj) : __builtin_amdgcn_readlane((int)(in[1] ? 1u : 0u), lj));
+                        if (!pj) continue;
+#pragma unroll 1
+                        for (int sl = 0; sl < 2; sl++) {
+                            const uint32_t mine = sl ? idx[1] : idx[0], myrun = sl ? run0[1] : run0[0];
+                            const bool have = sl ? in[1] : in[0];
+                            if (!have || myrun != rj || mine == ixj) continue;
+                            bool dp = false;
+                            const bool lt = fs_suffix_less<true>(T, n, ixj, mine, &dp, 0, tol);
+                            anydeep |= dp;
+                            if (sl) cnt[1] += lt ? 1u : 0u; else cnt[0] += lt ? 1u : 0u;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) if (in[sl]) s_xw[min((run0[sl] & 0xFFFFu) + cnt[sl], SSA_WIN - 1u)] = make_uint2(idx[sl], 0u);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++) if (in[sl]) idx[sl] = s_xw[64u * sl + lane].x;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (!tol && anydeep) *vdeep = 1;
+#pragma unroll
+                for (int sl = 0; sl < 2; sl++)
+                    if (in[sl]) s_s[w0 + 64u * sl + lane] = (wm[sl] & ~(uint64_t)0x0FFFFF00u) | ((uint64_t)idx[sl] << 8);
+            }
+            if (long_head == 0xFFFFu || (!tol && *vdeep)) continue;
+            // the run that leaves the window: up to SSA_LONG_CAP members, in their lanes for good
+            {
+                const uint32_t rs = w0 + long_head;
+                const uint64_t c = s_s[rs] >> 28;
+                uint64_t wl[SSA_SLOTS];
+                uint32_t ix[SSA_SLOTS], lab[SSA_SLOTS], pos[SSA_SLOTS];
+                bool lin[SSA_SLOTS], lunf[SSA_SLOTS];
+                uint32_t r = 0;
+#pragma unroll
+                for (int sl = 0; sl < SSA_SLOTS; sl++) {
+                    const uint32_t q = rs + 64u * sl + lane;
+                    wl[sl] = q < S ? s_s[q] : ~0ull;
+                    lin[sl] = q < S && (wl[sl] >> 28) == c;
+                    r += (uint32_t)__popcll(__ballot(lin[sl]));
+                    ix[sl] = (uint32_t)(wl[sl] >> 8) & 0xFFFFFu;
+                }
+                const int ns = (int)((r + 63u) >> 6);
+#pragma unroll
+                for (int sl = 0; sl < SSA_SLOTS; sl++) { lunf[sl] = lin[sl]; lab[sl] = r << 16; pos[sl] = lin[sl] ? 64u * sl + lane : 0xFFFFu; }
+                uint32_t d = 0;
+                bool pairwise = false;
+                for (;;) {
+                    bool sh = false, any = false;
+#pragma unroll
+                    for (int sl = 0; sl < SSA_SLOTS; sl++) { sh |= lunf[sl] && ix[sl] + d + 20 > n; any |= lunf[sl]; }
+                    if (!__any(any)) break;
+                    if (__any(sh)) { pairwise = true; break; }
+                    if (!tol && (d > FS_LCP_CAP || *vdeep)) { anydeep = true; break; }
+                    const bool by_place = tol && d > SS_TOL_CAP;
+                    uint64_t kh[SSA_SLOTS], kl[SSA_SLOTS];
+#pragma unroll
+                    for (int sl = 0; sl < SSA_SLOTS; sl++) {
+                        kh[sl] = 0; kl[sl] = 0;
+                        if (by_place) kl[sl] = ix[sl];
+                        else if (lunf[sl]) fs_load_be128(T + ix[sl] + d, kh[sl], kl[sl]);
+                    }
+                    uint32_t nab[SSA_SLOTS], npos[SSA_SLOTS];
+#pragma unroll
+                    for (int si = 0; si < SSA_SLOTS; si++) {
+                        nab[si] = lab[si]; npos[si] = pos[si];
+                        if (si >= ns) continue;
+                        uint64_t todo = __ballot(lunf[si]);
+                        while (todo) {
+                            const int li = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            const uint32_t AB = (uint32_t)__builtin_amdgcn_readlane((int)lab[si], li), P = (uint32_t)__builtin_amdgcn_readlane((int)pos[si], li);
+                            const uint64_t KH = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kh[si] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kh[si], li);
+                            const uint64_t KL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kl[si] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kl[si], li);
+                            const uint32_t A = AB & 0xFFFFu, B = AB >> 16;
+                            uint32_t cl = 0, ce = 0, ct = 0;
+#pragma unroll
+                            for (int sl = 0; sl < SSA_SLOTS; sl++) {
+                                if (sl >= ns) continue;
+                                const bool inr = pos[sl] >= A && pos[sl] < B;
+                                const bool eq = inr && kh[sl] == KH && kl[sl] == KL;
+                                const bool lt = inr && (kh[sl] < KH || (kh[sl] == KH && kl[sl] < KL));
+                                cl += (uint32_t)__popcll(__ballot(lt));
+                                ce += (uint32_t)__popcll(__ballot(eq));
+                                ct += (uint32_t)__popcll(__ballot(eq && pos[sl] < P));
+                            }
+                            if ((int)lane == li) { nab[si] = (A + cl) | ((A + cl + ce) << 16); npos[si] = A + cl + ct; }
+                        }
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < SSA_SLOTS; sl++) { lab[sl] = nab[sl]; pos[sl] = npos[sl]; lunf[sl] = lunf[sl] && (lab[sl] >> 16) - (lab[sl] & 0xFFFFu) > 1; }
+                    if (by_place) break;
+                    d += 16;
+                }
+                if (pairwise) {
+                    uint32_t cnt[SSA_SLOTS];
+#pragma unroll
+                    for (int sl = 0; sl < SSA_SLOTS; sl++) cnt[sl] = 0;
+                    for (uint32_t j = 0; j < r; j++) {
+                        uint32_t ixj = 0;
+#pragma unroll
+                        for (int sl = 0; sl < SSA_SLOTS; sl++) if ((int)(j >> 6) == sl) ixj = (uint32_t)__builtin_amdgcn_readlane((int)ix[sl], (int)(j & 63u));
+#pragma unroll 1
+                        for (int sl = 0; sl < ns; sl++) {
+                            uint32_t mine = 0;
+                            bool have = false;
+#pragma unroll
+                            for (int v = 0; v < SSA_SLOTS; v++) if (v == sl) { mine = ix[v]; have = lin[v]; }
+                            if (!have || mine == ixj) continue;
+                            bool dp = false;
+                            const bool lt = fs_suffix_less<true>(T, n, ixj, mine, &dp, 0, tol);
+                            anydeep |= dp;
+#pragma unroll
+                            for (int v = 0; v < SSA_SLOTS; v++) if (v == sl) cnt[v] += lt ? 1u : 0u;
+                        }
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < SSA_SLOTS; sl++) pos[sl] = min(cnt[sl], r - 1u);
+                }
+                if (!tol && anydeep) *vdeep = 1;
+#pragma unroll
+                for (int sl = 0; sl < SSA_SLOTS; sl++) if (lin[sl]) s_s[rs + pos[sl]] = wl[sl];
+            }
+        }
+        if (!tol && anydeep) s_deep = 1;
+    }
+    __syncthreads();
+    const bool ranked = s_big == 0;
+    SS_CLK(3);                                                 // runs ordered
+#else
+    const bool ranked = false;
+#endif
     uint32_t ties_before = 0;                                  // (tolerant form) ties counted up to the last stage
     bool many = false;
-    for (uint32_t k = 2; k <= S2; k <<= 1) {
+    for (uint32_t k = 2; !ranked && k <= S2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < S2 / 2; t += SSA_NT) {
                 const uint32_t low = t & (j - 1), i = ((t - low) << 1) + low, q = i + j;
@@ -1365,7 +1672,8 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         }
         if (s_deep || many) break;
     }
-    if (s_deep || many) { if (tid == 0) atomicOr(&flag[b], 2u); return; }
+    SS_CLK(5);                                                 // the network with text comparisons (when it runs)
+    if (s_deep || many) { if (tid == 0) atomicOr(&flag[b], 2u); SS_CLK_END(32); return; }
     if (tol) {
         // the tolerant form is for blocks with deep repeats INSIDE otherwise ordinary data.  Where a quarter of the
         // neighbouring samples agree beyond the cap (periodic data, a block made of copies) nearly every suffix would be left
@@ -1420,6 +1728,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         }
         l0_out[(size_t)b * FS_MAXNB + k] = l0;
     }
+    SS_CLK(6);                                                 // tolerant check, splitters, l0
     // cell[x] = first splitter (counted from 1) whose leading 12 code bits are >= x; nb if there is none
     for (uint32_t x = tid; x < SS_CELLS + 2; x += SSA_NT) {
         uint32_t lo = 1, hi = nb;
@@ -1429,6 +1738,8 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         }
         cell[(size_t)b * (SS_CELLS + 2) + x] = (uint16_t)lo;
     }
+    SS_CLK(7);                                                 // cells
+    SS_CLK_END(32);
 }
 
 // 7 symbols from position i as 9-bit digits (symbol + 1; 0 behind the end of the block: the shorter suffix is smaller).
@@ -1866,15 +2177,6 @@ constexpr int SSW_PER_BUCKET = GLC_SSW_PER_BUCKET;             // one-wave workg
 // a run descriptor whose positions still have to be ordered: more than one member, and not left as it is (SS_CAPPED)
 template <bool TOL>
 __device__ __forceinline__ bool ss_undecided_t(uint32_t g) { return ((g >> 12) & 0xFFFu) - (g & 0xFFFu) > 1 && (!TOL || (g >> 24) != SS_CAPPED); }
-
-// 16 bytes at any address as two big-endian numbers: ONE unaligned 16-byte load
-__device__ __forceinline__ void fs_load_be128(const uint8_t *p, uint64_t &hi, uint64_t &lo)
-{
-    uint64_t x[2];
-    __builtin_memcpy(x, p, 16);
-    hi = __builtin_bswap64(x[0]);
-    lo = __builtin_bswap64(x[1]);
-}
 
 // A round here takes 14 text bytes (two steps of the run descriptors' unit) from ONE 16-byte gather per member: the kernel is
 // bound by the number of scattered accesses a CU takes (~6 cycles per lane access out of L2: 12 rounds x 62 members per wave
@@ -2326,12 +2628,12 @@ hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32
 } // namespace glc
 
 #ifdef GLC_SS_CLOCKS
-extern "C" int glcSsClocks(unsigned long long *out32, int reset)
+extern "C" int glcSsClocks(unsigned long long *out48, int reset)
 {
-    static unsigned long long h[256][32];
-    if (out32) {
+    static unsigned long long h[256][48];
+    if (out48) {
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(glc::g_ss_clk), sizeof(glc::g_ss_clk)) != hipSuccess) return 0;
-        for (int k = 0; k < 32; k++) { out32[k] = 0; for (int c = 0; c < 256; c++) out32[k] += h[c][k]; }
+        for (int k = 0; k < 48; k++) { out48[k] = 0; for (int c = 0; c < 256; c++) out48[k] += h[c][k]; }
     }
     if (reset) { for (auto &r : h) for (auto &x : r) x = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(glc::g_ss_clk), h, sizeof h) != hipSuccess) return 0; }
     return 1;

@@ -17,19 +17,20 @@ d_in = (bench.text_blocks_on_device(torch, dev, rows) if kind == "text256" else 
 L = glc.lib()
 L.glcSsClocks.argtypes = [C.c_void_p, C.c_int]
 cut = ["load words", "gather + sort samples", "merge pivots", "bin", "scan + scatter", "list long bins", "-", "write back"]
+smp = ["draw samples", "integer sort", "-", "runs ordered", "-", "text network", "tol check + splitters + l0", "cells"]
 win = ["prologue", "window words", "round setup", "gather", "count", "move + re-read", "rows", "-"]
 with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
     out = glc.compress_batch(plan, d_in, n, rows)
     plan.synchronize()
     for it in range(2):
-        buf = (C.c_ulonglong * 32)()
+        buf = (C.c_ulonglong * 48)()
         L.glcSsClocks(buf, 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         glc.compress_batch_into(plan, d_in, n, rows, out)
         plan.synchronize()
         t1 = time.perf_counter()
         L.glcSsClocks(buf, 0)
-        for base, names, what in ((0, cut, "k_ss_cut workgroup"), (16, win, "k_ss_windows wave")):
+        for base, names, what in ((0, cut, "k_ss_cut workgroup"), (16, win, "k_ss_windows wave"), (32, smp, "k_ss_sample workgroup")):
             tot = sum(buf[base:base + 8]); cnt = max(1, buf[base + 8])
             print("%s batch %.2f ms; %s: %d of them, %.2f us each: " % (kind, (t1 - t0) * 1e3, what, cnt, tot / cnt / 100.0) +
                   ", ".join("%s %.2f us" % (names[i], buf[base + i] / cnt / 100.0) for i in range(8)))
