@@ -1326,6 +1326,46 @@ __device__ __forceinline__ bool ss_word_less(uint64_t a, uint64_t b, const uint8
     return fs_suffix_less<true>(T, n, ia, ib, deep, 0, tol);
 }
 
+// k_ss_sample's integer sort, up to four stages of the bitonic network per trip through LDS.  The stages of merge level L (runs
+// of k = 2^L) pair words at distances j = k/2 .. 1; the ones with j = 2^SH .. 2^(SH+3) only pair words whose indices differ in
+// bits [SH, SH + 4), so a thread that holds the 16 words base + (a << SH), a = 0 .. 15, does them all in registers.  Windows of
+// index bits: [10, 14), [6, 10), [2, 6) and the two lowest bits (NBITS = 2, on 16 consecutive words); levels 1 .. 4 are one trip
+// on 16 consecutive words (FIRST).  33 trips for 16384 words instead of 105.  Words live at ssa_phys(index) during the sort --
+// low nibble XORed with bits 5 .. 8 -- so that lanes 128 bytes (16 consecutive words) or 512 bytes apart spread over the banks.
+__device__ __forceinline__ uint32_t ssa_phys(uint32_t e) { return e ^ ((e >> 5) & 15u); }
+
+template <int SH, int NBITS, bool FIRST>
+__device__ __forceinline__ void ssa_sort_pass(uint64_t *s, uint32_t tid, uint32_t klevel)
+{
+    asm volatile("" : "+v"(tid));                              // (the 16 addresses are made here, trip by trip: hoisted out of the level loop they spill)
+    const uint32_t base = (tid & ((1u << SH) - 1u)) | ((tid >> SH) << (SH + 4));
+    uint64_t v[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) v[a] = s[ssa_phys(base + ((uint32_t)a << SH))];
+#pragma unroll
+    for (int lk = (FIRST ? 1 : 0); lk <= (FIRST ? 4 : 0); lk++) {
+        const uint32_t k = FIRST ? (1u << lk) : klevel;
+#pragma unroll
+        for (int bit = NBITS - 1; bit >= 0; bit--) {
+            const uint32_t j = 1u << (SH + bit);
+            if (j >= k) continue;                              // (a stage of this window that the level does not have)
+#pragma unroll
+            for (int a = 0; a < 16; a++) {
+                if (a & (1 << bit)) continue;
+                const int c = a | (1 << bit);
+                const bool up = ((base + ((uint32_t)a << SH)) & k) == 0;
+                const uint64_t x = v[a], y = v[c];
+                const bool sw = (y < x) == up;                 // (equal words: the padding; swapped or not, the same)
+                v[a] = sw ? y : x;
+                v[c] = sw ? x : y;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 16; a++) s[ssa_phys(base + ((uint32_t)a << SH))] = v[a];
+    __syncthreads();
+}
+
 template <bool TOL>
 __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                       uint32_t nbl, const uint2 *__restrict__ tab,
@@ -1357,7 +1397,8 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
             // advances by 55 mod 64 from one stride to the next, the samples sit on a near-lattice of 119 / 55 bytes, and log
             // lines of ~88 bytes beat against it -- whole classes of suffixes under-sampled, a bucket of > 4032 words and the
             // block handed to the general sorter: 2 of 256 log blocks, max LCP 51, found with distinct blocks in bench.py.)
-            const uint32_t lo = (uint32_t)(((uint64_t)j * n) / S), hi = (uint32_t)(((uint64_t)(j + 1) * n) / S);
+            // (j n / S: S is a power of two, or n itself -- no 64-bit divisions)
+            const uint32_t lo = S == n ? j : (uint32_t)(((uint64_t)j * n) >> (nbl + 5)), hi = S == n ? j + 1 : (uint32_t)(((uint64_t)(j + 1) * n) >> (nbl + 5));
             uint32_t h = (j + 1u + seed * SS_MAXS) * 0x9E3779B1u;       // (seed: a second attempt draws other samples)
             h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
             const uint32_t i = lo + h % (hi - lo);
@@ -1368,8 +1409,39 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     __syncthreads();
     SS_CLK(0);                                                 // samples drawn
 #ifndef GLC_SSA_NETWORK_ONLY
-    // (a) the words as plain integers: (code, position).  No text is read: a stage is LDS traffic only.
+    // (a) the words as plain integers: (code, position).  No text is read.  A full sample (16384 words, 16 per thread) goes
+    // through the bitonic network up to four stages at a time: a thread takes the 16 words whose indices differ in four given
+    // bits and does every stage that pairs words across those bits in registers -- 33 trips through LDS instead of 105
+    // (ssa_sort_pass): 157 -> 78 us.
+    if (S2 == SS_MAXS) {
+#ifndef GLC_SSA_PLAIN_STAGES
+        uint64_t v[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = s_s[a * SSA_NT + tid];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 16; a++) s_s[ssa_phys(a * SSA_NT + tid)] = v[a];
+        __syncthreads();
+        ssa_sort_pass<0, 4, true>(s_s, tid, 0);                // levels 1 .. 4
+        for (int L = 5; L <= 14; L++) {
+            const uint32_t k = 1u << L;
+            if (L >= 11) ssa_sort_pass<10, 4, false>(s_s, tid, k);
+            if (L >= 7) ssa_sort_pass<6, 4, false>(s_s, tid, k);
+            ssa_sort_pass<2, 4, false>(s_s, tid, k);
+            ssa_sort_pass<0, 2, false>(s_s, tid, k);
+        }
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = s_s[ssa_phys(a * SSA_NT + tid)];
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 16; a++) s_s[a * SSA_NT + tid] = v[a];
+        __syncthreads();
+#endif
+    }
     for (uint32_t k = 2; k <= S2; k <<= 1) {
+#ifndef GLC_SSA_PLAIN_STAGES
+        if (S2 == SS_MAXS) break;
+#endif
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             for (uint32_t t = tid; t < S2 / 2; t += SSA_NT) {
                 const uint32_t low = t & (j - 1), i = ((t - low) << 1) + low, q = i + j;
