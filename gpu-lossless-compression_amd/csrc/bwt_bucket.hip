@@ -1280,10 +1280,12 @@ __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__res
 __device__ unsigned long long g_ss_clk[256][48];           // 256 copies: the adds of a million workgroups do not queue on 32 addresses
 #define SS_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); clk_[k] += t_ - clk_t_; clk_t_ = t_; } } while (0)
 #define SS_CLK_BEGIN() unsigned long long clk_[8] = {}, clk_t_ = __builtin_amdgcn_s_memrealtime()
+#define SS_COUNT(k) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_ss_clk[blockIdx.x & 255u][k], 1ull); } while (0)
 #define SS_CLK_END(base) do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) if (clk_[k_]) atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + k_], clk_[k_]); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + 8], 1ull); } } while (0)
 #else
 #define SS_CLK(k) do { } while (0)
 #define SS_CLK_BEGIN() do { } while (0)
+#define SS_COUNT(k) do { } while (0)
 #define SS_CLK_END(base) do { } while (0)
 #endif
 constexpr int SSA_NT = 1024;                                   // k_ss_sample: threads
@@ -1472,6 +1474,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
         if (big) s_big = 1;
     }
     __syncthreads();
+    if (tid == 0 && s_big) SS_COUNT(43);
     if (s_big == 0) {
         const uint32_t lane = tid & 63u;
         const uint64_t upto = ~0ull >> (63u - lane);           // bits <= lane
@@ -1581,6 +1584,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                     d += 16;
                 }
                 if (pairwise) {
+                    SS_COUNT(41);
                     uint32_t cnt[2] = {0, 0};
                     for (uint32_t j = 0; j < SSA_WIN; j++) {
                         const int lj = (int)(j & 63u);
@@ -1617,6 +1621,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
             if (long_head == 0xFFFFu || (!tol && *vdeep)) continue;
             // the run that leaves the window: up to SSA_LONG_CAP members, in their lanes for good
             {
+                SS_COUNT(42);
                 const uint32_t rs = w0 + long_head;
                 const uint64_t c = s_s[rs] >> 28;
                 uint64_t wl[SSA_SLOTS];

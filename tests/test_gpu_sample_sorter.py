@@ -111,6 +111,51 @@ def test_sample_sorter_block_sizes(glc, ctx, cuda, n):
         assert f2 == 0 and f1 <= 1
 
 
+def _text_with_word(n, seed, every, word=b"QZXJKVWY", tail=12):
+    """text with ONE 8-byte word (and `tail` random letters behind it) every `every` bytes on average: the samples that fall on it
+    share one code -- a run of 16384 * (1 / every) equal codes in k_ss_sample"""
+    rng = np.random.default_rng(seed)
+    x = datagen.text_bytes(n, seed=seed).copy()
+    at = np.sort(rng.choice((n - 64) // 32, size=n // every, replace=False)) * 32
+    w = np.frombuffer(word, dtype=np.uint8)
+    for o in at:
+        x[o:o + 8] = w
+        x[o + 8:o + 8 + tail] = rng.integers(97, 123, tail, dtype=np.uint8)
+    return x
+
+
+def _text_with_tail_copy(n, seed, length, src=12345):
+    """the block's last `length` bytes repeat an earlier stretch: samples in the tail tie with samples in the stretch up to the
+    END of the text (k_ss_sample: the pair-by-pair form of a window with a tied member near the end)"""
+    x = datagen.text_bytes(n, seed=seed).copy()
+    x[n - length:] = x[src:src + length]
+    return x
+
+
+@pytest.mark.parametrize("name,gen", [
+    ("word_every_90", lambda: _text_with_word(N, 41, 90)),        # a run of ~180 equal codes: ordered on its own, four to a lane
+    ("word_every_200", lambda: _text_with_word(N, 42, 200)),      # ~80: inside a window
+    ("word_every_40", lambda: _text_with_word(N, 43, 40, tail=20)),   # ~410: past the cap, the network with text comparisons
+    ("tail_copy_40", lambda: _text_with_tail_copy(N, 44, 40)),
+    ("tail_copy_300", lambda: _text_with_tail_copy(N, 45, 300)),
+    ("tail_copy_3000_log", lambda: np.concatenate([datagen.log_bytes(N - 3000, seed=46), datagen.log_bytes(N, seed=46)[5000:8000]])),
+    # a 100-byte phrase 40 times at the very end: samples of equal phase tie up to the end of the text, past the exact form's cap
+    # and (sorter mode 6) inside the tolerant form's
+    ("tail_phrase_x40", lambda: np.concatenate([datagen.text_bytes(N - 4000, seed=47), np.tile(datagen.text_bytes(100, seed=48), 40)])),
+])
+def test_sample_step_paths(glc, ctx, cuda, name, gen):
+    """k_ss_sample orders its samples in three ways (windows of runs, long runs, the network with text comparisons) and ranks a
+    window pair by pair when a tied member is near the end of the text: every one of them must give the same splitters' order"""
+    import torch
+    x = gen()
+    want, widx = O.bwt(x)
+    with glc.Plan(ctx, glc.CUDPP_BWT, N, rows=1) as plan:
+        for mode in (0, 4, 6):
+            plan.set_sorter(mode)
+            got, gidx = _bwt(glc, plan, torch, x)
+            assert int(gidx[0]) == widx and np.array_equal(got, want), "%s, sorter mode %d" % (name, mode)
+
+
 def test_sample_sorter_mixed_batch(glc, ctx, cuda):
     """one batch, all three tiers at work: every block must carry its own tier's result"""
     import torch
