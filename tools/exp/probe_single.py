@@ -5,5 +5,6 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 import torch
 glc = bench._load("glc_binding", os.path.join(ROOT, "gpu-lossless-compression_amd", "glc_binding.py"))
 dev = torch.device("cuda:0")
-d_in = bench.zipf_blocks_on_device(torch, dev, 1, 0, 1)
+kind = sys.argv[1] if len(sys.argv) > 1 else "zipf"
+d_in = bench.zipf_blocks_on_device(torch, dev, 1, 0, 1) if kind == "zipf" else bench.text_blocks_on_device(torch, dev, 1).view(-1)
 print(bench.leg_single_call(torch, glc, dev, d_in[:1 << 20], iters=50))

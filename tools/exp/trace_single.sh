@@ -1,8 +1,8 @@
 #!/bin/bash
 # timeline of ONE cudppCompress call with a rows = 1 plan: kernel names, start offsets and durations (rocprofv3 --kernel-trace)
-#   bash tools/exp/trace_single.sh
+#   bash tools/exp/trace_single.sh [zipf|text]
 cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/ts; timeout 300 rocprofv3 --kernel-trace -d /tmp/ts -o t -- python $GRAFT_REPO_ROOT/tools/exp/probe_single.py > /tmp/ts.log 2>&1
+rm -rf /tmp/ts; timeout 300 rocprofv3 --kernel-trace -d /tmp/ts -o t -- python $GRAFT_REPO_ROOT/tools/exp/probe_single.py ${1:-zipf} > /tmp/ts.log 2>&1
 tail -2 /tmp/ts.log
 python - <<PY
 import sqlite3, glob
