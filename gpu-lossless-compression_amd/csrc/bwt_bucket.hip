@@ -1281,11 +1281,13 @@ __device__ unsigned long long g_ss_clk[256][48];           // 256 copies: the ad
 #define SS_CLK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); clk_[k] += t_ - clk_t_; clk_t_ = t_; } } while (0)
 #define SS_CLK_BEGIN() unsigned long long clk_[8] = {}, clk_t_ = __builtin_amdgcn_s_memrealtime()
 #define SS_COUNT(k) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_ss_clk[blockIdx.x & 255u][k], 1ull); } while (0)
+#define SS_MAX(k, i) do { if (threadIdx.x == 0) atomicMax(&g_ss_clk[0][k], clk_[i]); } while (0)
 #define SS_CLK_END(base) do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) if (clk_[k_]) atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + k_], clk_[k_]); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][(base) + 8], 1ull); } } while (0)
 #else
 #define SS_CLK(k) do { } while (0)
 #define SS_CLK_BEGIN() do { } while (0)
 #define SS_COUNT(k) do { } while (0)
+#define SS_MAX(k, i) do { } while (0)
 #define SS_CLK_END(base) do { } while (0)
 #endif
 constexpr int SSA_NT = 1024;                                   // k_ss_sample: threads
@@ -1543,6 +1545,17 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     uint32_t cl[2] = {0, 0}, ce[2] = {0, 0}, ct[2] = {0, 0};
+                    // (a round in which every sub-run's keys are all equal -- the inside of a deep repeat, round after round up to
+                    //  the cap -- changes nothing: seen from one look at each member's successor)
+                    bool differs = false;
+#pragma unroll
+                    for (int sl = 0; sl < 2; sl++)
+                        if (unf[sl]) {
+                            const uint32_t t = 64u * sl + lane, A = ab[sl] & 0xFFFFu, B = ab[sl] >> 16;
+                            const ulonglong2 k = s_kw[t + 1 < B ? t + 1 : A];
+                            differs |= k.x != kh[sl] || k.y != kl[sl];
+                        }
+                    if (!__any(differs)) { if (by_place) break; d += 16; continue; }
                     for (uint32_t dl = 1;; dl++) {
                         bool act[2];
 #pragma unroll
@@ -1656,6 +1669,25 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                         if (by_place) kl[sl] = ix[sl];
                         else if (lunf[sl]) fs_load_be128(T + ix[sl] + d, kh[sl], kl[sl]);
                     }
+                    {   // (all tied members in ONE sub-run with ONE key -- the inside of a deep repeat -- : nothing to count)
+                        bool other = false;
+                        bool found = false;
+                        uint64_t FH = 0, FL = 0;
+                        uint32_t FAB = 0;
+#pragma unroll
+                        for (int sl = 0; sl < SSA_SLOTS; sl++) {
+                            const uint64_t mk = __ballot(lunf[sl]);
+                            if (!found && mk) {
+                                const int li = __builtin_ctzll(mk);
+                                FH = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kh[sl] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kh[sl], li);
+                                FL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kl[sl] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kl[sl], li);
+                                FAB = (uint32_t)__builtin_amdgcn_readlane((int)lab[sl], li);
+                                found = true;
+                            }
+                            other |= lunf[sl] && (kh[sl] != FH || kl[sl] != FL || lab[sl] != FAB);
+                        }
+                        if (!by_place && !__any(other)) { d += 16; continue; }
+                    }
                     uint32_t nab[SSA_SLOTS], npos[SSA_SLOTS];
 #pragma unroll
                     for (int si = 0; si < SSA_SLOTS; si++) {
@@ -1723,6 +1755,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     __syncthreads();
     const bool ranked = s_big == 0;
     SS_CLK(3);                                                 // runs ordered
+    SS_MAX(tol ? 45 : 44, 3);
 #else
     const bool ranked = false;
 #endif

@@ -14,6 +14,10 @@ dev = torch.device("cuda:0")
 n = 1 << 20
 bench._GLC = glc
 d_in = (bench.text_blocks_on_device(torch, dev, rows) if kind == "text256" else bench.log_buffers_on_device(torch, dev, rows)).view(-1)
+if kind == "logruns":                                          # pd_batch.py's kind: log lines with 1500 spaces and 9000 zero bytes inside
+    v = d_in.view(rows, n)
+    v[:, 200000:201500] = 32
+    v[:, 700000:709000] = 0
 L = glc.lib()
 L.glcSsClocks.argtypes = [C.c_void_p, C.c_int]
 cut = ["load words", "gather + sort samples", "merge pivots", "bin", "scan + scatter", "list long bins", "-", "write back"]
@@ -37,3 +41,5 @@ with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan
         r = max(1, buf[25])
         print("   rounds per wave %.2f; per round: summed wave-max run length of the 4 item loops %.1f, undecided positions %.1f, window %.1f positions"
               % (r / max(1, buf[24]), buf[26] / r, buf[27] / r, buf[28] / r))
+        print("   k_ss_sample: windows pair by pair %d, long runs %d, blocks to the network %d; slowest 'runs ordered' exact %.1f us, tolerant %.1f us"
+              % (buf[41], buf[42], buf[43], buf[44] / 100.0, buf[45] / 100.0))
