@@ -2367,7 +2367,7 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
                 for (uint32_t p = pos + lane; p < se; p += 64) {
                     const uint32_t v = (uint32_t)K[p] & (uint32_t)FS_LOW_MASK, idx = v >> 8;
                     if (O) O[p] = (uint8_t)v;
-                    if (SAo) SAo[p] = idx | SA_CAND;
+                    if (SAo) SAo[p] = idx | (p == pos ? SA_CAND : GRP_SAME);   // (see the rows written below)
                     if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
                 }
                 pos = se;
@@ -2517,7 +2517,15 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
                     //  l0 + 7 (st + 1): a round here advances the label with the decision, but a member alone in a bin BETWEEN two pivots
                     //  of k_ss_cut / k_ss_long keeps the run's label and differs somewhere in the NEXT seven symbols -- the hunt that
                     //  found it: two suffixes 131 and 132 symbols from the end of a block, cut apart at label 18 in some runs.)
-                    if (SAo) SAo[p] = idx | ((tol && (p == 0 || l0 + SS_STEP * ((g4[j] >> 24) + 1) >= SS_TOL_CAP)) ? SA_CAND : 0u);
+                    //  A member of a run left as it is agrees with the member before it in SS_TOL_MAXSTEP x 7 >= SS_TOL_CAP symbols: it
+                    //  continues that row's group for sure (GRP_SAME), and k_grp_flags need not read 2 x 128 bytes of text to find that
+                    //  out -- those full-length comparisons were most of its 0.72 ms per 64 partly deep blocks.
+                    uint32_t mark = 0;
+                    if (tol) {
+                        if ((g4[j] >> 24) == SS_CAPPED && p > (g4[j] & 0xFFFu)) mark = GRP_SAME;
+                        else if (p == 0 || l0 + SS_STEP * ((g4[j] >> 24) + 1) >= SS_TOL_CAP) mark = SA_CAND;
+                    }
+                    if (SAo) SAo[p] = idx | mark;
                     if (idx == 0 && d_index) d_index[b] = (int)(R0 + p);
                 }
             }

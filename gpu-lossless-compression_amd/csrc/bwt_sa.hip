@@ -818,7 +818,6 @@ __global__ void k_sa_export(const uint32_t *__restrict__ sa, uint32_t n, uint32_
 __device__ uint32_t g_cand_dbg[64];
 #endif
 constexpr uint32_t GRP_NT = 256;
-constexpr uint32_t GRP_SAME = 0x80000000u;                     // marks a row that continues its predecessor's group, in s.sa for a moment
 
 __global__ __launch_bounds__(GRP_NT) void k_grp_flags(const uint8_t *__restrict__ text, size_t text_stride, uint32_t n,
                                                       uint32_t *__restrict__ sa, uint32_t nmax, const uint32_t *__restrict__ list,
@@ -838,7 +837,7 @@ __global__ __launch_bounds__(GRP_NT) void k_grp_flags(const uint8_t *__restrict_
         // first row of a bucket); every other row it told from the row before by fewer than `cap` symbols.  (Looking at every
         // row -- two scattered 8-byte loads at least -- was 1.35 ms per 64 blocks, a tenth of the resumed path.)
 #ifdef GLC_DEBUG_CAND
-        if (r > 0 && !(cur & SA_CAND)) {                       // the check: would the full comparison have called this row a continuation?
+        if (r > 0 && !(cur & (SA_CAND | GRP_SAME))) {          // the check: would the full comparison have called this row a continuation?
             const uint32_t a = SA[r - 1] & ~(GRP_SAME | SA_CAND), c = cur & ~(GRP_SAME | SA_CAND);
             if (max(a, c) + cap <= n) {
                 bool sm = true;
@@ -855,7 +854,24 @@ __global__ __launch_bounds__(GRP_NT) void k_grp_flags(const uint8_t *__restrict_
             }
         }
 #endif
-        if (r > 0 && (cur & SA_CAND)) {
+#ifdef GLC_DEBUG_CAND
+        if (r > 0 && (cur & GRP_SAME)) {                       // the check: does a row marked up front really continue its group?
+            const uint32_t a = SA[r - 1] & ~(GRP_SAME | SA_CAND), c = cur & ~(GRP_SAME | SA_CAND);
+            bool sm = max(a, c) + cap <= n;
+            for (uint32_t k = 0; sm && k < cap; k += 8) {
+                uint64_t x, y;
+                __builtin_memcpy(&x, T + a + k, 8);
+                __builtin_memcpy(&y, T + c + k, 8);
+                sm = x == y;
+            }
+            if (!sm) {
+                const uint32_t at = atomicAdd(&g_cand_dbg[0], 1u);
+                if (at < 15) { g_cand_dbg[1 + 4 * at] = b | 0x80000000u; g_cand_dbg[2 + 4 * at] = r; g_cand_dbg[3 + 4 * at] = a; g_cand_dbg[4 + 4 * at] = c; }
+            }
+        }
+#endif
+        if (r > 0 && (cur & GRP_SAME)) same = true;            // (a member of a run the sample sorter left at the cap: marked there)
+        else if (r > 0 && (cur & SA_CAND)) {
             const uint32_t prev = SA[r - 1];                   // (a neighbour may have set the mark in it already)
             const uint32_t a = prev & ~(GRP_SAME | SA_CAND), c = cur & ~(GRP_SAME | SA_CAND);
             if (max(a, c) + cap <= n) {                        // a suffix shorter than the cap shares less than the cap with anybody
@@ -869,7 +885,7 @@ __global__ __launch_bounds__(GRP_NT) void k_grp_flags(const uint8_t *__restrict_
             }
         }
         head = !same;
-        if (same) atomicOr(&SA[r], GRP_SAME);                   // (atomic: the row's own thread only ever ORs this bit; readers mask it)
+        if (same && !(cur & GRP_SAME)) atomicOr(&SA[r], GRP_SAME);                   // (atomic: the row's own thread only ever ORs this bit; readers mask it)
     }
     const uint32_t cw = (uint32_t)__popcll(__ballot(head));
     if ((tid & 63) == 0) s_c[tid >> 6] = cw;

@@ -28,6 +28,7 @@ constexpr uint32_t FS_LCP_CAP = 512;             // suffix comparisons and the s
 #define GLC_SS_TOL_CAP 128
 #endif
 constexpr uint32_t SS_TOL_CAP = GLC_SS_TOL_CAP;  // ... and in the sample sorter's tolerant form STOP behind this many: prefix doubling takes over from there (a multiple of 8)
+constexpr uint32_t GRP_SAME = 0x80000000u;        // ... this row continues the group of the row before it (k_grp_flags' result; set up front for the members of a run left at the cap)
 constexpr uint32_t SA_CAND = 0x40000000u;         // tolerant form, in the rows of s.sa: this row may share SS_TOL_CAP symbols with the row before it (it was still in a
                                                   // run at that depth, or it is a bucket's first row); every other row was told from its neighbours by fewer
 #ifndef GLC_SS_LONG

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Hunt for rows that share the cap with their predecessor and go unmarked (library built with -DGLC_DEBUG_CAND)."""
+"""Hunt for rows that share the cap with their predecessor and go unmarked, and for rows marked as continuations up front (members
+of a run left at the cap) that do not share it (library built with -DGLC_DEBUG_CAND)."""
 import ctypes as C, importlib.util, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,6 +25,8 @@ with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_BWT, N, rows=4) as plan:
             print("iteration %d: %d unmarked rows that share the cap" % (it, buf[0]))
             for k in range(min(buf[0], 15)):
                 b, r, a, c = buf[1 + 4 * k: 5 + 4 * k]
+                pre, b = b >> 31, b & 0x7FFFFFFF                # (bit 31: a row marked GRP_SAME up front that does NOT share the cap)
+                if pre: print("   the next one: marked as a continuation up front, and is not")
                 xa, xc = blocks[b][a:a + 160], blocks[b][c:c + 160]
                 lcp = int(np.argmax(xa[:min(len(xa), len(xc))] != xc[:min(len(xa), len(xc))])) if not np.array_equal(xa[:min(len(xa), len(xc))], xc[:min(len(xa), len(xc))]) else min(len(xa), len(xc))
                 print("   block %d row %d: suffixes %d, %d (from the end: %d, %d), common prefix >= %d" % (b, r, a, c, N - a, N - c, lcp))
