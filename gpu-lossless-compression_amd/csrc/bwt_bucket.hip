@@ -2445,6 +2445,31 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
                 }
                 __builtin_amdgcn_wave_barrier();
                 SS_CLK(3);                                     // text gathered
+                if (tol) {
+                    // the inside of a deep repeat: every member's key equals its run's first -- places, words and runs stay as they
+                    // are, only the labels advance (the count below would find exactly that, quadratically, round after round up to
+                    // the cap: a 2000-byte phrase 64 times in a block is 2000 runs of 64 that stay whole for ten rounds).  Taken when
+                    // no run of the window changes; telling the runs apart (a byte per run in LDS, the count skipped member by member)
+                    // measured 1.69 against 1.71 ms per 64 partly deep blocks, not worth its two extra barriers per round.
+                    bool differs = false;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (mv[j]) {
+                            const ulonglong2 k = s_kw[lane + 64 * j], k0 = s_kw[(g4[j] & 0xFFFu) - pos];
+                            differs |= (k.x != k0.x) | (((k.y ^ k0.y) >> 16) != 0);
+                        }
+                    if (__ballot(differs) == 0) {
+                        und = false;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (mv[j]) {
+                                g4[j] = ss_run(g4[j] & 0xFFFu, (g4[j] >> 12) & 0xFFFu, (g4[j] >> 24) + step);
+                                und |= ss_undecided(g4[j]);
+                            }
+                        __builtin_amdgcn_wave_barrier();
+                        continue;
+                    }
+                }
                 // a member's new place = the smaller keys of its run; the place learns which slot comes to it
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
