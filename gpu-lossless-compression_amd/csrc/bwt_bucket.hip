@@ -1669,50 +1669,54 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                         if (by_place) kl[sl] = ix[sl];
                         else if (lunf[sl]) fs_load_be128(T + ix[sl] + d, kh[sl], kl[sl]);
                     }
-                    {   // (all tied members in ONE sub-run with ONE key -- the inside of a deep repeat -- : nothing to count)
-                        bool other = false;
+                    // counted class by class: the members of one sub-run with one key get their new sub-run and places together (the
+                    // key broadcast with v_readlane, two ballots per slot; equal keys keep their order, which inside a sub-run is the
+                    // order of the lanes: places are handed out that way from the start).  A deep repeat is ONE class round after
+                    // round, and two in the round in which a member reaches the end of the repeat -- member by member that round
+                    // cost 20 us for 140 members.
+                    uint32_t nab[SSA_SLOTS], npos[SSA_SLOTS];
+                    bool todo[SSA_SLOTS];
+#pragma unroll
+                    for (int sl = 0; sl < SSA_SLOTS; sl++) { nab[sl] = lab[sl]; npos[sl] = pos[sl]; todo[sl] = lunf[sl]; }
+                    for (;;) {
                         bool found = false;
-                        uint64_t FH = 0, FL = 0;
-                        uint32_t FAB = 0;
+                        uint64_t KH = 0, KL = 0;
+                        uint32_t AB = 0;
 #pragma unroll
                         for (int sl = 0; sl < SSA_SLOTS; sl++) {
-                            const uint64_t mk = __ballot(lunf[sl]);
+                            const uint64_t mk = __ballot(todo[sl]);
                             if (!found && mk) {
                                 const int li = __builtin_ctzll(mk);
-                                FH = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kh[sl] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kh[sl], li);
-                                FL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kl[sl] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kl[sl], li);
-                                FAB = (uint32_t)__builtin_amdgcn_readlane((int)lab[sl], li);
+                                KH = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kh[sl] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kh[sl], li);
+                                KL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kl[sl] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kl[sl], li);
+                                AB = (uint32_t)__builtin_amdgcn_readlane((int)lab[sl], li);
                                 found = true;
                             }
-                            other |= lunf[sl] && (kh[sl] != FH || kl[sl] != FL || lab[sl] != FAB);
                         }
-                        if (!by_place && !__any(other)) { d += 16; continue; }
-                    }
-                    uint32_t nab[SSA_SLOTS], npos[SSA_SLOTS];
+                        if (!found) break;
+                        const uint32_t A = AB & 0xFFFFu;
+                        uint32_t cl = 0, ce = 0;
+                        uint64_t eqm[SSA_SLOTS];
+                        bool eq[SSA_SLOTS];
 #pragma unroll
-                    for (int si = 0; si < SSA_SLOTS; si++) {
-                        nab[si] = lab[si]; npos[si] = pos[si];
-                        if (si >= ns) continue;
-                        uint64_t todo = __ballot(lunf[si]);
-                        while (todo) {
-                            const int li = __builtin_ctzll(todo);
-                            todo &= todo - 1;
-                            const uint32_t AB = (uint32_t)__builtin_amdgcn_readlane((int)lab[si], li), P = (uint32_t)__builtin_amdgcn_readlane((int)pos[si], li);
-                            const uint64_t KH = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kh[si] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kh[si], li);
-                            const uint64_t KL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(kl[si] >> 32), li) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)kl[si], li);
-                            const uint32_t A = AB & 0xFFFFu, B = AB >> 16;
-                            uint32_t cl = 0, ce = 0, ct = 0;
+                        for (int sl = 0; sl < SSA_SLOTS; sl++) {
+                            eqm[sl] = 0; eq[sl] = false;
+                            if (sl >= ns) continue;
+                            const bool inr = lunf[sl] && lab[sl] == AB;
+                            eq[sl] = inr && kh[sl] == KH && kl[sl] == KL;
+                            cl += (uint32_t)__popcll(__ballot(inr && (kh[sl] < KH || (kh[sl] == KH && kl[sl] < KL))));
+                            eqm[sl] = __ballot(eq[sl]);
+                            ce += (uint32_t)__popcll(eqm[sl]);
+                        }
+                        uint32_t before = 0;
 #pragma unroll
-                            for (int sl = 0; sl < SSA_SLOTS; sl++) {
-                                if (sl >= ns) continue;
-                                const bool inr = pos[sl] >= A && pos[sl] < B;
-                                const bool eq = inr && kh[sl] == KH && kl[sl] == KL;
-                                const bool lt = inr && (kh[sl] < KH || (kh[sl] == KH && kl[sl] < KL));
-                                cl += (uint32_t)__popcll(__ballot(lt));
-                                ce += (uint32_t)__popcll(__ballot(eq));
-                                ct += (uint32_t)__popcll(__ballot(eq && pos[sl] < P));
+                        for (int sl = 0; sl < SSA_SLOTS; sl++) {
+                            if (eq[sl]) {
+                                nab[sl] = (A + cl) | ((A + cl + ce) << 16);
+                                npos[sl] = A + cl + before + (uint32_t)__popcll(eqm[sl] & ((1ull << lane) - 1ull));
+                                todo[sl] = false;
                             }
-                            if ((int)lane == li) { nab[si] = (A + cl) | ((A + cl + ce) << 16); npos[si] = A + cl + ct; }
+                            before += (uint32_t)__popcll(eqm[sl]);
                         }
                     }
 #pragma unroll

@@ -24,6 +24,7 @@ cut = ["load words", "gather + sort samples", "merge pivots", "bin", "scan + sca
 smp = ["draw samples", "integer sort", "-", "runs ordered", "-", "text network", "tol check + splitters + l0", "cells"]
 win = ["prologue", "window words", "round setup", "gather", "count", "move + re-read", "rows", "-"]
 with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan:
+    if os.environ.get("GLC_SORTER"): plan.set_sorter(int(os.environ["GLC_SORTER"]))   # (5: the exact form alone on deep blocks)
     out = glc.compress_batch(plan, d_in, n, rows)
     plan.synchronize()
     for it in range(2):
