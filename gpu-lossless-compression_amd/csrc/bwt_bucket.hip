@@ -1465,8 +1465,8 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     // position goes through the same LDS).  These are fs_suffix_less's 16-byte steps, so the order is the network's order; a
     // window with a tied member whose next 16 bytes come within 4 of the end of the text (where fs_suffix_less changes its step)
     // is ranked pair by pair with fs_suffix_less itself.  A run that does not end inside its window is ordered on its own if it
-    // has up to 256 members (they stay in their lanes, four to a lane, and are counted member by member: key broadcast with
-    // v_readlane, three ballots per slot); a longer one (one code on 1.5 % of the samples: not text) sends the block to the
+    // has up to 256 members (they stay in their lanes, four to a lane, and are counted class by class -- the members of one sub-run
+    // with one key together: key broadcast with v_readlane, two ballots per slot); a longer one (one code on 1.5 % of the samples: not text) sends the block to the
     // network with the text comparisons in it, which works from any order -- decided before any of this work is done.
     if (tid == 0) { s_work = 0; s_big = 0; }
     __syncthreads();
