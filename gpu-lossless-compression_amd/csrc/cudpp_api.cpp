@@ -296,13 +296,13 @@ static CUDPPResult compress_batch(CUDPPHandle planHandle, const unsigned char *d
     p->sa.parity = k;
     e = sa_build_begin(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex);
     tm.mark(1);
-    auto after_sort = [&](const uint32_t *redo_flag, const uint32_t *only) {
+    auto after_sort = [&](const uint32_t *redo_flag, const uint32_t *only, bool skewed) {
         if (p->pipelined) {
             (void)hipEventRecord(p->ev_sorted[k], st);
             (void)hipStreamWaitEvent(s2, p->ev_sorted[k], 0);
             if (p->timing) (void)hipEventRecord(p->ev_s2, s2);
         }
-        if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist, only);
+        if (e == hipSuccess) e = mtf_forward(s2, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist, only, skewed);
         if (p->timing) (void)hipEventRecord(p->ev[2], s2);
         // (compact layout: a block has no slot of its own to overflow -- the array's capacity is checked with the offsets)
         if (e == hipSuccess) e = huff_build(s2, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
@@ -316,14 +316,14 @@ static CUDPPResult compress_batch(CUDPPHandle planHandle, const unsigned char *d
     // speculative pass (`only` = the sorter's keep mask of this call) and encoded below, once their sort is final.
     const bool tiers = p->sa.sorter == 0 || p->sa.sorter == 3 || p->sa.sorter == 4;
     const bool speculate = !tiers || p->sa.sorter != 4;
-    if (speculate) after_sort(nullptr, tiers ? p->sa.fs_keep[k] : nullptr);
+    if (speculate) after_sort(nullptr, tiers ? p->sa.fs_keep[k] : nullptr, false);
     uint32_t nflag = 0;
     if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
     if (e == hipSuccess && (nflag || !speculate)) {
         // sa_build_finish has queued the other sorters for the flagged blocks on st; this pass is ordered after the
         // last of them (ev_sorted) and touches only those blocks
         tm.mark(1);                                            // the sort stage ends here: the other tiers' time is the sort's
-        after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr);
+        after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr, true);   // (the blocks of the other tiers: text-like)
     }
     if (e == hipSuccess && compact) {
         e = huff_block_offsets(s2, d_compressedSize, nb, d_blockOffsets, d_startOffset, capacityWords, p->d_status);

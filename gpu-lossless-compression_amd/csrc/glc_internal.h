@@ -261,9 +261,11 @@ void       mtf_scratch_free(MtfScratch &s);
 // out = MTF(in) per block; if sub_hist != nullptr also writes the histogram of
 // each 4096-symbol chunk of the output: sub_hist[b][chunk][256].
 hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint32_t n, uint32_t nblk,
-                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist, const uint32_t *only = nullptr);
+                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist, const uint32_t *only = nullptr,
+                       bool skewed = false);
 // (`only`, here and in the Huffman stages: if given, blocks whose entry is 0 are skipped -- the second pass over the
-//  blocks a later sorter tier rewrote)
+//  blocks a later sorter tier rewrote; `skewed`: those blocks are text-like, rank 0 is most of their output -- the encoder's
+//  histogram counts it with a ballot per row instead of sixteen adds to one counter)
 
 // ---------------------------------------------------------------------------
 // Huffman

@@ -260,7 +260,7 @@ constexpr uint32_t MTF_QUARTERS_MAX_CHUNKS = GLC_MTF_QUARTERS_MAX;   // up to th
 // batch loop is a chain of LDS round trips, ~1400 cycles per batch for a wave alone on its SIMD).  The start lists of
 // quarters 1..3 are made here: recency list of the quarter before (as k_mtf_chunk_lists does for a chunk) folded into
 // its start list (the operator of k_mtf_scan_lists), three times, by the whole wave.
-template <bool WITH_HIST, bool QUARTERS>
+template <bool WITH_HIST, bool QUARTERS, bool ZEROS = false>
 __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__restrict__ in,
                                                               size_t in_stride, uint32_t n,
                                                               const uint8_t *__restrict__ lists,
@@ -447,12 +447,22 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
                 const uint32_t half = (row & 2) ? (uint32_t)(nl >> 32) : (uint32_t)nl;
                 if (lr == 0) reinterpret_cast<uint16_t *>(bm)[(lb + 256u) >> 4] = (uint16_t)(half >> (16 * (row & 1)));
             }
+            if (WITH_HIST && ZEROS) {
+                // ZEROS (the blocks that come back from the other sorter tiers: text, logs): rank 0 is half and more of the output
+                // behind the BWT of text, and sixteen lanes adding to ONE counter are sixteen passes of the LDS atomic unit -- the
+                // row's zeros are counted with a ballot and added by one lane: 256 text blocks 12.25 -> 12.09 ms.  Not for the
+                // bucket sorter's blocks: on Zipf bytes rank 0 is one output in nine, and the ballot made the kernel 6 % slower.
+                const uint64_t zb = __ballot(valid && o == 0);
+                const uint32_t zrow = (uint32_t)(zb >> (16u * row)) & 0xFFFFu;
+                if (lr == 0 && zrow) atomicAdd(&s_hist[slot][0], (uint32_t)__builtin_popcount(zrow));
+            }
             if (valid) {
 #if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 3                       // timing experiment: (nearly) no output
                 if (o == 0x12345u)
 #endif
                 dst[i] = (uint8_t)o;
-                if (WITH_HIST) atomicAdd(&s_hist[slot][o & 127], 1u << ((o >> 3) & 16));
+                // (ZEROS: rank 0 is counted per row with a ballot, above -- see the template parameter)
+                if (WITH_HIST && !(ZEROS && o == 0)) atomicAdd(&s_hist[slot][o & 127], 1u << ((o >> 3) & 16));
 #if !(defined(GLC_EXP_MTF) && GLC_EXP_MTF == 5)                    // (timing experiment 5: nothing is killed)
                 // timestamp P is killed by i: a DWORD atomic (a 64-bit ds_or with its 64-bit shift: 2.72 -> 2.54 ms per GiB without it;
                 // prefix counts per dword instead of per 64-bit word, measured too, were slower: 2.66)
@@ -517,7 +527,7 @@ void mtf_scratch_free(MtfScratch &s)
 }
 
 hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint32_t n, uint32_t nblk,
-                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist, const uint32_t *only)
+                       uint8_t *out, size_t out_stride, MtfScratch &s, uint32_t *sub_hist, const uint32_t *only, bool skewed)
 {
     if (n == 0 || n > s.nmax || nblk == 0 || nblk > s.rows) return hipErrorInvalidValue;
     const uint32_t nchunks = (n + MTF_CHUNK - 1) / MTF_CHUNK;
@@ -541,6 +551,9 @@ hipError_t mtf_forward(hipStream_t st, const uint8_t *in, size_t in_stride, uint
                            out_stride, sub_hist, only);
     else if (quarters)
         hipLaunchKernelGGL((k_mtf_encode<false, true>), g, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
+                           out_stride, sub_hist, only);
+    else if (sub_hist && skewed)
+        hipLaunchKernelGGL((k_mtf_encode<true, false, true>), ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
                            out_stride, sub_hist, only);
     else if (sub_hist)
         hipLaunchKernelGGL((k_mtf_encode<true, false>), ge, t, 0, st, in, in_stride, n, s.lists, s.max_chunks, out,
