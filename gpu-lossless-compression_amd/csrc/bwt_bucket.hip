@@ -1463,8 +1463,8 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     // walks over the other places of its sub-run -- all members at once, as many steps as the longest sub-run of the window is
     // long: keys below it, keys equal, equal ones standing before it -> its new sub-run and place, where it then moves (its
     // position goes through the same LDS).  These are fs_suffix_less's 16-byte steps, so the order is the network's order; a
-    // window with a tied member whose next 16 bytes come within 4 of the end of the text (where fs_suffix_less changes its step)
-    // is ranked pair by pair with fs_suffix_less itself.  A run that does not end inside its window is ordered on its own if it
+    // run with a tied member whose next 16 bytes come within 4 of the end of the text (where fs_suffix_less changes its step)
+    // leaves the rounds and is ranked pair by pair with fs_suffix_less itself.  A run that does not end inside its window is ordered on its own if it
     // has up to 256 members (they stay in their lanes, four to a lane, and are counted class by class -- the members of one sub-run
     // with one key together: key broadcast with v_readlane, two ballots per slot); a longer one (one code on 1.5 % of the samples: not text) sends the block to the
     // network with the text comparisons in it, which works from any order -- decided before any of this work is done.
@@ -1525,13 +1525,24 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
             }
             if (__any(in[0] || in[1])) {
                 uint32_t d = 0;
-                bool pairwise = false;
+                bool pairwise = false, pw[2] = {false, false};     // places of the runs set aside for the pair-by-pair ranking
                 for (;;) {
-                    bool sh = false;
-#pragma unroll
-                    for (int sl = 0; sl < 2; sl++) sh |= unf[sl] && idx[sl] + d + 20 > n;
                     if (!__any(unf[0] || unf[1])) break;
-                    if (__any(sh)) { pairwise = true; break; }
+                    // a tied member whose next 16 bytes come within 4 of the end of the text: ITS run leaves the rounds (the
+                    // window's other runs go on) and is ranked pair by pair below -- ranking the whole window that way was a chain
+                    // of 120 x 2 walks, 0.25 ms, and the slowest block is what a kernel with one workgroup per block takes
+#pragma unroll
+                    for (int ss = 0; ss < 2; ss++) {
+                        uint64_t shm = __ballot(unf[ss] && idx[ss] + d + 20 > n);
+                        while (shm) {
+                            const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)run0[ss], __builtin_ctzll(shm));
+                            shm &= shm - 1;
+#pragma unroll
+                            for (int sl = 0; sl < 2; sl++) if (in[sl] && run0[sl] == R) { pw[sl] = true; unf[sl] = false; }
+                            pairwise = true;
+                        }
+                    }
+                    if (!__any(unf[0] || unf[1])) break;
                     if (!tol && (d > FS_LCP_CAP || *vdeep)) { anydeep = true; break; }
                     const bool by_place = tol && d > SS_TOL_CAP;   // tied up to the cap: by position (fs_suffix_less's rule)
                     uint64_t kh[2], kl[2];
@@ -1603,12 +1614,12 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                         const int lj = (int)(j & 63u);
                         const uint32_t ixj = (uint32_t)(j < 64 ? __builtin_amdgcn_readlane((int)idx[0], lj) : __builtin_amdgcn_readlane((int)idx[1], lj));
                         const uint32_t rj = (uint32_t)(j < 64 ? __builtin_amdgcn_readlane((int)run0[0], lj) : __builtin_amdgcn_readlane((int)run0[1], lj));
-                        const uint32_t pj = (uint32_t)(j < 64 ? __builtin_amdgcn_readlane((int)(in[0] ? 1u : 0u), lj) : __builtin_amdgcn_readlane((int)(in[1] ? 1u : 0u), lj));
+                        const uint32_t pj = (uint32_t)(j < 64 ? __builtin_amdgcn_readlane((int)(pw[0] ? 1u : 0u), lj) : __builtin_amdgcn_readlane((int)(pw[1] ? 1u : 0u), lj));
                         if (!pj) continue;
 #pragma unroll 1
                         for (int sl = 0; sl < 2; sl++) {
                             const uint32_t mine = sl ? idx[1] : idx[0], myrun = sl ? run0[1] : run0[0];
-                            const bool have = sl ? in[1] : in[0];
+                            const bool have = sl ? pw[1] : pw[0];
                             if (!have || myrun != rj || mine == ixj) continue;
                             bool dp = false;
                             const bool lt = fs_suffix_less<true>(T, n, ixj, mine, &dp, 0, tol);
@@ -1618,11 +1629,11 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int sl = 0; sl < 2; sl++) if (in[sl]) s_xw[min((run0[sl] & 0xFFFFu) + cnt[sl], SSA_WIN - 1u)] = make_uint2(idx[sl], 0u);
+                    for (int sl = 0; sl < 2; sl++) if (pw[sl]) s_xw[min((run0[sl] & 0xFFFFu) + cnt[sl], SSA_WIN - 1u)] = make_uint2(idx[sl], 0u);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int sl = 0; sl < 2; sl++) if (in[sl]) idx[sl] = s_xw[64u * sl + lane].x;
+                    for (int sl = 0; sl < 2; sl++) if (pw[sl]) idx[sl] = s_xw[64u * sl + lane].x;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
