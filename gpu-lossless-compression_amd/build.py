@@ -53,6 +53,9 @@ def rocm_root():
 
 
 def build(force=False, verbose=False):
+    if os.environ.get("GLC_CXXFLAGS", "").strip() and os.path.abspath(LIB) == os.path.join(HERE, "libglc_amd.so"):
+        raise RuntimeError("a build with GLC_CXXFLAGS is a variant: name its library with GLC_LIB_OUT (libglc_amd.so is always the "
+                           "plain build -- tests, bench.py and smoke() load that one)")
     hipcc = os.environ.get("HIPCC", os.path.join(rocm_root(), "bin", "hipcc"))
     rccl = have_rccl()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s)) and (rccl or s != "exchange.cpp")]

@@ -646,19 +646,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
             uint32_t y = e[j + FS_DEPTH - 1].x;
 #pragma unroll
             for (int d = FS_DEPTH - 2; d >= 1; d--) y = e[j + d].x + __umulhi(e[j + d].y, y);
-#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & 4)                  // timing experiment: no codes
-            const uint64_t X = (uint64_t)((gi0 + j) * 2654435761u) << 32 | by4[0];
-#else
             const uint64_t X = ((uint64_t)e[j].x << 32) + (uint64_t)e[j].y * y;
-#endif
             const uint32_t gi = gi0 + j;
             w[j] = (X & ~FS_LOW_MASK) | ((uint64_t)gi << 8) | FS_BYTE(j);
             const uint32_t bk = nbl ? (uint32_t)(X >> (64 - nbl)) : 0u;
-#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & 1)                  // timing experiment: no rank atomic in LDS
-            br[j] = (bk << 16) | ((tid + j) & 7u);
-#else
             br[j] = (bk << 16) | (gi < n ? atomicAdd(&s_cnt[bk], 1u) : 0u);
-#endif
             if (j == 0 && gi == 0) zero_bucket[b] = bk;        // where the word of suffix 0 goes: k_fs_sort_bwt looks for the BWT index there only
         }
 #undef FS_BYTE
@@ -667,25 +659,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         {
             c = tid < FS_MAXNB ? s_cnt[tid] : 0u;
             const uint32_t start = block_excl_add_lds<NT>(c, s_tmp);
-#if defined(GLC_EXP_PART) && (GLC_EXP_PART == 2 || GLC_EXP_PART == 3)   // timing experiment: no global atomic (a made-up base)
-            if (c) g = (tile * 8u) & (FS_CAP / 2 - 1);
-#else
             if (c) g = atomicAdd(&fill[(size_t)b * FS_MAXNB + tid], c);     // issued here, looked at behind the scatter
-#endif
             if (tid < FS_MAXNB) s_start[tid] = (uint16_t)start;
         }
         lds_only_barrier();                                    // (the staged text and the table reads are done: s_w takes the words)
-#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & (2 | 8))            // timing experiment: no scatter (2: and no read back below; 16: only no read back)
-        if (w[0] == 0x1234567ull) s_w[tid] = w[1] ^ w[2] ^ w[3] ^ w[ITEMS - 1] ^ br[0] ^ br[1] ^ br[2] ^ br[3] ^ br[ITEMS - 1];
-#else
 #pragma unroll
         for (int j = 0; j < ITEMS; j++)
-#ifdef GLC_EXP_PART2
-            if (gi0 + j < n) s_w[((uint32_t)s_start[br[j] >> 16] + (br[j] & 0xFFFFu)) & (TILE - 1)] = w[j];
-#else
             if (gi0 + j < n) s_w[s_start[br[j] >> 16] + (br[j] & 0xFFFFu)] = w[j];
-#endif
-#endif
         if (c && g + c > FS_FILLMAX) { atomicOr(&flag[b], 1u); s_flagged = 1; }
         if (tid < FS_MAXNB) s_gbase[tid] = (uint16_t)(g < FS_CAP ? g : FS_CAP);
         if (next_inner) {                                      // the next tile's text has arrived before this tile's stores are issued
@@ -695,40 +675,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(WPE, 8))) vo
         have = next_inner;
         lds_only_barrier();
         const uint32_t tile_n = min((uint32_t)TILE, n - base);
-#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & 32)                 // timing experiment: TWO words per store (16 bytes, half the store instructions; the layout is not a sort's)
-#pragma unroll
-        for (int r = 0; r < ITEMS / 2; r++) {
-            const uint32_t p = 2 * (r * NT + tid);
-            if (p < tile_n) {
-                const uint4 q = *reinterpret_cast<const uint4 *>(&s_w[p]);
-                const uint32_t d = nbl ? (q.y >> (32 - nbl)) : 0u;
-                const uint32_t off = ((uint32_t)s_gbase[d] + (p - (uint32_t)s_start[d])) & ~1u;
-                if (off < FS_CAP) *reinterpret_cast<uint4 *>(&K[(size_t)d * FS_CAP + off]) = q;
-            }
-        }
-        if (false)
-#endif
 #pragma unroll
         for (int r = 0; r < ITEMS; r++) {
             const uint32_t p = r * NT + tid;
-#if defined(GLC_EXP_PART2) && (GLC_EXP_PART2 & (2 | 16))
-            if (p == 0xFFFFFFFFu) {
-#else
             if (p < tile_n) {
-#endif
                 const uint64_t ww = s_w[p];
                 const uint32_t d = nbl ? (uint32_t)(ww >> (64 - nbl)) : 0u;
                 const uint32_t off = (uint32_t)s_gbase[d] + (p - (uint32_t)s_start[d]);
-#if defined(GLC_EXP_PART) && (GLC_EXP_PART == 1 || GLC_EXP_PART == 3)   // timing experiment: no stores
-                if (off == 0xFFFFFFFFu) K[(size_t)d * FS_CAP + off] = ww;
-#elif defined(GLC_EXP_PART) && GLC_EXP_PART == 4                   // timing experiment: 6 bytes per word, a dword array and a halfword array per slot
-                if (off < FS_CAP) {
-                    reinterpret_cast<uint32_t *>(K + (size_t)d * FS_CAP)[off] = (uint32_t)(ww >> 24);
-                    reinterpret_cast<uint16_t *>(K + (size_t)d * FS_CAP + FS_CAP / 2)[off] = (uint16_t)ww;
-                }
-#else
                 if (off < FS_CAP) K[(size_t)d * FS_CAP + off] = ww;
-#endif
             }
         }
         lds_only_barrier();                                    // s_w is free for the next tile's text
@@ -994,15 +948,6 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
     if (tid < FSS_LOOK && cc) s_w[cc + tid] = ~0ull;                  // what the rank step reads past the last bin compares as larger
     __syncthreads();
     if (s_deep || cc == 0) return;                             // flagged: the block is another sorter's
-#if defined(GLC_EXP_SORT) && GLC_EXP_SORT == 3                     // timing experiment: the loads alone
-    {
-        uint64_t x = 0;
-#pragma unroll
-        for (int r = 0; r < FSS_ITEMS; r++) x ^= w[r];
-        if (x == 0x1234567ull) bwt_out[tid] = 1;
-        return;
-    }
-#endif
     // 1. counting sort on the 12 bits below the bucket number (arrival order inside a bin: any order will do)
     const uint32_t bshift = 64 - nbl - FS_BIN_BITS;
     uint32_t rk[FSS_ITEMS];
@@ -1048,9 +993,6 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
             if ((uint32_t)r <= full) scatter(r);
     }
     __syncthreads();
-#if defined(GLC_EXP_SORT) && GLC_EXP_SORT == 4                     // timing experiment: up to the bin-sorted array
-    if (s_w[tid] != 0x1234567ull) return;
-#endif
     // 2. final position = bin start + number of smaller codes in the bin (thread = the words at positions i0 / (r - 1) NT +
     //    tid of the bin-sorted array).  The four words from the bin start are compared in straight-line code with no bounds
     //    at all -- what lies behind the bin's end is a larger code or a sentinel; a bin of more than four, or a second word
@@ -1143,9 +1085,6 @@ __global__ __launch_bounds__(FSS_NT) void k_fs_sort_bwt(uint32_t nbl, const uint
         }
     }
     // 4. the rows
-#if defined(GLC_EXP_SORT) && GLC_EXP_SORT == 1                     // timing experiment: no row stores
-    if (s_cp[tid] == 0x12345677u)
-#endif
     {
         const uint32_t end = shift + c;                        // staged bytes [shift, end)
         for (uint32_t q = tid; 4 * q < end; q += FSS_NT) {
@@ -2698,9 +2637,6 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                            s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_flag + b0, (const uint32_t *)nullptr,
                            (const uint64_t *)nullptr, (const uint16_t *)nullptr, (const uint64_t *)nullptr, s.fs_zero + b0, false);
         if (pi >= 0) s.prof->end(pi, u, st);
-#ifdef GLC_EXP_PART
-        if (getenv("GLC_FS_STOP_AFTER_PART")) return hipGetLastError();        // timing experiments on the bucketing pass alone
-#endif
         hipLaunchKernelGGL(k_fs_scan, dim3(nbk), dim3(FS_MAXNB), 0, st, s.fs_fill + (size_t)b0 * FS_MAXNB, s.fs_base + (size_t)b0 * FS_MAXNB,
                            s.fs_flag + b0, (const uint32_t *)nullptr);
         pi = s.prof ? s.prof->begin(PROF_FS_SORT, st) : -1;

@@ -8,36 +8,41 @@
 // the floor out of that cliff for the blocks where the answer has a closed form.  The result is the same unique suffix array.
 //
 // Let p be the smallest period of the block's beginning, e the first position with T[e] != T[e - p] (e = n if there is none),
-// t = n - e the tail, L = the multiple of p that covers max(p, t); taken if p, L <= PER_PMAX and e >= L + 2 p + 1.  Suffixes are
-// of three kinds (the text below says p where t <= p, i.e. L = p; with a longer tail read L for "p symbols ahead"):
-//   far       i < e - L         more than L periodic symbols ahead: T[i ..] starts with the rotation R_c^inf, c = i mod p
-//   exit      e - L <= i < e    (L of them) the last periods before the break
-//   tail      e <= i < n        (t of them)
+// t = n - e the tail, L = the multiple of p that covers max(p, t), Z = PER_Z = 2; taken if p, L <= PER_PMAX and
+// e >= Z L + 2 p + 1.  Suffixes are of three kinds:
+//   far       i < e - Z L          more than Z L periodic symbols ahead: T[i ..] starts with the rotation R_c^inf, c = i mod p
+//   exit      e - Z L <= i < e     (Z L of them) the last periods before the break
+//   tail      e <= i < n           (t of them)
 // * Two far suffixes of different classes differ within p symbols (p is the smallest period: the rotations are distinct), so
 //   their order is the order of the rotations R_c.
 // * Two far suffixes i < i' of ONE class agree until the nearer one reaches e; there it reads T[e] (or the end of the text)
 //   where the other reads T[e - p]: the nearer one is the smaller iff X := (e == n or T[e] < T[e - p]).  The same for every
 //   pair: a class is one monotone chain of positions, descending if X, ascending if not.
-// * An exit or tail suffix is a finite string of at most L + t <= 2 L symbols; against a far suffix of class c it is decided
-//   within L + 1 symbols (an exit suffix reads T[e] where the rotation reads T[e - p]; a tail suffix is no longer than L), i.e.
-//   inside the far suffix's periodic part wherever in the chain that suffix sits: the comparison is ONE comparison with R_c^inf.
-// So the block's suffix array is the sorted order of p + L + t REPRESENTATIVES -- p rotations, L + t explicit suffixes -- with
-// every rotation expanded into its class's chain.  The representatives are the suffixes of a small text
-//   U = T[0 .. L + 2 p + 1)  |  0xFF  |  T[e - L .. n)  |  0 0 0 ...        (<= 2 L + 2 p + t + 2 bytes and zero padding)
-// at positions c < p (rotation c: L + p + 2 or more periodic symbols before the separator, enough for every comparison above
-// even when an explicit suffix has run into the padding and ties with zeros of the rotation) and L + 2 p + 2 + k (explicit
-// suffix e - L + k; it ends where U ends, and the zero padding behind it makes "the shorter suffix is the smaller" come out
-// as it does at the end of a text).  U is sorted by the general sorter (a few thousand suffixes, whatever n is), and a
-// class's rows of the BWT are one byte repeated: T[i - 1] = T[(c + p - 1) mod p] for every member but position 0.
+// * An exit or tail suffix against a far suffix of class c must be decided INSIDE the far suffix's periodic part, wherever in
+//   its chain that suffix sits -- then the comparison is ONE comparison with R_c^inf.  How deep can it go?  An exit suffix i of
+//   class c reads T[e] where the rotation reads T[e - p], at depth e - i <= Z L.  An exit suffix of ANOTHER class with p or more
+//   periodic symbols left differs from R_c within p.  But one with FEWER than p left (e - i < p) may agree with R_c through
+//   all of them and go on agreeing through the tail: depth up to (p - 1) + t + 1 <= 2 L.  That is why the zone is 2 L wide and
+//   not L (round 5's form: 'abaa' * k + 'baab' has the exit suffix "ab" + "baab" tie with the far suffix nearest the break for
+//   all of that suffix's L + 1 periodic symbols, and the real text then reads T[e] where the model read T[e - p]; a CPU model
+//   of this layout against a naive suffix array, tests/periodic_model.py, gives 30 wrong of 60 000 random small blocks with
+//   Z = 1 and none with Z = 2).  A tail suffix is no longer than t <= L.
+// So the block's suffix array is the sorted order of p + Z L + t REPRESENTATIVES -- p rotations, Z L + t explicit suffixes --
+// with every rotation expanded into its class's chain.  The representatives are the suffixes of a small text
+//   U = T[0 .. Z L + 2 p + 1)  |  0xFF  |  T[e - Z L .. n)  |  0 0 0 ...     (2 Z L + 2 p + t + 2 bytes and zero padding)
+// at positions c < p (rotation c: Z L + p + 2 or more periodic symbols before the separator, enough for every comparison above
+// even when an explicit suffix has run into the padding and ties with up to p - 1 zeros of the rotation: 2 p + t - 1 <= 2 L + p)
+// and Z L + 2 p + 2 + k (explicit suffix e - Z L + k; it ends where U ends, and the zero padding behind it makes "the shorter
+// suffix is the smaller" come out as it does at the end of a text).  U is sorted by the general sorter (a few thousand
+// suffixes, whatever n is), and a class's rows of the BWT are one byte repeated: T[i - 1] = T[(c + p - 1) mod p] for every
+// member but position 0.
 #include "glc_device.h"
 #include "glc_internal.h"
 
 namespace glc {
 
 constexpr uint32_t PER_NT = 1024;
-// L: the multiple of the period that covers the longer of the period and the tail
-__host__ __device__ inline uint32_t per_span(uint32_t p, uint32_t t) { const uint32_t m = t > p ? t : p; return p * ((m + p - 1) / p); }
-__host__ __device__ inline uint32_t per_text_len(uint32_t p, uint32_t t) { return 2 * per_span(p, t) + 2 * p + 2 + t; }
+// (per_span = L, per_text_len = bytes of U: glc_internal.h)
 constexpr uint32_t PER_TRIES = 8;                              // candidate periods looked at per block
 
 __device__ __forceinline__ bool per_eq16(const uint8_t *a, const uint8_t *b)
@@ -89,8 +94,8 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         __syncthreads();
         // p is the SMALLEST period of T[0 .. e) iff no smaller candidate reached as far (the rotations of a smallest period are
         // distinct, which the closed form rests on: "11111" taken with p = 5 would have five equal classes)
-        const uint32_t t = n - e, L = per_span(p, t);
-        if (e > emax && t <= PER_PMAX && L <= PER_PMAX && e >= L + 2 * p + 1 && per_text_len(p, t) + 16 <= PER_NU) {
+        const uint32_t t = n - e, L = PER_Z * per_span(p, t);    // (L: the explicit zone, Z spans)
+        if (e > emax && t <= PER_PMAX && L <= PER_Z * PER_PMAX && e >= L + 2 * p + 1 && per_text_len(p, t) + 16 <= PER_NU) {
             if (tid == 0) {
                 const uint32_t slot = atomicAdd(pcount, 1u);
                 plist[slot] = b;
@@ -103,14 +108,14 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
     }
 }
 
-// U of every taken block: T[0 .. L + 2 p + 1) | 0xFF | T[e - L .. n) | zeros up to nu
+// U of every taken block: T[0 .. Z L + 2 p + 1) | 0xFF | T[e - Z L .. n) | zeros up to nu   (below, L stands for Z L)
 __global__ __launch_bounds__(256) void k_per_text(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                   const uint32_t *__restrict__ plist, const uint4 *__restrict__ info,
                                                   uint8_t *__restrict__ U, uint32_t nu)
 {
     const uint32_t b = plist[blockIdx.y];
     const uint4 in = info[b];
-    const uint32_t p = in.x, e = in.y, L = per_span(p, n - e), la = L + 2 * p + 1, lb = L + (n - e);
+    const uint32_t p = in.x, e = in.y, L = PER_Z * per_span(p, n - e), la = L + 2 * p + 1, lb = L + (n - e);
     const uint8_t *T = text + (size_t)b * stride;
     uint8_t *D = U + (size_t)blockIdx.y * PER_NU;
     for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < nu; q += gridDim.x * 256) {
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(PER_NT) void k_per_bases(uint32_t n, const uint32_t
     __shared__ uint32_t s_tmp[PER_NT / 64 + 1];
     const uint32_t slot = blockIdx.x, b = plist[slot], tid = threadIdx.x;
     const uint4 in = info[b];
-    const uint32_t p = in.x, e = in.y, L = per_span(p, n - e), lb = L + (n - e), x0 = L + 2 * p + 2;
+    const uint32_t p = in.x, e = in.y, L = PER_Z * per_span(p, n - e), lb = L + (n - e), x0 = L + 2 * p + 2;
     const uint32_t *SA = sa_u + (size_t)slot * sa_stride;
     uint32_t *B = base + (size_t)slot * (PER_NU + 1);
     uint32_t carry = 0;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void k_per_rows(const uint8_t *__restrict__ te
     const uint32_t slot = blockIdx.y, b = plist[slot];
     if (!ok[slot]) return;                                     // (uniform) left to the general sorter
     const uint4 in = info[b];
-    const uint32_t p = in.x, e = in.y, X = in.z, L = per_span(p, n - e), x0 = L + 2 * p + 2;
+    const uint32_t p = in.x, e = in.y, X = in.z, L = PER_Z * per_span(p, n - e), x0 = L + 2 * p + 2;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t *SA = sa_u + (size_t)slot * sa_stride;
     const uint32_t *B = base + (size_t)slot * (PER_NU + 1);

@@ -1290,8 +1290,7 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
                 uint32_t nu = 64;
                 for (uint32_t k = 0; k < nper; k++) {
                     const uint4 in = info[lst[k]];
-                    const uint32_t t = n - in.y, m = t > in.x ? t : in.x, L = in.x * ((m + in.x - 1) / in.x);
-                    const uint32_t need = 2 * L + 2 * in.x + 2 + t + 16;   // (per_text_len, bwt_periodic.hip)
+                    const uint32_t need = per_text_len(in.x, n - in.y) + 16;
                     if (need > nu) nu = need;
                 }
                 nu = (nu + 15u) & ~15u;

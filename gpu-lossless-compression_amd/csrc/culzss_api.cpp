@@ -88,8 +88,8 @@ void free_slot(Slot &s)
     if (s.h_packed) (void)hipHostFree(s.h_packed);
     if (s.h_size) (void)hipHostFree(s.h_size);
     s.d_packed = nullptr; s.d_in = nullptr; s.d_cand = nullptr; s.d_size = nullptr; s.d_work = nullptr; s.h_packed = nullptr; s.h_size = nullptr;
-    s.cap = 0; s.valid = false;
-}
+    s.cap = 0;                                                 // (the tracking entry {valid, key, len} is read and written under g.mu only:
+}                                                              //  the callers that hold it clear it; the wrapper drops it before reusing a slot)
 
 bool ensure_slot(Slot &s, int buf_length)
 {
@@ -113,10 +113,13 @@ bool host_mapped(const void *p, size_t bytes)
     if (reinterpret_cast<uintptr_t>(p) & 15) return false;
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    // the kernel is handed p itself: only memory whose device address IS its host address (hipHostMalloc on this platform) -- a
+    // registered or otherwise mapped range with another device address takes the copy-engine path
+    if (a.type != hipMemoryTypeHost || a.devicePointer != p) return false;
     hipPointerAttribute_t b;                                   // ... to its last byte
-    if (hipPointerGetAttributes(&b, (const char *)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return b.type == hipMemoryTypeHost && b.devicePointer != nullptr;
+    const void *last = (const char *)p + bytes - 1;
+    if (hipPointerGetAttributes(&b, last) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return b.type == hipMemoryTypeHost && b.devicePointer == last;
 }
 
 bool valid_len(int n) { return n > 0 && n % GLC_LZSS_PACKET == 0 && n <= GLC_LZSS_MAX_BUF; }
@@ -136,6 +139,7 @@ void resetGPU(void)
     std::lock_guard<std::mutex> lk(g.mu);
     for (auto &s : g.slot) {
         free_slot(s);
+        s.valid = false;
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.e0) (void)hipEventDestroy(s.e0);
         if (s.e1) (void)hipEventDestroy(s.e1);
@@ -157,6 +161,7 @@ void deleteGPUStreams(void)
     for (auto &s : g.slot) {
         if (s.stream) { (void)hipStreamSynchronize(s.stream); }
         free_slot(s);
+        s.valid = false;
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.e0) (void)hipEventDestroy(s.e0);
         if (s.e1) (void)hipEventDestroy(s.e1);
@@ -197,6 +202,7 @@ int compression_kernel_wrapper(unsigned char *buffer, int buf_length, unsigned c
         std::lock_guard<std::mutex> lk(g.mu);
         init_locked();
         sp = &g.slot[((index % NSLOTS) + NSLOTS) % NSLOTS];
+        sp->valid = false;                         // the slot is taken again: what it tracked is gone (written under g.mu, as it is read)
     }
     Slot &s = *sp;
     std::lock_guard<std::mutex> lk(s.mu);

@@ -6,6 +6,14 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// Diagnostic switches change what a kernel does (extra stores, cycle stamps, debug counters): a library built with one is an
+// experiment, never the product.  They compile only with -DGLC_EXPERIMENT_BUILD, and build.py writes such a library (any
+// library built with GLC_CXXFLAGS) to GLC_LIB_OUT only -- libglc_amd.so is always the plain build.
+#if (defined(GLC_DEBUG_CAND) || defined(GLC_SS_CLOCKS) || defined(GLC_HB_TIMING) || defined(GLC_FS2_CLOCKS) || defined(GLC_EXP_PART) || \
+     defined(GLC_EXP_PART2) || defined(GLC_EXP_SORT) || defined(GLC_EXP_MTF)) && !defined(GLC_EXPERIMENT_BUILD)
+#error "diagnostic / timing-experiment switches need -DGLC_EXPERIMENT_BUILD (and GLC_LIB_OUT: build.py never writes libglc_amd.so from such a build)"
+#endif
+
 namespace glc {
 
 constexpr uint32_t MAX_BLOCK_ELEMS = 1u << 20;   // cudppCompress/BWT limit (cudpp-inpar/README.md:96,99)
@@ -22,7 +30,11 @@ constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^2
 constexpr uint32_t FS_MAXNB_LOG2 = 9;
 // periodic tier (bwt_periodic.hip): blocks that are one periodic stretch with a period of up to PER_PMAX symbols
 constexpr uint32_t PER_PMAX = 4096;
-constexpr uint32_t PER_NU   = 5 * PER_PMAX + 32;     // bytes of the text of representatives: 3 p + 1 | separator | <= 2 p | padding
+constexpr uint32_t PER_Z    = 2;                     // the explicit zone before the break is PER_Z * L symbols wide (bwt_periodic.hip: why 2)
+constexpr uint32_t PER_NU   = (2 * PER_Z + 3) * PER_PMAX + 32;   // bytes of the text of representatives: Z L + 2 p + 1 | separator | Z L + t | padding
+// L: the multiple of the period p that covers the longer of the period and the tail t
+inline __host__ __device__ uint32_t per_span(uint32_t p, uint32_t t) { const uint32_t m = t > p ? t : p; return p * ((m + p - 1) / p); }
+inline __host__ __device__ uint32_t per_text_len(uint32_t p, uint32_t t) { return 2 * PER_Z * per_span(p, t) + 2 * p + 2 + t; }
 constexpr uint32_t FS_LCP_CAP = 512;             // suffix comparisons and the sample sorter's rounds give up behind this many symbols
 #ifndef GLC_SS_TOL_CAP
 #define GLC_SS_TOL_CAP 128

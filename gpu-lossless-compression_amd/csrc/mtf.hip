@@ -417,22 +417,14 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
 #define GLC_SLIDE(K)                                                                                                \
             "v_sub_co_u32_dpp %1, vcc, %2, %2 row_shr:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"            \
             "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
-#if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 2                       // timing experiment: no in-batch count
-            t0 = Pb; G = t0 & 7u;
-#else
             asm volatile(GLC_SLIDE(1) GLC_SLIDE(2) GLC_SLIDE(3) GLC_SLIDE(4) GLC_SLIDE(5) GLC_SLIDE(6) GLC_SLIDE(7) GLC_SLIDE(8)
                          GLC_SLIDE(9) GLC_SLIDE(10) GLC_SLIDE(11) GLC_SLIDE(12) GLC_SLIDE(13) GLC_SLIDE(14) GLC_SLIDE(15)
                          : "+v"(G), "=&v"(t0) : "v"(Pb) : "vcc");
-#endif
 #undef GLC_SLIDE
             const uint32_t T = G + lr - 15u;
             const uint32_t bitx = Pb - 1u;                           // index into the killed-timestamp bitmap
             uint32_t o;
-#if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 4                       // timing experiment: no look at the bitmap
-            if (true) o = T - (p + 1u);
-#else
             if (hasprev) o = T - (p + 1u);
-#endif
             else {
                 // killed timestamps below bit r of word wd: bit r itself (the timestamp of MY previous occurrence) is still
                 // alive -- this position kills it further down -- so "bits 0 .. r" counts the same and is one shift
@@ -457,24 +449,16 @@ __global__ __launch_bounds__(MTF_WAVES * 64) void k_mtf_encode(const uint8_t *__
                 if (lr == 0 && zrow) atomicAdd(&s_hist[slot][0], (uint32_t)__builtin_popcount(zrow));
             }
             if (valid) {
-#if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 3                       // timing experiment: (nearly) no output
-                if (o == 0x12345u)
-#endif
                 dst[i] = (uint8_t)o;
                 // (ZEROS: rank 0 is counted per row with a ballot, above -- see the template parameter)
                 if (WITH_HIST && !(ZEROS && o == 0)) atomicAdd(&s_hist[slot][o & 127], 1u << ((o >> 3) & 16));
-#if !(defined(GLC_EXP_MTF) && GLC_EXP_MTF == 5)                    // (timing experiment 5: nothing is killed)
                 // timestamp P is killed by i: a DWORD atomic (a 64-bit ds_or with its 64-bit shift: 2.72 -> 2.54 ms per GiB without it;
                 // prefix counts per dword instead of per 64-bit word, measured too, were slower: 2.66)
                 if (!hasprev) atomicOr(&reinterpret_cast<uint32_t *>(bm)[bitx >> 5], 1u << (bitx & 31));
-#endif
                 if (last_in_batch) tab[sym] = (lb + lr + 256u) << 16;        // new last occurrence, lane bits cleared
             }
             __builtin_amdgcn_wave_barrier();
             // prefix counts of the killed-timestamp bitmap: 2 words per lane, scan across the row
-#if defined(GLC_EXP_MTF) && GLC_EXP_MTF == 1                       // timing experiment: no recount
-            if (base == 0xFFFFFFF0u)
-#endif
             {
                 const uint4 v = *reinterpret_cast<const uint4 *>(bm + 2 * lr);
                 const uint32_t c0 = (uint32_t)__builtin_popcount(v.x) + (uint32_t)__builtin_popcount(v.y);

@@ -16,7 +16,7 @@
 // reference holds its CUHDGPUDecoderMemory; the caller then owns the rule "one decode in flight per DecoderMemory").
 // Any other type (or a null pointer) makes the adapter keep its own work buffers, ONE PER (calling thread, stream):
 // two decodes enqueued from one thread on different streams never share scratch, and decodes on the same stream are
-// ordered by the stream.  A buffer that has to grow waits for its stream before the old allocation is freed.  The subsequence
+// ordered by the stream.  A buffer that has to grow (or go) waits for the EVENT its last decode recorded, never for a stream handle.  The subsequence
 // size and threads-per-block hints are accepted and ignored (the span functions of hd_decode.hip need no
 // self-synchronisation rounds, so there is nothing to tune and no device->host flag copy per round,
 // cuhd_gpu_decoder.cu:459-495); codewords longer than 11 bits are refused, as the reference's table format does.
@@ -31,35 +31,55 @@
 
 namespace glc { namespace cuhd {
 
-// work buffer of a decode (what cuhd::CUHDGPUDecoderMemory is to the reference): sized for the largest stream seen
+// work buffer of a decode (what cuhd::CUHDGPUDecoderMemory is to the reference): sized for the largest stream seen.  It never
+// touches a stream handle it does not own (the caller may have destroyed the stream since): every decode that used the buffer
+// RECORDS an event behind itself (used()), and the buffer is released -- to grow, or for good -- only behind that event.
 class DecoderMemory {
   public:
     DecoderMemory() = default;
     DecoderMemory(const DecoderMemory &) = delete;
     DecoderMemory &operator=(const DecoderMemory &) = delete;
-    ~DecoderMemory() { if (ptr_) (void)hipFree(ptr_); }
-    // `stream`: where the decodes that used this buffer were enqueued; waited for before a smaller buffer is released
-    void *reserve(std::size_t units, hipStream_t stream = nullptr)
+    ~DecoderMemory()
+    {
+        wait_idle();
+        if (ptr_) (void)hipFree(ptr_);
+        if (done_) (void)hipEventDestroy(done_);
+    }
+    void *reserve(std::size_t units)
     {
         const std::size_t need = glcHdWorkBytes(units);
         if (need > bytes_) {
-            if (ptr_) {
-                // a stream handle that has been destroyed since (the per-stream cache below keeps its buffer): nothing of it can
-                // still be running, so the buffer is free to go
-                const hipError_t e = hipStreamSynchronize(stream);
-                if (e == hipErrorInvalidHandle || e == hipErrorContextIsDestroyed || e == hipErrorInvalidResourceHandle) (void)hipGetLastError();
-                else if (e != hipSuccess) throw std::runtime_error("glc::cuhd::DecoderMemory: hipStreamSynchronize failed");
-                (void)hipFree(ptr_);
-            }
+            wait_idle();                                       // the last decode that used the smaller buffer is through
+            if (ptr_) (void)hipFree(ptr_);
             ptr_ = nullptr; bytes_ = 0;
             if (hipMalloc(&ptr_, need) != hipSuccess) throw std::runtime_error("glc::cuhd::DecoderMemory: hipMalloc failed");
             bytes_ = need;
         }
         return ptr_;
     }
+    // called right behind a decode enqueued on `stream` (a live stream: the caller has just used it)
+    void used(hipStream_t stream)
+    {
+        if (!done_ && hipEventCreateWithFlags(&done_, hipEventDisableTiming) != hipSuccess) {
+            done_ = nullptr;
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(stream);                // no event to be had: the decode is waited for here instead
+            pending_ = false;
+            return;
+        }
+        pending_ = hipEventRecord(done_, stream) == hipSuccess;
+        if (!pending_) { (void)hipGetLastError(); (void)hipStreamSynchronize(stream); }
+    }
   private:
+    void wait_idle()
+    {
+        if (pending_ && done_ && hipEventSynchronize(done_) != hipSuccess) (void)hipGetLastError();
+        pending_ = false;
+    }
     void *ptr_ = nullptr;
     std::size_t bytes_ = 0;
+    hipEvent_t done_ = nullptr;
+    bool pending_ = false;
 };
 
 class CUHDGPUDecoder {
@@ -72,33 +92,27 @@ class CUHDGPUDecoder {
     {
         if (!input || !output || !table) throw std::invalid_argument("glc::cuhd::CUHDGPUDecoder::decode: null buffer");
         if (max_codeword_length > GLC_HD_MAX_LEN) throw std::invalid_argument("glc::cuhd::CUHDGPUDecoder::decode: codewords longer than 11 bits");
-        void *w = nullptr;
+        DecoderMemory *mem = nullptr;
         if constexpr (std::is_same<Aux, DecoderMemory>::value) {
-            if (aux) w = aux->reserve(input_size, stream);     // the caller's decoder memory, as in the reference
+            if (aux) mem = aux.get();                          // the caller's decoder memory, as in the reference
         }
-        if (!w) {
+        if (!mem) {
             // one per (thread, stream); bounded: a caller that keeps creating streams gets the cache emptied at 16 entries
-            // (every buffer is released behind a wait for its stream) instead of one work buffer per handle ever seen.
+            // (every buffer is released behind the event of its last decode) instead of one work buffer per handle ever seen.
             // release_work_buffers() empties it on request.
             auto &work = cache();
             if (work.size() >= 16 && work.find(stream) == work.end()) release_work_buffers();
-            w = work[stream].reserve(input_size, stream);
+            mem = &work[stream];
         }
+        void *w = mem->reserve(input_size);
         const int ok = glcHdDecodeDeviceTableOnDevice(reinterpret_cast<const unsigned int *>(input->get()), input_size,
                                                       reinterpret_cast<const unsigned char *>(table->get()),
                                                       reinterpret_cast<unsigned char *>(output->get()), output_size, w, stream);
+        mem->used(stream);
         if (!ok) throw std::runtime_error("glc::cuhd::CUHDGPUDecoder::decode: glcHdDecodeDeviceTableOnDevice failed");
     }
-    // frees the calling thread's cached work buffers (each behind a wait for the stream it was used on)
-    static void release_work_buffers()
-    {
-        auto &work = cache();
-        for (auto &kv : work) {
-            const hipError_t e = hipStreamSynchronize(kv.first);
-            if (e != hipSuccess) (void)hipGetLastError();      // (a destroyed stream: nothing of it is running)
-        }
-        work.clear();
-    }
+    // frees the calling thread's cached work buffers (each behind the event its last decode recorded; no stream handle is touched)
+    static void release_work_buffers() { cache().clear(); }
   private:
     static std::unordered_map<hipStream_t, DecoderMemory> &cache()
     {

@@ -147,3 +147,40 @@ def test_periodic_blocks_inside_a_mixed_compress_batch(glc, cuda):
             assert np.array_equal(out["words"][out["stride"] * k: out["stride"] * k + size].cpu().numpy().view(np.uint32), want["words"]), k
         back = glc.decompress_batch(plan, out, n, len(blocks))
         assert torch.equal(back, d_in)
+
+
+def test_exit_suffixes_that_agree_with_a_rotation_through_the_tail(glc, cuda):
+    """'abaa' * k + 'baab' and 47 more (tests/periodic_model.ADVERSARIAL): an exit suffix with fewer than p periodic symbols left
+    that goes on agreeing with ANOTHER class's rotation through the tail -- deeper than the L + 1 symbols round 5's layout gave a far
+    suffix.  Every phase of the first period, three block lengths."""
+    import periodic_model as M
+    for n in (1 << 16, (1 << 16) + 5, 1 << 17):
+        blocks = [np.frombuffer(M.adversarial_block(per, cut, tail, n), dtype=np.uint8) for per, cut, tail in M.ADVERSARIAL]
+        got, idx, nper, (f1, f2) = _bwt_batch(glc, cuda, blocks, n)
+        for k, x in enumerate(blocks):
+            want, widx = O.bwt(x)
+            assert int(idx[k]) == widx, (n, k)
+            assert np.array_equal(got[k], want), (n, k, M.ADVERSARIAL[k], int(np.nonzero(got[k] != want)[0][0]))
+        assert nper == len(blocks), (n, nper, f1, f2)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_small_alphabet_sweep_short_periods_short_tails(glc, cuda, seed):
+    """periods 1..7, tails 0..10, two or three symbols, every phase of the break: 256 blocks of 64 KiB per seed (the shapes the
+    CPU model sweeps by the ten thousand, tests/test_cpu_periodic_model.py)"""
+    rng = np.random.default_rng(4242 + seed)
+    n = 1 << 16
+    blocks = []
+    while len(blocks) < 256:
+        p, t, A = int(rng.integers(1, 8)), int(rng.integers(0, 11)), int(rng.integers(2, 4))
+        per = rng.integers(0, A, p, dtype=np.uint8)
+        tail = rng.integers(0, A, t, dtype=np.uint8)
+        x = np.concatenate([np.tile(per, n // p + 1)[:n - t], tail])
+        if len(set(x.tolist())) > 1:
+            blocks.append(x)
+    got, idx, nper, (f1, f2) = _bwt_batch(glc, cuda, blocks, n)
+    for k, x in enumerate(blocks):
+        want, widx = O.bwt(x)
+        assert int(idx[k]) == widx, (seed, k)
+        assert np.array_equal(got[k], want), (seed, k, int(np.nonzero(got[k] != want)[0][0]))
+    assert nper >= 200, (nper, f1, f2)
