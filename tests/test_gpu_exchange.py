@@ -131,3 +131,100 @@ def test_count_exchange_tickets(glc, cuda):
     assert L.glcGatherCountsReady(xch.comm, 9, C.byref(ready)) == glc.CUDPP_ERROR_ILLEGAL_CONFIGURATION
     xch.close()
 
+
+
+def _two_rank_worker(rank, world, port, q, nblk_per_rank):
+    """one rank of the two-rank RCCL run: device `rank`, gloo only for the unique id and the cross-check bytes"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datagen as dg
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_pkg_module
+    glc = load_pkg_module("glc_binding")
+    ex = _dist_mod()
+    L = glc.lib()
+    ok, why = True, ""
+    try:
+        xch = ex.RcclExchange(glc, torch, dist)
+        nr, rk = C.c_int(-1), C.c_int(-1)
+        assert L.glcCommInfo(xch.comm, C.byref(nr), C.byref(rk)) == 0 and (nr.value, rk.value) == (world, rank)
+        nblk, nglobal = nblk_per_rank[rank], sum(nblk_per_rank)
+        nsub, stride = N // 4096, glc.compressed_stride_words(N)
+        gen = lambda g: dg.float_bytes(N, seed=0x5EED0004 + g)      # global block g lives on rank g % world as its block g // world
+        with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, N, rows=max(nglobal, 1)) as plan:
+            d_in = torch.from_numpy(np.concatenate([gen(rank + i * world) for i in range(nblk)])).to(dev)
+            out = glc.compress_batch(plan, d_in, N, nblk)
+            compact = torch.empty(nblk * stride, dtype=torch.int32, device=dev)
+            off = torch.empty(nblk + 1, dtype=torch.int64, device=dev)
+            assert L.glcCompactStreams(plan.handle, out["words"].data_ptr(), stride, out["size"].data_ptr(), nblk,
+                                       compact.data_ptr(), off.data_ptr()) == 0
+            plan.synchronize()
+            rec = xch.pack_records(out, nblk, nsub)
+            g = xch.gather(compact, off.data_ptr() + 8 * nblk, rec, dst=0)     # glcGatherCounts (ncclAllGather) + glcGatherStreams (ncclSend / ncclRecv)
+            torch.cuda.synchronize()
+            counts = list(xch.counts)
+            mine = int(off[nblk].item())
+            if rank == 0:
+                g = xch.finish(g)
+                ok = ok and g["nblk"] == list(nblk_per_rank) and torch.equal(g["buffers"][0], compact[:mine]) and torch.equal(g["records"][0], rec)
+                # the gathered streams == what ONE process produces for the same global blocks, block by block
+                d_all = torch.from_numpy(np.concatenate([gen(gb) for gb in range(nglobal)])).to(dev)
+                ref = glc.compress_batch(plan, d_all, N, nglobal)
+                plan.synchronize()
+                sizes = ref["size"].cpu().numpy()
+                for gb in range(nglobal):
+                    words, record = ex.block_of(g, gb)
+                    ok = ok and int(record[0].item()) == int(sizes[gb]) and torch.equal(words, ref["words"][gb * stride: gb * stride + int(sizes[gb])])
+                # ... and the other rank's bytes as that rank holds them (through gloo)
+                other = torch.empty(g["words"][1], dtype=torch.int32)
+                dist.recv(other, 1)
+                ok = ok and torch.equal(other.to(dev), g["buffers"][1])
+            else:
+                dist.send(compact[:mine].cpu(), 0)
+            buf, boff, brec = xch.scatter(g, counts, rec.shape[1], src=0)       # glcScatterStreams: the mirror
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(buf, compact[:mine]) and torch.equal(brec, rec) and torch.equal(boff, off)
+        xch.close()
+    except Exception as e:                                                      # report, do not hang the other rank's join
+        ok, why = False, repr(e)
+    q.put((rank, bool(ok), why))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _device_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="two ranks of an RCCL communicator need two devices (RCCL refuses two ranks on one)")
+@pytest.mark.parametrize("nblk_per_rank", [(3, 3), (3, 2), (2, 1)])
+def test_two_ranks_rccl(nblk_per_rank):
+    """The N > 1 branch of glcGatherCounts / glcGatherStreams / glcScatterStreams on REAL RCCL: two processes, one device each,
+    ragged block counts; the gathered stream equals the single-process stream block by block.  Skips on a one-GPU box; runs
+    itself on the first box with two."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 1500) + 7 * sum(nblk_per_rank) + nblk_per_rank[0]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, nblk_per_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive, "a rank hung"
+    assert [p.exitcode for p in procs] == [0, 0]
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, True, ""), (1, True, "")], got
