@@ -1925,8 +1925,34 @@ __device__ __forceinline__ uint32_t ss_pivot_bin(uint64_t piv, uint64_t key)
 //                when this was the tail of the cutting kernel, the slowest of 16 waves took 3x the mean and the
 //                other 15 sat on 73 KB of LDS meanwhile.
 // Nothing here depends on the symbol statistics.
+// sorts one 128-bit key {hi, lo} per lane across the wave (ascending by lane)
+__device__ __forceinline__ void wave_sort_u128(uint64_t &h, uint64_t &l, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            const uint64_t oh = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(h >> 32), (int)j) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)h, (int)j);
+            const uint64_t ol = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(l >> 32), (int)j) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)l, (int)j);
+            const bool up = (lane & kk) == 0, lower = (lane & j) == 0;
+            const bool oless = (oh < h) | ((oh == h) & (ol < l));
+            const bool take = (up == lower) ? oless : !oless;  // keep the smaller of the pair in the lower lane of an ascending half
+            const bool same = (oh == h) & (ol == l);
+            if (take && !same) { h = oh; l = ol; }
+        }
+    }
+}
+
+__device__ __forceinline__ bool ss_less128(const ulonglong2 a, uint64_t h, uint64_t l) { return (a.x < h) | ((a.x == h) & (a.y < l)); }
+
+#ifndef GLC_SSC_SIDE
+#define GLC_SSC_SIDE 2                                      // k_ss_cut: pivot searches of a thread that run side by side
+#endif
+#ifndef GLC_SSC_WPE
+#define GLC_SSC_WPE 8
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(GLC_SSC_WPE, 8))) void k_ss_cut(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                uint32_t nbl, uint64_t *__restrict__ keys, size_t kstride,
                                                const uint32_t *__restrict__ fill,
                                                uint32_t *__restrict__ flag, const uint32_t *__restrict__ list,
@@ -1935,16 +1961,22 @@ __global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text,
 {
     // The first cut of a bucket, nothing else: keys and words stay in registers, the pivots are gathered on their own
     // (256 threads read the word and the text of one sample each, beside the loads of everybody's positions), and LDS
-    // only stages the bucket on its way back to the slot -- 39 KB, four workgroups per CU, where the cut-until-done form
+    // only stages the bucket on its way back to the slot -- 35 KB, four workgroups per CU, where the cut-until-done form
     // (keys, words and runs of 4032 positions: 73 KB) had two, each a chain of memory and LDS round trips between barriers.
+    // Round 6: the key is FOURTEEN text bytes from ONE 16-byte gather ({bytes 0..7, bytes 8..13 << 16}: two steps of the run
+    // descriptors' unit, the windows' form of a round).  A gather of 16 bytes costs what one of 8 does, and a bin "equal to a
+    // pivot" is then two steps deeper and a fraction of the size: log lines share "2026-09-28T12:3" and " host-17 svc-" --
+    // on 7 bytes a bucket's first cut left ~800 bins of more than a window per block for k_ss_long (3.1 ms per 256 blocks),
+    // text ~150.  The pivot lists and the merged pivots live where the bucket is staged afterwards.
     constexpr int ITEMS = FS_CAP / NT;
     static_assert(NT >= (int)SS_NPIV0 && FS_CAP % NT == 0, "one pivot sample per thread of the first four waves");
-    __shared__ uint64_t s_out[FS_FILLMAX];                     // the bucket in its new order: [run : 32 | index : 20 | bwt : 8 ...]
+    static_assert(2 * SS_NPIV0 * sizeof(ulonglong2) <= FS_FILLMAX * sizeof(uint64_t), "pivot lists + merged pivots inside the staging array");
+    __shared__ __attribute__((aligned(16))) uint64_t s_out[FS_FILLMAX];   // the bucket in its new order: [run : 32 | index : 20 | bwt : 8 ...]
     __shared__ uint32_t s_cnt[2 * SS_NPIV0 + 4];               // bin counters, then bin starts (+ end)
-    __shared__ uint64_t s_piv0[SS_NPIV0];                      // pivots, sorted
-    __shared__ uint64_t s_pl[SS_NPL][64];                      // ... as the four sorted lists they are merged from
     __shared__ uint32_t s_nlong, s_bound[64];
     __shared__ unsigned long long s_at;
+    ulonglong2 *s_pl = reinterpret_cast<ulonglong2 *>(s_out);  // [SS_NPL][64] the sorted lists the pivots are merged from ...
+    ulonglong2 *s_piv0 = s_pl + SS_NPIV0;                      // ... and the pivots, sorted (both dead before the bucket is staged)
     uint32_t gx, gy;
     xcd_order(gx, gy);
     const uint32_t b = list[gy], bk = gx, tid = threadIdx.x;
@@ -1967,30 +1999,44 @@ __global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text,
     for (uint32_t i = tid; i < 2 * SS_NPIV0 + 4; i += NT) s_cnt[i] = 0;
     if (tid == 0) s_nlong = 0;
     SS_CLK(0);                                                 // words loaded
-    // a member whose 8 bytes reach the end of the text: the whole cut uses the 9-bit digits that tell "ended" from a zero byte
+    // a member whose 16 bytes reach the end of the text: the whole cut takes ONE step with the 9-bit digits that tell "ended"
+    // from a zero byte (63 bits in the key's high half, the low half 0)
     bool tl = false;
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++) tl |= r * NT + tid < c && (vv[r] >> 8) + l0 + 12 > n;
+    for (int r = 0; r < ITEMS; r++) tl |= r * NT + tid < c && (vv[r] >> 8) + l0 + 20 > n;
     const bool digits = __syncthreads_or(tl) != 0;
-    uint64_t key[ITEMS], skey = 0;
-    if (tid < SS_NPIV0) skey = digits ? ss_sym_load(T, n, (sv >> 8) + l0) : fs_load_be64(T + (sv >> 8) + l0) >> 8;
+    const uint32_t deeper = digits ? 1u : 2u;                  // steps a bin "equal to a pivot" is deeper than its run
+    uint64_t kh[ITEMS], kl[ITEMS], sh = 0, sl = 0;
+    if (tid < SS_NPIV0) {
+        if (digits) sh = ss_sym_load(T, n, (sv >> 8) + l0);
+        else fs_load_be128(T + (sv >> 8) + l0, sh, sl);
+    }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t p = r * NT + tid;
-        key[r] = p < c ? (digits ? ss_sym_load(T, n, (vv[r] >> 8) + l0) : fs_load_be64(T + (vv[r] >> 8) + l0) >> 8) : 0ull;
+        kh[r] = 0; kl[r] = 0;
+        if (p < c) {
+            if (digits) kh[r] = ss_sym_load(T, n, (vv[r] >> 8) + l0);
+            else fs_load_be128(T + (vv[r] >> 8) + l0, kh[r], kl[r]);
+        }
     }
     // 256 pivots (bins of ~c / 513: the windows count inside runs directly, quadratic in their length): four waves sort 64
     // sampled keys each, every pivot then finds its place among the other three lists
-    if (tid < SS_NPIV0) s_pl[wv][lane] = wave_sort_u64(digits ? ss_sym_key(skey) : skey, lane);
-    if (digits) {
+    if (tid < SS_NPIV0) {
+        if (digits) { sh = ss_sym_key(sh); sl = 0; } else sl &= ~0xFFFFull;
+        wave_sort_u128(sh, sl, lane);
+        s_pl[wv * 64 + lane] = make_ulonglong2(sh, sl);
+    }
 #pragma unroll
-        for (int r = 0; r < ITEMS; r++) key[r] = ss_sym_key(key[r]);
+    for (int r = 0; r < ITEMS; r++) {
+        if (digits) kh[r] = ss_sym_key(kh[r]);
+        else kl[r] &= ~0xFFFFull;
     }
     __syncthreads();
     SS_CLK(1);
     if (tid < SS_NPIV0) {
         const uint32_t w = tid >> 6;
-        const uint64_t kv = s_pl[w][lane];
+        const ulonglong2 kv = s_pl[w * 64 + lane];
         uint32_t rank = lane;
 #pragma unroll
         for (uint32_t ow = 0; ow < SS_NPL; ow++) {
@@ -1998,8 +2044,8 @@ __global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text,
             uint32_t lo = 0, hi = 64;                          // elements of list ow that come before kv (ties: the lower list first)
             while (lo < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                const uint64_t x = s_pl[ow][mid];
-                if (x < kv || (x == kv && ow < w)) lo = mid + 1; else hi = mid;
+                const ulonglong2 x = s_pl[ow * 64 + mid];
+                if (ss_less128(x, kv.x, kv.y) || (x.x == kv.x && x.y == kv.y && ow < w)) lo = mid + 1; else hi = mid;
             }
             rank += lo;
         }
@@ -2007,19 +2053,36 @@ __global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text,
     }
     __syncthreads();
     SS_CLK(2);                                                 // pivots
-    uint32_t bin[ITEMS], rk[ITEMS];
+    // first pivot >= key: eight branch-free steps over the first 255 pivots (the searches of a thread's eight members side by
+    // side: their LDS reads overlap), then a look at the pivot found -- or at the 256th
+    uint32_t br[ITEMS];                                        // bin : 10 | arrival rank in the bin : 12
+    {
+        uint32_t at[ITEMS];
 #pragma unroll
-    for (int r = 0; r < ITEMS; r++) {
-        const uint32_t p = r * NT + tid;
-        if (p < c) {
-            uint32_t lo = 0, hi = SS_NPIV0;                    // first pivot >= key
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_piv0[mid] < key[r]) lo = mid + 1; else hi = mid; }
-            bin[r] = 2 * lo + ((lo < SS_NPIV0 && s_piv0[lo] == key[r]) ? 1u : 0u);
-            rk[r] = atomicAdd(&s_cnt[bin[r]], 1u);
+        for (int r = 0; r < ITEMS; r++) at[r] = 0;
+#pragma unroll
+        for (int r0 = 0; r0 < ITEMS; r0 += GLC_SSC_SIDE) {
+#pragma unroll
+            for (uint32_t step = SS_NPIV0 / 2; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int r = r0; r < r0 + GLC_SSC_SIDE; r++)
+                    if (ss_less128(s_piv0[at[r] + step - 1], kh[r], kl[r])) at[r] += step;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++) {
+            const uint32_t p = r * NT + tid;
+            br[r] = 0;
+            if (p < c) {
+                const ulonglong2 x = s_piv0[at[r]];            // (at <= 255)
+                const bool past = at[r] == SS_NPIV0 - 1 && ss_less128(x, kh[r], kl[r]);
+                const uint32_t bn = past ? 2 * SS_NPIV0 : 2 * at[r] + ((x.x == kh[r] && x.y == kl[r]) ? 1u : 0u);
+                br[r] = bn | (atomicAdd(&s_cnt[bn], 1u) << 10);
+            }
         }
     }
     __syncthreads();
-    SS_CLK(3);                                                 // binned
+    SS_CLK(3);                                                 // binned (the pivots are dead: s_out takes the bucket)
     if (wv == 0) {
         constexpr int PER = (2 * SS_NPIV0 + 2 + 63) / 64;      // 514 starts + the end
         uint32_t cc[PER], tot = 0;
@@ -2034,8 +2097,8 @@ __global__ __launch_bounds__(NT) void k_ss_cut(const uint8_t *__restrict__ text,
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t p = r * NT + tid;
         if (p < c) {
-            const uint32_t gs = s_cnt[bin[r]], ge = s_cnt[bin[r] + 1];
-            s_out[gs + rk[r]] = (uint64_t)vv[r] | ((uint64_t)ss_run(gs, ge, bin[r] & 1) << 32);   // a pivot's bin: all keys equal, one round done
+            const uint32_t bn = br[r] & 0x3FFu, gs = s_cnt[bn], ge = s_cnt[bn + 1];
+            s_out[gs + (br[r] >> 10)] = (uint64_t)vv[r] | ((uint64_t)ss_run(gs, ge, (bn & 1) ? deeper : 0u) << 32);   // a pivot's bin: all keys equal
         }
     }
     // bins still longer than a window (a key shared by hundreds of suffixes, or an unlucky gap between pivots) go on a
@@ -2372,6 +2435,24 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
                         const uint32_t L = mv[j] ? ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) : 0u;
                         tr += wave_max(L > 1 ? L : 0u);
                         und_n += (uint32_t)__popcll(__ballot(L > 1));
+                    }
+                    {   // members of this round by the size of their run; rounds with few undecided members / small runs only
+                        uint32_t c2 = 0, c4 = 0, c16 = 0, c64 = 0, cbig = 0, maxL = 0;
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t L = mv[j] ? ((g4[j] >> 12) & 0xFFFu) - (g4[j] & 0xFFFu) : 0u;
+                            c2 += (uint32_t)__popcll(__ballot(L == 2)); c4 += (uint32_t)__popcll(__ballot(L == 3 || L == 4));
+                            c16 += (uint32_t)__popcll(__ballot(L > 4 && L <= 16)); c64 += (uint32_t)__popcll(__ballot(L > 16 && L <= 64));
+                            cbig += (uint32_t)__popcll(__ballot(L > 64)); maxL = max(maxL, wave_max(L));
+                        }
+                        if (lane == 0) {
+                            unsigned long long *G = g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u];
+                            atomicAdd(&G[9], (unsigned long long)c2); atomicAdd(&G[10], (unsigned long long)c4); atomicAdd(&G[11], (unsigned long long)c16);
+                            atomicAdd(&G[12], (unsigned long long)c64); atomicAdd(&G[13], (unsigned long long)cbig);
+                            if (und_n <= 8) atomicAdd(&G[14], 1ull);
+                            if (maxL <= 4) atomicAdd(&G[15], 1ull);
+                            if (maxL <= 2) atomicAdd(&G[29], 1ull);
+                            if (maxL <= 16) atomicAdd(&G[30], 1ull);
+                        }
                     }
                     if (lane == 0) { atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][25], 1ull); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][26], (unsigned long long)tr);
                                      atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][27], (unsigned long long)und_n); atomicAdd(&g_ss_clk[(blockIdx.x * 7u + blockIdx.y) & 255u][28], (unsigned long long)(W - pos)); }

@@ -42,5 +42,7 @@ with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows) as plan
         r = max(1, buf[25])
         print("   rounds per wave %.2f; per round: summed wave-max run length of the 4 item loops %.1f, undecided positions %.1f, window %.1f positions"
               % (r / max(1, buf[24]), buf[26] / r, buf[27] / r, buf[28] / r))
+        print("   members per round by run size: 2: %.1f, 3-4: %.1f, 5-16: %.1f, 17-64: %.1f, 65+: %.1f; rounds with <= 8 undecided %.3f, longest run <= 2: %.3f, <= 4: %.3f, <= 16: %.3f"
+              % (buf[9] / r, buf[10] / r, buf[11] / r, buf[12] / r, buf[13] / r, buf[14] / r, buf[29] / r, buf[15] / r, buf[30] / r))
         print("   k_ss_sample: windows pair by pair %d, long runs %d, blocks to the network %d; slowest 'runs ordered' exact %.1f us, tolerant %.1f us"
               % (buf[41], buf[42], buf[43], buf[44] / 100.0, buf[45] / 100.0))
