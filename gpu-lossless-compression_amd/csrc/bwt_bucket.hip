@@ -2629,6 +2629,13 @@ __global__ void k_ss_finish(const uint32_t *__restrict__ flag, const uint32_t *_
     }
 }
 
+__global__ void k_ss_split_masks(const uint32_t *__restrict__ redo, const uint32_t *__restrict__ lcnt, uint32_t nblk,
+                                 uint32_t *__restrict__ done, uint32_t *__restrict__ open)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nblk) { const uint32_t l = lcnt[b]; done[b] = (redo[b] && !l) ? 1u : 0u; open[b] = l; }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -2797,6 +2804,12 @@ hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32
     GLC_TRY(hipMemsetAsync(s.fs_nflag + 2, 0, 4, st));
     hipLaunchKernelGGL(k_ss_retry_list, dim3(nflag), dim3(256), 0, st, s.ss_flag, s.ss_list, nflag, s.ss_list + (size_t)to * s.rows,
                        s.fs_nflag + 2, s.fs_fill, to, count_only ? 0u : 1u);
+    return hipGetLastError();
+}
+
+hipError_t ss_split_masks(hipStream_t st, uint32_t nblk, SaScratch &s)
+{
+    hipLaunchKernelGGL(k_ss_split_masks, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_redo[s.parity & 1], s.fs_lcnt, nblk, s.ss_mask[0], s.ss_mask[1]);
     return hipGetLastError();
 }
 

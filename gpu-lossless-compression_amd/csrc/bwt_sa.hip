@@ -969,6 +969,8 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.fs_redo[1], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_keep[0], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_keep[1], (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.ss_mask[0], (size_t)rows * 4));
+    GLC_TRY(A((void **)&s.ss_mask[1], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_dup, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_zero, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_nflag, 16));
@@ -1022,11 +1024,14 @@ hipError_t sa_general_reserve(SaScratch &s, bool only_sa)
 
 void sa_scratch_free(SaScratch &s)
 {
-    void *ps[] = {s.keyA, s.ss_long, s.ss_long_count, s.ss_gtile, s.ss_cnt2, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.per_info, s.per_list, s.per_ok, s.per_count, s.per_base, s.per_text, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
+    void *ps[] = {s.keyA, s.ss_mask[0], s.ss_mask[1], s.ss_long, s.ss_long_count, s.ss_gtile, s.ss_cnt2, s.ss_list, s.ss_split, s.ss_flag, s.ss_cell, s.ss_l0, s.fs_hist, s.fs_tab, s.fs_fill, s.fs_base, s.fs_flag, s.fs_lcnt, s.fs_redo[0], s.fs_redo[1], s.fs_keep[0], s.fs_keep[1], s.fs_dup, s.fs_zero, s.fs_nflag, s.per_info, s.per_list, s.per_ok, s.per_count, s.per_base, s.per_text, s.fs_wl, s.fs_wlcnt, s.posA, s.posB, s.hdA, s.hdB, s.isa, s.sa, s.tile_hist, s.digit_base, s.ghist,
                   s.tile_state, s.ticket, s.cntA, s.cntB, s.d_max_cnt, s.rl_flag, s.rl_cnt};
     for (void *p : ps) if (p) (void)hipFree(p);
     if (s.h_max_cnt) (void)hipHostFree(s.h_max_cnt);
     if (s.ev_flag) (void)hipEventDestroy(s.ev_flag);
+    if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
+    if (s.ev_join) (void)hipEventDestroy(s.ev_join);
+    if (s.aux) { (void)hipStreamSynchronize(s.aux); (void)hipStreamDestroy(s.aux); }
     s = SaScratch();
 }
 
@@ -1224,8 +1229,21 @@ hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_strid
     return hipSuccess;
 }
 
+static hipError_t sa_build_finish_tiers(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                                        SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *nflagged);
+
 hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
                            SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *nflagged)
+{
+    s.partial_used = false;
+    const hipError_t e = sa_build_finish_tiers(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, nflagged);
+    // whatever the tiers did, the side stream's stages (if any were queued) are joined into st here
+    if (s.partial_used) { const hipError_t j = hipStreamWaitEvent(st, s.ev_join, 0); if (e == hipSuccess && j != hipSuccess) return j; }
+    return e;
+}
+
+static hipError_t sa_build_finish_tiers(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nblk,
+                                        SaScratch &s, uint8_t *bwt_out, size_t bwt_stride, int *d_index, uint32_t *nflagged)
 {
     if (nflagged) *nflagged = 0;
     if (!s.pending) return hipSuccess;                       // general sorter only: nothing was deferred
@@ -1249,12 +1267,31 @@ hipError_t sa_build_finish(hipStream_t st, const uint8_t *text, size_t text_stri
             // some blocks were given up on.  Those whose only trouble was a bucket past its slot get ONE more attempt with
             // other samples (a bucket of 4033-4200 words where 4032 fit: ~1 % of log-style blocks; the general sorter
             // costs ten times the sample sorter, and its rounds hold the host)
+            if (s.stage_partial) GLC_TRY(ss_split_masks(st, nblk, s));
             GLC_TRY(ss_retry_prepare(st, nflag, s));
             GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.fs_nflag + 2, 4, hipMemcpyDeviceToHost, st));
             GLC_TRY(hipEventRecord(s.ev_flag, st));
             GLC_TRY(hipEventSynchronize(s.ev_flag));
             const uint32_t again = s.h_max_cnt[6];
             s.last_retried = again;
+            if (again && s.stage_partial && left < nflag) {
+                // the stages behind the sort for the blocks the first attempt finished, on a side stream BESIDE the second attempt
+                // (ss_mask was written before ss_retry_prepare touched anything: see above)
+                if (!s.aux) {
+                    // (lowest priority: the side stream's kernels fill the chip, the second attempt's small launches on `st` are a
+                    //  chain of latencies -- with equal priorities its bucketing pass took 614 us beside k_mtf_encode instead of 27)
+                    int least = 0, greatest = 0;
+                    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                    GLC_TRY(hipStreamCreateWithPriority(&s.aux, hipStreamNonBlocking, least));
+                    GLC_TRY(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming));
+                    GLC_TRY(hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming));
+                }
+                GLC_TRY(hipEventRecord(s.ev_fork, st));
+                GLC_TRY(hipStreamWaitEvent(s.aux, s.ev_fork, 0));
+                GLC_TRY(s.stage_partial(s.aux, s.ss_mask[0]));
+                GLC_TRY(hipEventRecord(s.ev_join, s.aux));
+                s.partial_used = true;
+            }
             if (again) {
                 s.h_max_cnt[7] = left - again;                 // the others stay given up on; the second attempt adds its own
                 GLC_TRY(hipMemcpyAsync(s.fs_nflag + 1, s.h_max_cnt + 7, 4, hipMemcpyHostToDevice, st));

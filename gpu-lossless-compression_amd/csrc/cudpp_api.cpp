@@ -318,12 +318,25 @@ static CUDPPResult compress_batch(CUDPPHandle planHandle, const unsigned char *d
     const bool speculate = !tiers || p->sa.sorter != 4;
     if (speculate) after_sort(nullptr, tiers ? p->sa.fs_keep[k] : nullptr, false);
     uint32_t nflag = 0;
+    // (not in the pipelined mode, whose stages have a stream of their own already, nor under the stage timer, whose events sit on
+    //  the plan's stream: the blocks the sample sorter's first attempt finished get their MTF + Huffman beside its second attempt)
+    if (speculate && tiers && !p->pipelined && !p->timing)
+        p->sa.stage_partial = [&](hipStream_t aux, const uint32_t *only) -> hipError_t {
+            hipError_t e2 = mtf_forward(aux, bwt, p->n, n, nb, p->d_mtf, p->n, p->mtf, p->huff.sub_hist, only, true);
+            if (e2 == hipSuccess) e2 = huff_build(aux, n, nb, p->huff, d_hist, d_encodeOffset, offsetStride, d_compressedSize,
+                                                  compact ? (size_t)(HUFF_MAX_WORDS + 1) * nsub : compressedStrideWords, p->d_status, nullptr, only);
+            if (e2 == hipSuccess && !compact) e2 = huff_pack(aux, p->d_mtf, p->n, n, nb, p->huff, d_encodeOffset, offsetStride, d_compressed,
+                                                             compressedStrideWords, only);
+            return e2;
+        };
     if (e == hipSuccess) e = sa_build_finish(st, d_uncompressed, n, n, nb, p->sa, bwt, p->n, d_bwtIndex, &nflag);
+    p->sa.stage_partial = nullptr;                             // (it refers to this call's arguments)
     if (e == hipSuccess && (nflag || !speculate)) {
         // sa_build_finish has queued the other sorters for the flagged blocks on st; this pass is ordered after the
-        // last of them (ev_sorted) and touches only those blocks
+        // last of them (ev_sorted) and touches only those blocks -- those still open after the sample sorter's first attempt if
+        // the others' stages have been queued beside its second one
         tm.mark(1);                                            // the sort stage ends here: the other tiers' time is the sort's
-        after_sort(nullptr, speculate && tiers ? p->sa.fs_redo[k] : nullptr, true);   // (the blocks of the other tiers: text-like)
+        after_sort(nullptr, p->sa.partial_used ? p->sa.ss_mask[1] : (speculate && tiers ? p->sa.fs_redo[k] : nullptr), true);   // (the blocks of the other tiers: text-like)
     }
     if (e == hipSuccess && compact) {
         e = huff_block_offsets(s2, d_compressedSize, nb, d_blockOffsets, d_startOffset, capacityWords, p->d_status);

