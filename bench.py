@@ -436,10 +436,24 @@ def leg_single_call(torch, glc, dev, d_block, iters=20, what="Zipf"):
         t_call = time.perf_counter() - t0
         plan.synchronize()
         assert rc == 0
+        # the reference caller's LOOP (test_compress.cpp:744: one cudppCompress call per block): `loop_calls` calls back to back,
+        # ONE wait at the end.  Each call still holds the host for the sorter's one readback, and one block's chain of ~20 small
+        # dependent kernels cannot fill the chip: this figure is the price of the one-block-per-call entry point
+        # (glcCompressBatch takes the same blocks in one call: `value`).
+        loop_calls = 256
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(loop_calls):
+            rc = L.cudppCompress(plan.handle, d_block.data_ptr(), o["idx"].data_ptr(), None, o["hist"].data_ptr(),
+                                 o["off"].data_ptr(), o["size"].data_ptr(), o["words"].data_ptr(), n)
+            assert rc == 0
+        plan.synchronize()
+        t_loop = time.perf_counter() - t0
     med = statistics.median(ts)
     return {"api": "cudppCompress (reference entry point), plan rows=1, one 1 MiB %s block, glcPlanSynchronize after each call" % what,
             "ms_per_call_median": round(med * 1e3, 4), "GBps": round(n / med / 1e9, 4),
             "ms_host_in_call": round(t_call * 1e3, 4), "calls": iters,
+            "loop_GBps": round(loop_calls * n / t_loop / 1e9, 3), "loop_calls": loop_calls, "loop_ms_per_call": round(t_loop * 1e3 / loop_calls, 4),
             "host_syncs_per_call": "1 inside (flagged-block count of the bucket sorter) + the caller's wait"}
 
 
@@ -548,6 +562,42 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
                                           "equal bytes inside: given up by the sample sorter for depth, finished by prefix doubling resumed from "
                                           "its tolerant form"}
     del d_pd, outp, back
+    # ... and what no tier but the general sorter takes: TWO periodic regions in one block (the
+    # periodic tier takes blocks that are ONE stretch), and a long periodic stretch inside otherwise ordinary (Zipf) data.  64
+    # blocks, 32 of each kind, every block distinct.
+    rng2 = np.random.default_rng(11)
+    zb = zipf_blocks_on_device(torch, dev, 32, 100, 1).view(32, n).clone()
+    two = []
+    for k in range(32):
+        p1, p2 = int(rng2.integers(3, 400)), int(rng2.integers(3, 400))
+        a = np.tile(rng2.integers(0, 256, p1, dtype=np.uint8), n // (2 * p1) + 1)[:n // 2]
+        b2 = np.tile(rng2.integers(0, 256, p2, dtype=np.uint8), n // (2 * p2) + 1)[:n - n // 2]
+        two.append(np.concatenate([a, b2]))
+        unit = torch.from_numpy(rng2.integers(0, 256, int(rng2.integers(20, 300)), dtype=np.uint8)).to(dev)
+        o0 = int(rng2.integers(100000, 500000))
+        zb[k, o0:o0 + 262144] = unit.repeat(262144 // unit.numel() + 1)[:262144]
+    d_tr = torch.cat([torch.from_numpy(np.stack(two)).to(dev), zb]).reshape(-1).contiguous()
+    ntr = 64
+    del zb, two
+    with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=ntr) as plan:
+        outr = glc.compress_batch(plan, d_tr, n, ntr)
+        plan.synchronize()
+        ts = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            glc.compress_batch_into(plan, d_tr, n, ntr, outr)
+            plan.synchronize()
+            ts.append(time.perf_counter() - t0)
+        f1, f2 = plan.last_sort_stats()
+        back = glc.decompress_batch(plan, outr, n, ntr)
+        torch.cuda.synchronize()
+        out_res["two_regions"] = {"GBps": round(n * ntr / min(ts) / 1e9, 2), "ms_per_block": round(min(ts) * 1e3 / ntr, 3), "blocks": ntr,
+                                  "blocks_left_by_sample_sorter": f2, "blocks_finished_by_periodic_tier": plan.last_sort_periodic(),
+                                  "blocks_resumed": plan.last_sort_resumed(), "round_trip_ok": bool(torch.equal(back, d_tr)),
+                                  "what": "32 blocks of two different periodic halves + 32 Zipf blocks with a 256 KiB periodic stretch inside: "
+                                          "neither one periodic stretch nor ordered to depth 128 by the tolerant pass everywhere"}
+    del d_tr, outr, back
     out_res["single_call_text"] = leg_single_call(torch, glc, dev, one, what="text")
     out_res["note"] = ("cudppCompress path (glcCompressBatch, one plan, %d distinct synthetic 1 MiB blocks per call); best of %d calls "
                        "incl. the host wait" % (rows, iters))
@@ -777,7 +827,7 @@ def compact_line(res, details_path):
                       "dtype", "data"])
     line["vs_baseline"] = res.get("vs_baseline")
     cfg = res.get("config", {})
-    line["config"] = pick(cfg, ["workload", "block_bytes", "blocks_per_gpu", "batch_rows", "output_layout", "stage_pipelining", "drain_between_steps", "parallelism",
+    line["config"] = pick(cfg, ["workload", "block_bytes", "blocks_per_gpu", "batch_rows", "batch_rows_asked", "output_layout", "stage_pipelining", "drain_between_steps", "parallelism",
                                 "blocks_left_by_bucket_sorter", "blocks_left_by_sample_sorter"])
     if "output_layout" in line["config"]:
         line["config"]["output_layout"] = line["config"]["output_layout"].split(":")[0]
@@ -797,11 +847,14 @@ def compact_line(res, details_path):
     sc = res.get("single_call") or {}
     tl = res.get("text_like") or {}
     line["single_call"] = {"zipf_ms": sc.get("ms_per_call_median"), "zipf_host_ms_in_call": sc.get("ms_host_in_call"),
+                           "loop_GBps": sc.get("loop_GBps"), "text_loop_GBps": (tl.get("single_call_text") or {}).get("loop_GBps"),
                            "text_ms": (tl.get("single_call_text") or {}).get("ms_per_call_median"), "host_syncs_in_call": sc.get("host_syncs_per_call")}
     if tl:
         line["text_like"] = {k: pick(tl[k], ["GBps", "ratio", "distinct_blocks", "blocks_left_by_sample_sorter", "round_trip_ok"]) for k in ("text", "log") if k in tl}
         if tl.get("deep_repeats"):
             line["text_like"]["deep_repeats"] = pick(tl["deep_repeats"], ["GBps", "ms_per_block", "blocks", "blocks_left_by_sample_sorter", "blocks_finished_by_periodic_tier", "round_trip_ok"])
+        if tl.get("two_regions"):
+            line["text_like"]["two_regions"] = pick(tl["two_regions"], ["GBps", "blocks", "blocks_left_by_sample_sorter", "blocks_resumed", "round_trip_ok"])
         if tl.get("partly_deep"):
             line["text_like"]["partly_deep"] = pick(tl["partly_deep"], ["GBps", "blocks", "blocks_resumed", "GBps_general_sorter_from_scratch", "round_trip_ok"])
     cz = res.get("culzss") or {}
@@ -939,8 +992,13 @@ def main():
         free_b //= world
     if world > 1:
         free_b -= 2 * world * nblocks * MiB                   # rank 0 also holds what it gathers (one shot + per batch)
+    rows_asked = rows
     while rows > 64 and nplans * rows * 36 * MiB > 0.85 * free_b:
         rows //= 2
+    if rows != rows_asked and rank == 0:
+        # not silently: the batch size is part of `value` (2048-row batches give ~1 % more than 1024-row ones)
+        print("bench.py: batch rows %d -> %d (%.1f GB of HBM free, %d plans x %d rows x ~36 MiB asked for)"
+              % (rows_asked, rows, free_b / 1e9, nplans, rows_asked), file=sys.stderr, flush=True)
     plans, streams = [], []
     for _ in range(nplans):
         pl = glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=rows)
@@ -1422,7 +1480,7 @@ def main():
                                          "(+ per-block offsets, sizes, histograms, sub-block offsets, BWT indices); no copy pass"
                                          if use_compact else
                                          "strided (the reference's per-block layout, glcCompressBatch) + one glcCompactStreams copy pass into a contiguous array"),
-                       "block_bytes": n, "blocks_per_gpu": nblocks, "batch_rows": rows,
+                       "block_bytes": n, "blocks_per_gpu": nblocks, "batch_rows": rows, "batch_rows_asked": rows_asked,
                        "plans_per_gpu": nplans, "encode_host_threads": min(args.enc_threads, nplans),
                        "decode_host_threads": min(args.dec_threads, nplans),
                        "suffix_sorter": {0: "bucket sorter; sample sorter for the blocks it flags; general sorter for what that flags",

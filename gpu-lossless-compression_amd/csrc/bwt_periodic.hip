@@ -57,7 +57,7 @@ __device__ __forceinline__ bool per_eq16(const uint8_t *a, const uint8_t *b)
 __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                        const uint32_t *__restrict__ list, const uint32_t *__restrict__ flag,
                                                        uint4 *__restrict__ info, uint32_t *__restrict__ plist,
-                                                       uint32_t *__restrict__ pcount)
+                                                       uint32_t *__restrict__ pcount, uint32_t take)
 {
     __shared__ uint32_t s_cand[PER_PMAX / 32];
     __shared__ uint32_t s_e, s_p;
@@ -97,9 +97,12 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         const uint32_t t = n - e, L = PER_Z * per_span(p, t);    // (L: the explicit zone, Z spans)
         if (e > emax && t <= PER_PMAX && L <= PER_Z * PER_PMAX && e >= L + 2 * p + 1 && per_text_len(p, t) + 16 <= PER_NU) {
             if (tid == 0) {
-                const uint32_t slot = atomicAdd(pcount, 1u);
-                plist[slot] = b;
-                info[b] = make_uint4(p, e, (e == n || T[e] < T[e - p]) ? 1u : 0u, slot);
+                const uint32_t slot = atomicAdd(pcount, 1u);   // (past `take` slots: the block stays with the tiers behind this one; the host clamps the count)
+                if (slot < take) {
+                    atomicMax(pcount + 1, per_text_len(p, t) + 16u);   // the longest text of representatives of the call: they are sorted as one batch
+                    plist[slot] = b;
+                    info[b] = make_uint4(p, e, (e == n || T[e] < T[e - p]) ? 1u : 0u, slot);
+                }
             }
             return;
         }
@@ -215,8 +218,9 @@ hipError_t per_reserve(SaScratch &s)
     GLC_TRY(A((void **)&s.per_list, (size_t)s.rows * 4));
     GLC_TRY(A((void **)&s.per_ok, (size_t)s.rows * 4));
     GLC_TRY(A((void **)&s.per_count, 16));
-    GLC_TRY(A((void **)&s.per_base, (size_t)s.rows * (PER_NU + 1) * 4));
-    GLC_TRY(A((void **)&s.per_text, (size_t)s.rows * PER_NU));
+    const size_t take = s.rows < PER_TAKE ? s.rows : PER_TAKE;
+    GLC_TRY(A((void **)&s.per_base, take * (PER_NU + 1) * 4));
+    GLC_TRY(A((void **)&s.per_text, take * PER_NU));
     return hipSuccess;
 }
 
@@ -224,7 +228,7 @@ hipError_t per_detect(hipStream_t st, const uint8_t *text, size_t text_stride, u
 {
     GLC_TRY(hipMemsetAsync(s.per_count, 0, 16, st));
     hipLaunchKernelGGL(k_per_detect, dim3(nlisted), dim3(PER_NT), 0, st, text, text_stride, n, s.ss_list, s.ss_flag, s.per_info,
-                       s.per_list, s.per_count);
+                       s.per_list, s.per_count, s.rows < PER_TAKE ? s.rows : PER_TAKE);
     return hipGetLastError();
 }
 
@@ -240,7 +244,7 @@ hipError_t per_expand(hipStream_t st, const uint8_t *text, size_t text_stride, u
 {
     hipLaunchKernelGGL(k_per_bases, dim3(nper), dim3(PER_NT), 0, st, n, s.per_list, s.per_info, s.sa, s.nmax, nu, s.per_base, s.per_ok);
     hipLaunchKernelGGL(k_per_rows, dim3((n + 4095) / 4096, nper), dim3(256), 0, st, text, text_stride, n, s.per_list, s.per_info, s.sa,
-                       s.nmax, nu, s.per_base, s.per_ok, bwt_out, bwt_stride, d_index, s.ss_flag, s.fs_lcnt, s.per_count + 1);
+                       s.nmax, nu, s.per_base, s.per_ok, bwt_out, bwt_stride, d_index, s.ss_flag, s.fs_lcnt, s.per_count + 2);
     return hipGetLastError();
 }
 

@@ -1309,33 +1309,24 @@ static hipError_t sa_build_finish_tiers(hipStream_t st, const uint8_t *text, siz
             // Blocks that are ONE periodic stretch (a page repeated, a short pattern, one byte up to a different last one):
             // every suffix ties with the one a period further on for nearly the whole block -- ~18 doubling rounds over a
             // million live suffixes.  Their suffix array has a closed form over the sorted rotations of the period and the
-            // few suffixes around the break (bwt_periodic.hip); only those -- a text of <= 5 p + 2 bytes per block -- are
+            // few suffixes around the break (bwt_periodic.hip); only those -- a text of <= 7 p + 2 bytes per block -- are
             // sorted, by the general sorter, whatever the block's size.
             GLC_TRY(per_reserve(s));
             GLC_TRY(per_detect(st, text, text_stride, n, nflag, s));
-            GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.per_count, 4, hipMemcpyDeviceToHost, st));
+            GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.per_count, 8, hipMemcpyDeviceToHost, st));   // {blocks taken, longest text of representatives}
             GLC_TRY(hipEventRecord(s.ev_flag, st));
             GLC_TRY(hipEventSynchronize(s.ev_flag));
-            const uint32_t nper = s.h_max_cnt[6];
+            const uint32_t nper = s.h_max_cnt[6] < PER_TAKE ? s.h_max_cnt[6] : PER_TAKE;   // (k_per_detect takes no more than its scratch holds)
             if (nper) {
-                // the longest text of representatives among the taken blocks (they are sorted as one batch of equal length)
-                std::vector<uint4> info(s.rows);
-                std::vector<uint32_t> lst(nper);
-                GLC_TRY(hipMemcpyAsync(info.data(), s.per_info, (size_t)s.rows * sizeof(uint4), hipMemcpyDeviceToHost, st));
-                GLC_TRY(hipMemcpyAsync(lst.data(), s.per_list, (size_t)nper * 4, hipMemcpyDeviceToHost, st));
-                GLC_TRY(hipStreamSynchronize(st));
-                uint32_t nu = 64;
-                for (uint32_t k = 0; k < nper; k++) {
-                    const uint4 in = info[lst[k]];
-                    const uint32_t need = per_text_len(in.x, n - in.y) + 16;
-                    if (need > nu) nu = need;
-                }
+                // (the longest text of representatives among the taken blocks -- they are sorted as one batch of equal length -- comes
+                //  with the count: round 5 copied every block's info to the host and waited a second time for it: ADVICE r5)
+                uint32_t nu = s.h_max_cnt[7] < 64 ? 64 : s.h_max_cnt[7];
                 nu = (nu + 15u) & ~15u;
                 if (nu > PER_NU) nu = PER_NU;
                 GLC_TRY(per_text(st, text, text_stride, n, nper, nu, s));
                 GLC_TRY(sa_build_general(st, s.per_text, PER_NU, nu, nper, s, nullptr, 0, nullptr, nullptr, nullptr, nper));
                 GLC_TRY(per_expand(st, text, text_stride, n, nper, nu, s, bwt_out, bwt_stride, d_index));
-                GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.per_count + 1, 4, hipMemcpyDeviceToHost, st));
+                GLC_TRY(hipMemcpyAsync(s.h_max_cnt + 6, s.per_count + 2, 4, hipMemcpyDeviceToHost, st));
                 GLC_TRY(hipEventRecord(s.ev_flag, st));
                 GLC_TRY(hipEventSynchronize(s.ev_flag));
                 const uint32_t done = s.h_max_cnt[6];

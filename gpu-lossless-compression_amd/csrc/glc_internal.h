@@ -31,6 +31,7 @@ constexpr uint32_t FS_MAXNB = 512;               // buckets per block at n = 2^2
 constexpr uint32_t FS_MAXNB_LOG2 = 9;
 // periodic tier (bwt_periodic.hip): blocks that are one periodic stretch with a period of up to PER_PMAX symbols
 constexpr uint32_t PER_PMAX = 4096;
+constexpr uint32_t PER_TAKE = 256;                   // blocks of one call the periodic tier takes (its scratch, ~140 KB per slot, is sized by this, not by the plan's rows)
 constexpr uint32_t PER_Z    = 2;                     // the explicit zone before the break is PER_Z * L symbols wide (bwt_periodic.hip: why 2)
 constexpr uint32_t PER_NU   = (2 * PER_Z + 3) * PER_PMAX + 32;   // bytes of the text of representatives: Z L + 2 p + 1 | separator | Z L + t | padding
 // L: the multiple of the period p that covers the longer of the period and the tail t
@@ -196,9 +197,9 @@ struct SaScratch {
     bool      periodic = true;                   // glcPlanSetSorter 7 switches it off
     uint4    *per_info = nullptr;                // [rows] {period, first break, exit smaller?, slot}
     uint32_t *per_list = nullptr, *per_ok = nullptr;   // [rows] taken blocks by slot; whose rows were written
-    uint32_t *per_count = nullptr;               // [4] taken, finished
-    uint32_t *per_base = nullptr;                // [rows][PER_NU + 1] first row of every representative
-    uint8_t  *per_text = nullptr;                // [rows][PER_NU] the texts of representatives
+    uint32_t *per_count = nullptr;               // [4] taken, bytes of the longest text of representatives, finished
+    uint32_t *per_base = nullptr;                // [min(rows, PER_TAKE)][PER_NU + 1] first row of every representative
+    uint8_t  *per_text = nullptr;                // [min(rows, PER_TAKE)][PER_NU] the texts of representatives
     uint32_t  last_periodic = 0;                 // blocks of the last sa_build this tier finished
     uint32_t  resume_min = 4;                    // fewest blocks given up on for depth that are worth the tolerant pass (0: never; sorter modes 5 / 6)
     bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
@@ -259,9 +260,9 @@ hipError_t ss_retry_prepare(hipStream_t st, uint32_t nflag, SaScratch &s, uint32
 hipError_t ss_split_masks(hipStream_t st, uint32_t nblk, SaScratch &s);
 
 // periodic tier (bwt_periodic.hip); enqueue only.  per_detect lists the taken blocks of s.ss_list[0 .. nlisted) whose ss_flag is
-// raised (count -> s.per_count[0]); per_text writes their texts of representatives (nu bytes each, stride PER_NU); per_expand
+// raised (count -> s.per_count[0], the longest text of representatives -> s.per_count[1]); per_text writes their texts of representatives (nu bytes each, stride PER_NU); per_expand
 // turns the suffix arrays of those texts (s.sa, rows 0 .. nper) into the blocks' BWT rows and indices, clears ss_flag /
-// fs_lcnt of every block it finishes and counts them in s.per_count[1]
+// fs_lcnt of every block it finishes and counts them in s.per_count[2]
 hipError_t per_reserve(SaScratch &s);
 hipError_t per_detect(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nlisted, SaScratch &s);
 hipError_t per_text(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nper, uint32_t nu, SaScratch &s);
