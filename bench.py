@@ -325,6 +325,27 @@ def text_blocks_on_device(torch, dev, nblocks, seed=0x5EED0001, chunk_blocks=32)
     return out
 
 
+def two_region_blocks_on_device(torch, dev, kinds="both"):
+    """64 (32 per kind) DISTINCT 1 MiB blocks that no tier but the general sorter finishes: 32 blocks of two different periodic
+    halves (periods 3..399) and 32 Zipf blocks with a 256 KiB periodic stretch (unit of 20..299 bytes) somewhere inside"""
+    import numpy as np
+    n = MiB
+    rng2 = np.random.default_rng(11)
+    zb = zipf_blocks_on_device(torch, dev, 32, 100, 1).view(32, n).clone()
+    two = []
+    for k in range(32):
+        p1, p2 = int(rng2.integers(3, 400)), int(rng2.integers(3, 400))
+        a = np.tile(rng2.integers(0, 256, p1, dtype=np.uint8), n // (2 * p1) + 1)[:n // 2]
+        b2 = np.tile(rng2.integers(0, 256, p2, dtype=np.uint8), n // (2 * p2) + 1)[:n - n // 2]
+        two.append(np.concatenate([a, b2]))
+        unit = torch.from_numpy(rng2.integers(0, 256, int(rng2.integers(20, 300)), dtype=np.uint8)).to(dev)
+        o0 = int(rng2.integers(100000, 500000))
+        zb[k, o0:o0 + 262144] = unit.repeat(262144 // unit.numel() + 1)[:262144]
+    halves = torch.from_numpy(np.stack(two)).to(dev)
+    parts = {"both": [halves, zb], "halves": [halves], "stretch": [zb]}[kinds]
+    return torch.cat(parts).reshape(-1).contiguous()
+
+
 def effective_cores():
     """cores this process may actually use: affinity mask, capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0))
@@ -565,20 +586,8 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
     # ... and what no tier but the general sorter takes: TWO periodic regions in one block (the
     # periodic tier takes blocks that are ONE stretch), and a long periodic stretch inside otherwise ordinary (Zipf) data.  64
     # blocks, 32 of each kind, every block distinct.
-    rng2 = np.random.default_rng(11)
-    zb = zipf_blocks_on_device(torch, dev, 32, 100, 1).view(32, n).clone()
-    two = []
-    for k in range(32):
-        p1, p2 = int(rng2.integers(3, 400)), int(rng2.integers(3, 400))
-        a = np.tile(rng2.integers(0, 256, p1, dtype=np.uint8), n // (2 * p1) + 1)[:n // 2]
-        b2 = np.tile(rng2.integers(0, 256, p2, dtype=np.uint8), n // (2 * p2) + 1)[:n - n // 2]
-        two.append(np.concatenate([a, b2]))
-        unit = torch.from_numpy(rng2.integers(0, 256, int(rng2.integers(20, 300)), dtype=np.uint8)).to(dev)
-        o0 = int(rng2.integers(100000, 500000))
-        zb[k, o0:o0 + 262144] = unit.repeat(262144 // unit.numel() + 1)[:262144]
-    d_tr = torch.cat([torch.from_numpy(np.stack(two)).to(dev), zb]).reshape(-1).contiguous()
+    d_tr = two_region_blocks_on_device(torch, dev)
     ntr = 64
-    del zb, two
     with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=ntr) as plan:
         outr = glc.compress_batch(plan, d_tr, n, ntr)
         plan.synchronize()

@@ -669,7 +669,13 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_rank1(const uint64_t *__restr
 // flagged blocks (only those) go through the global radix sort afterwards.
 // ---------------------------------------------------------------------------
 constexpr uint32_t RL_T = 2048, RL_HALO = 2048, RL_NT = 256;
-constexpr uint32_t RL_MAXG = 1024;                              // longest group ranked by direct count
+#ifndef GLC_RL_MAXG
+#define GLC_RL_MAXG 128
+#endif
+constexpr uint32_t RL_MAXG = GLC_RL_MAXG;                       // longest group ranked by direct count (quadratic in the group: 1024 until
+                                                                // round 6 -- a 256 KiB periodic stretch inside Zipf data spent a third of its 17.8 ms
+                                                                // per 32 blocks counting inside groups of hundreds; 128: 12.8 ms, 32: the same, and
+                                                                // bench.py's partly_deep batch 9.4 / 9.2 / 10.5 ms)
 constexpr uint32_t RL_E = (RL_T + RL_HALO + 1 + RL_NT - 1) / RL_NT;   // staged entries per thread (17)
 
 __global__ __launch_bounds__(RL_NT) void k_refine_local(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
