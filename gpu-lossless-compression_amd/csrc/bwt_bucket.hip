@@ -1158,9 +1158,13 @@ __global__ __launch_bounds__(256) void k_fs_ties(const uint8_t *__restrict__ tex
 //  pipelining the next call clears `flag` while they may still be reading)
 // nflag[0] = flagged blocks; nflag[3] = ticket of this launch's workgroups: the last one stores the count where the host reads
 // it (h_nflag: pinned, device-mapped) -- a copy command behind the pass was one more launch in every call
+// nflag[4] = blocks the text-likeness probe did NOT call text-like (constant blocks apart): h_nflag[1].  The host's streak of
+// "every block of the call was text-like" (sa_build_begin: small calls skip the bucket sorter's attempt while it lasts) ends
+// with the first such block, also in a call that skipped.
 __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint32_t nblk, uint32_t *__restrict__ lcnt,
                             uint32_t *__restrict__ nflag, uint32_t *__restrict__ redo, uint32_t *__restrict__ keep,
-                            uint32_t *__restrict__ list, uint32_t *__restrict__ h_nflag)
+                            uint32_t *__restrict__ list, uint32_t *__restrict__ h_nflag, const uint32_t *__restrict__ dup,
+                            uint32_t dup_flag)
 {
     __shared__ uint32_t s_last;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1170,6 +1174,7 @@ __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint3
         redo[b] = f;
         keep[b] = f ? 0u : 1u;
         if (f) list[atomicAdd(nflag, 1u)] = b;                 // (any order)
+        if (flag[b] != FS_DONE && dup[b] < dup_flag) atomicAdd(nflag + 4, 1u);
     }
     __threadfence();
     __syncthreads();
@@ -1177,6 +1182,7 @@ __global__ void k_fs_finish(const uint32_t *__restrict__ flag, uint32_t n, uint3
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
         __threadfence();
+        reinterpret_cast<volatile uint32_t *>(h_nflag)[1] = atomicAdd(nflag + 4, 0u);
         *reinterpret_cast<volatile uint32_t *>(h_nflag) = atomicAdd(nflag, 0u);
         __threadfence_system();
     }
@@ -1188,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__res
                                                   uint32_t *__restrict__ flag, uint32_t flag_value, uint32_t *__restrict__ wlcnt,
                                                   uint32_t *__restrict__ dup, uint32_t *__restrict__ nflag)
 {
-    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + nf + 3u * nblk + 4u;
+    const uint32_t nh = nblk * 256u, nf = nblk * FS_MAXNB, total = nh + nf + 3u * nblk + 8u;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         if (i < nh) hist[i] = 0;
         else if (i < nh + nf) fill[i - nh] = 0;
@@ -1197,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_fs_clear(uint32_t nblk, uint32_t *__res
             if (j < nblk) flag[j] = flag_value;
             else if (j < 2 * nblk) wlcnt[j - nblk] = 0;
             else if (j < 3 * nblk) dup[j - 2 * nblk] = 0;
-            else nflag[j - 3 * nblk] = 0;                       // [0] flagged blocks, [1] [2] the sample sorter's, [3] k_fs_finish's ticket
+            else nflag[j - 3 * nblk] = 0;                       // [0] flagged blocks, [1] [2] the sample sorter's, [3] k_fs_finish's ticket, [4] blocks the probe did not call text-like
         }
     }
 }
@@ -2646,7 +2652,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
 {
     const uint32_t nbl = fs_bucket_log2(n), nb = 1u << nbl;
     {
-        const uint32_t words = nblk * (256u + FS_MAXNB + 3u) + 4u, g = (words + 1023) / 1024;
+        const uint32_t words = nblk * (256u + FS_MAXNB + 3u) + 8u, g = (words + 1023) / 1024;
         // (skip_tier1: every block starts flagged -- no attempt, the sample sorter takes them all)
         hipLaunchKernelGGL(k_fs_clear, dim3(g < 2048 ? g : 2048), dim3(256), 0, st, nblk, s.fs_hist, s.fs_fill, s.fs_flag,
                            s.skip_tier1 ? 1u : 0u, s.fs_wlcnt, s.fs_dup, s.fs_nflag);
@@ -2665,9 +2671,9 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_tables, dim3(nblk), dim3(256), 0, st, s.fs_hist, n, s.fs_tab, s.fs_dup, s.fs_flag, text, text_stride,
                        bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax, hstep);
     if (s.skip_tier1) {
-        // most blocks of the plan's previous call were flagged: no attempt, every block goes to the sample sorter
+        // sorter mode 4, or a small call behind a streak of all-text-like calls: no attempt, every block goes to the sample sorter
         hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
-                           s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list, h_nflag);
+                           s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list, h_nflag, s.fs_dup, (FS_DUP_FLAG + hstep - 1) / hstep);
         return hipGetLastError();
     }
     // Sub-waves (GLC_FS_SUBWAVE = blocks per sub-wave, 0 = the whole call at once): the 8-byte suffix words of a block make
@@ -2746,7 +2752,7 @@ hipError_t fs_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     hipLaunchKernelGGL(k_fs_ties, dim3(tg_env > 0 ? tg_env : 24, nblk), dim3(256), 0, st, text, text_stride, n, s.fs_wl, s.fs_wl_cap, s.fs_wlcnt,
                        s.fs_flag, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     hipLaunchKernelGGL(k_fs_finish, dim3((nblk + 255) / 256), dim3(256), 0, st, s.fs_flag, n, nblk, s.fs_lcnt, s.fs_nflag,
-                       s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list, h_nflag);
+                       s.fs_redo[s.parity & 1], s.fs_keep[s.parity & 1], s.ss_list, h_nflag, s.fs_dup, (FS_DUP_FLAG + hstep - 1) / hstep);
     return hipGetLastError();
 }
 

@@ -979,7 +979,7 @@ hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows)
     GLC_TRY(A((void **)&s.ss_mask[1], (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_dup, (size_t)rows * 4));
     GLC_TRY(A((void **)&s.fs_zero, (size_t)rows * 4));
-    GLC_TRY(A((void **)&s.fs_nflag, 16));
+    GLC_TRY(A((void **)&s.fs_nflag, 32));
     GLC_TRY(A((void **)&s.ss_list, (size_t)rows * 4 * 3));
     GLC_TRY(A((void **)&s.ss_split, (size_t)rows * FS_MAXNB * 8 * 3));    // words, then the first 8 text bytes of every splitter, then the next 8
     GLC_TRY(A((void **)&s.ss_flag, (size_t)rows * 4));
@@ -1225,7 +1225,7 @@ hipError_t sa_build_begin(hipStream_t st, const uint8_t *text, size_t text_strid
     }
     // bucket sorter first; the suffix array itself is only written when it is the result asked for
     if (!bwt_out) GLC_TRY(sa_general_reserve(s, true));
-    s.skip_tier1 = s.sorter == 4;                            // the caller knows its data is text-like: no bucket-sorter attempt
+    s.skip_tier1 = sa_skips_tier1(s, nblk);                  // the caller knows its data is text-like (sorter 4), or the plan's last calls say so
     GLC_TRY(fs_build(st, text, text_stride, n, nblk, s, bwt_out, bwt_stride, d_index, bwt_out ? nullptr : s.sa));
     // (the flagged-block count is in s.h_max_cnt[4] when the pass's last kernel is through: it writes it there itself --
     //  k_fs_finish / k_fs_ties -- where a copy command behind the pass was one more ~5 us link in a single call's chain)
@@ -1256,6 +1256,9 @@ static hipError_t sa_build_finish_tiers(hipStream_t st, const uint8_t *text, siz
     s.pending = false;
     GLC_TRY(hipEventSynchronize(s.ev_flag));
     uint32_t nflag = s.h_max_cnt[4];
+    // the streak of calls whose every block the probe called text-like (k_fs_finish counts the others, in skipped calls too)
+    s.last_skipped = s.skip_tier1;
+    s.textlike_streak = (nflag == nblk && s.h_max_cnt[5] == 0) ? (s.textlike_streak < 1000u ? s.textlike_streak + 1 : 1000u) : 0u;
     s.last_flagged = nflag;
     s.last_general = 0;
     s.last_retried = 0;

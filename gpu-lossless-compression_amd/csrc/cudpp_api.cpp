@@ -315,7 +315,7 @@ static CUDPPResult compress_batch(CUDPPHandle planHandle, const unsigned char *d
     // Blocks the bucket sorter has given up on (flagged up front as text-like, or after its attempt) are skipped by this
     // speculative pass (`only` = the sorter's keep mask of this call) and encoded below, once their sort is final.
     const bool tiers = p->sa.sorter == 0 || p->sa.sorter == 3 || p->sa.sorter == 4;
-    const bool speculate = !tiers || p->sa.sorter != 4;
+    const bool speculate = !tiers || !sa_skips_tier1(p->sa, nb);   // (no attempt of the bucket sorter: nothing to speculate on)
     if (speculate) after_sort(nullptr, tiers ? p->sa.fs_keep[k] : nullptr, false);
     uint32_t nflag = 0;
     // (not in the pipelined mode, whose stages have a stream of their own already, nor under the stage timer, whose events sit on
@@ -647,6 +647,19 @@ CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out)
     SaScratch *s = sa_of(p);
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
     out[0] = s->last_retried;
+    return CUDPP_SUCCESS;
+}
+
+// out[0] = 1 if the plan's last call skipped the bucket sorter's attempt (sorter mode 4, or a small call behind a streak of calls
+// whose every block the text-likeness probe flagged), out[1] = the streak
+CUDPPResult glcPlanLastSortSkipped(CUDPPHandle planHandle, unsigned int *out2)
+{
+    PlanBase *p = plan_from<PlanBase>(planHandle);
+    if (!p || planHandle == CUDPP_INVALID_HANDLE || !out2) return CUDPP_ERROR_INVALID_HANDLE;
+    SaScratch *s = sa_of(p);
+    if (!s) return CUDPP_ERROR_INVALID_PLAN;
+    out2[0] = s->last_skipped ? 1u : 0u;
+    out2[1] = s->textlike_streak;
     return CUDPP_SUCCESS;
 }
 

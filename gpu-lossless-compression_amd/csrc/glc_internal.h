@@ -183,7 +183,7 @@ struct SaScratch {
     uint32_t *fs_dup = nullptr;                  // [rows] repeated 6-grams among the samples k_fs_hist looks at (text-likeness probe)
     uint32_t *fs_zero = nullptr;                 // [rows] bucket that holds the word of suffix 0 (k_fs_part -> k_fs_sort_bwt: the BWT index is looked for there only)
     uint32_t  parity = 0;                        // set by the caller before sa_build_begin
-    uint32_t *fs_nflag = nullptr;                // [4] blocks flagged by the bucket sorter; given up on by the sample sorter; listed for its second attempt; ticket of the finishing kernel
+    uint32_t *fs_nflag = nullptr;                // [8] blocks flagged by the bucket sorter; given up on by the sample sorter; listed for its second attempt; ticket of the finishing kernel; blocks the probe did not call text-like
     uint4    *fs_wl = nullptr;                   // [rows][fs_wl_cap] runs of equal codes: {index << 8 | bwt, first row, first entry, size}
     uint32_t *fs_wlcnt = nullptr;                // [rows] entries in use
     uint32_t  fs_wl_cap = 0;
@@ -203,6 +203,13 @@ struct SaScratch {
     uint32_t  last_periodic = 0;                 // blocks of the last sa_build this tier finished
     uint32_t  resume_min = 4;                    // fewest blocks given up on for depth that are worth the tolerant pass (0: never; sorter modes 5 / 6)
     bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
+    // ... and, adaptively, for SMALL calls (sa_skips_tier1): the reference's callers hand over one block per call, and a text
+    // block's call spent 0.13 of its 0.69 ms on the bucket sorter's fourteen launches that find the block flagged.  After
+    // TEXT_STREAK calls in a row in which the probe called every block text-like, a call of up to TEXT_SKIP_MAX blocks goes
+    // straight to the sample sorter; the first block the probe does not call text-like (it is evaluated in skipped calls too)
+    // ends the streak.  A wrong guess costs time (that one call's blocks take the sample sorter), never correctness.
+    uint32_t  textlike_streak = 0;
+    bool      last_skipped = false;              // the plan's last sa_build skipped the bucket sorter's attempt
     // second tier (bwt_bucket.hip, string sample sort): the blocks the bucket sorter flagged
     uint32_t *ss_list = nullptr;                 // [3 rows] their block numbers; behind them the ones that get a second attempt; then the ones for the tolerant form
     uint64_t *ss_split = nullptr;                // [rows][FS_MAXNB] first suffix of every bucket as a word [code : 36 | index : 20 | 0 : 8]
@@ -226,6 +233,11 @@ struct SaScratch {
     KernelProf *prof = nullptr;                  // owned by the plan
 };
 
+constexpr uint32_t TEXT_STREAK = 2, TEXT_SKIP_MAX = 4;
+inline bool sa_skips_tier1(const SaScratch &s, uint32_t nblk)
+{
+    return s.sorter == 4 || (s.sorter == 0 && nblk <= TEXT_SKIP_MAX && s.textlike_streak >= TEXT_STREAK);
+}
 hipError_t sa_scratch_alloc(SaScratch &s, uint32_t nmax, uint32_t rows);
 hipError_t sa_general_reserve(SaScratch &s, bool only_sa);
 void       sa_scratch_free(SaScratch &s);

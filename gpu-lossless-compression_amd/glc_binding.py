@@ -38,7 +38,7 @@ CUDPP_SYMBOLS = [
     "cudppBurrowsWheelerTransform", "cudppMoveToFrontTransform", "cudppSuffixArray",
     "glcCompressBatch", "glcBwtBatch", "glcMtfBatch", "glcDecompressBatch", "glcPlanSetStream",
     "glcPlanSynchronize", "glcPlanEnableTiming", "glcPlanLastTiming", "glcPlanKernelProfile",
-    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanLastSortResumed", "glcPlanLastSortPeriodic", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcGenFloatPhilox", "glcPlanKernelProfileLost",
+    "glcCompactStreams", "glcPlanSetPipelining", "glcPlanSetSorter", "glcPlanLastSortStats", "glcPlanLastSortStatsEx", "glcPlanLastSortRetries", "glcPlanLastSortResumed", "glcPlanLastSortPeriodic", "glcPlanLastSortSkipped", "glcPlanDebugSortFlags", "glcPlanDebugBucketFill", "glcHuffmanEncodeBatch", "glcExpandStreams", "glcPlanKernelProfileEx", "glcProbeStreamRead", "glcGenZipfPhilox", "glcGenFloatPhilox", "glcPlanKernelProfileLost",
     "glcCompressBatchCompact", "glcDecompressBatchCompact",
 ]
 CULZSS_SYMBOLS = [
@@ -107,6 +107,7 @@ def lib():
     L.glcPlanLastSortRetries.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanLastSortResumed.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanLastSortPeriodic.argtypes = [sz, C.POINTER(C.c_uint)]
+    L.glcPlanLastSortSkipped.argtypes = [sz, C.POINTER(C.c_uint)]
     L.glcPlanDebugSortFlags.argtypes = [sz, C.POINTER(C.c_uint), C.POINTER(C.c_uint), sz]
     L.glcPlanDebugBucketFill.argtypes = [sz, sz, C.POINTER(C.c_uint)]
     L.glcPlanEnableTiming.argtypes = [sz, C.c_int]
@@ -308,6 +309,12 @@ class Plan:
         a = (C.c_uint * 1)()
         _chk("glcPlanLastSortPeriodic", lib().glcPlanLastSortPeriodic(self.handle, a))
         return a[0]
+
+    def last_sort_skipped(self):
+        """(skipped, streak): did the plan's last call go straight to the sample sorter, and the streak of all-text-like calls"""
+        a = (C.c_uint * 2)()
+        _chk("glcPlanLastSortSkipped", lib().glcPlanLastSortSkipped(self.handle, a))
+        return bool(a[0]), int(a[1])
 
     def enable_timing(self, mode=1):
         """0 off, 1 stage events, 3 stage events + dominant-kernel events"""

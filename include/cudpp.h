@@ -273,6 +273,11 @@ CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out);
 CUDPPResult glcPlanLastSortResumed(CUDPPHandle planHandle, unsigned int *out);
 /* out[0] = how many of the blocks the sample sorter gave up on were finished by the periodic tier (see glcPlanSetSorter) */
 CUDPPResult glcPlanLastSortPeriodic(CUDPPHandle planHandle, unsigned int *out);
+/* out2[0] = 1 if the plan's last call went straight to the sample sorter (sorter mode 4, or adaptively: a call of up to 4 blocks
+   behind two calls in a row whose every block the text-likeness probe flagged -- the reference's callers hand over one block per
+   call, test_compress.cpp:744, and a text block's call spent a fifth of its time on launches that found the block flagged);
+   out2[1] = the length of that streak.  A wrong guess costs time, never correctness. */
+CUDPPResult glcPlanLastSortSkipped(CUDPPHandle planHandle, unsigned int *out2);
 /* diagnostics (tests, tools/exp): per-block give-up flags of the last sort (bucket sorter: 1 bucket overflow / text-like, 2 deep,
  * 4 work list full; sample sorter: 1 bucket overflow, 2 deep), numBlocks entries each, either pointer may be NULL; and the
  * 512 bucket fills of one block as the last bucketing pass left them.  Both wait for the plan's stream. */
