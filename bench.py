@@ -509,6 +509,31 @@ def leg_text_like(torch, glc, dev, rows=256, iters=3):
             if name == "text":
                 one = d_in[:n].clone()
             del d_in, out, back
+    # the same two kinds in batches of the headline's size (2048 DISTINCT blocks per call): what a call's fixed parts -- the
+    # sampling kernel's one workgroup per block (the slowest block's time whatever the batch), the second attempt's chain of small
+    # launches, the bucket sorter's launches that find every block flagged -- cost a 256-block call.  New keys; `GBps` above keeps
+    # its 256-block meaning.
+    big = 2048
+    free_b, _t = torch.cuda.mem_get_info(dev)
+    if free_b > big * 40 * MiB:
+        with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=big) as plan:
+            for name, gen in (("text", text_blocks_on_device), ("log", log_buffers_on_device)):
+                d_in = gen(torch, dev, big)
+                out = glc.compress_batch(plan, d_in, n, big)
+                plan.synchronize()
+                ts = []
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    glc.compress_batch_into(plan, d_in, n, big, out)
+                    plan.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                back = glc.decompress_batch(plan, out, n, big)
+                torch.cuda.synchronize()
+                out_res[name].update({"GBps_rows2048": round(n * big / min(ts) / 1e9, 2), "ms_per_batch_rows2048": round(min(ts) * 1e3, 3),
+                                      "round_trip_ok_rows2048": bool(torch.equal(back, d_in)),
+                                      "blocks_left_by_sample_sorter_rows2048": plan.last_sort_stats()[1]})
+                del d_in, out, back
     # the cliff, measured: blocks whose repeats are deeper than the sample sorter's cap (~500 symbols) take the general
     # sorter (LSD radix passes + prefix doubling, host-driven rounds).  64 blocks, 16 of each: a 4 KiB random page repeated, one
     # byte repeated up to the last position, a two-byte period, text with a 2000-byte phrase pasted in every 16 KiB.
@@ -859,7 +884,7 @@ def compact_line(res, details_path):
                            "loop_GBps": sc.get("loop_GBps"), "text_loop_GBps": (tl.get("single_call_text") or {}).get("loop_GBps"),
                            "text_ms": (tl.get("single_call_text") or {}).get("ms_per_call_median"), "host_syncs_in_call": sc.get("host_syncs_per_call")}
     if tl:
-        line["text_like"] = {k: pick(tl[k], ["GBps", "ratio", "distinct_blocks", "blocks_left_by_sample_sorter", "round_trip_ok"]) for k in ("text", "log") if k in tl}
+        line["text_like"] = {k: pick(tl[k], ["GBps", "GBps_rows2048", "ratio", "distinct_blocks", "blocks_left_by_sample_sorter", "round_trip_ok"]) for k in ("text", "log") if k in tl}
         if tl.get("deep_repeats"):
             line["text_like"]["deep_repeats"] = pick(tl["deep_repeats"], ["GBps", "ms_per_block", "blocks", "blocks_left_by_sample_sorter", "blocks_finished_by_periodic_tier", "round_trip_ok"])
         if tl.get("two_regions"):
