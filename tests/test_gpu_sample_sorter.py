@@ -451,3 +451,25 @@ def test_small_calls_behind_a_text_like_streak_skip_the_bucket_sorter(glc, cuda)
             glc.compress_batch(plan, d5, n, 5)
             plan.synchronize()
             assert plan.last_sort_skipped()[0] is False
+
+
+@pytest.mark.parametrize("n,cut", [(70000, 0), (70003, 5), (262144, 11), (1 << 20, 13)])
+def test_first_cut_keys_tie_in_their_high_half(glc, ctx, cuda, n, cut):
+    """k_ss_cut's keys are fourteen text bytes {bytes 0..7, bytes 8..13}: records of 8 fixed bytes + 6 bytes of a three-letter alphabet +
+    2 fixed bytes make most pivots tie in the high half and differ in the low one (and in its last byte: the fourteenth); the block is
+    cut off `cut` bytes into a record, so the keys of its last suffixes reach the end of the text (the 9-bit digits) while the
+    others are bytes.  The sample sorter first (mode 4) and by the tiers' own choice."""
+    import torch
+    rng = np.random.default_rng(n + cut)
+    nrec = n // 16 + 2
+    rec = np.empty((nrec, 16), dtype=np.uint8)
+    rec[:, :8] = np.frombuffer(b"HEADER__", dtype=np.uint8)
+    rec[:, 8:14] = rng.integers(0, 3, (nrec, 6), dtype=np.uint8) + 120
+    rec[:, 14:] = np.frombuffer(b";\n", dtype=np.uint8)
+    x = rec.reshape(-1)[:n].copy()
+    want, widx = O.bwt(x)
+    with glc.Plan(ctx, glc.CUDPP_BWT, n, rows=1) as plan:
+        for mode in (4, 0):
+            plan.set_sorter(mode)
+            got, gidx = _bwt(glc, plan, torch, x)
+            assert int(gidx[0]) == widx and np.array_equal(got, want), (mode, int(np.nonzero(got != want)[0][0]) if not np.array_equal(got, want) else -1)
