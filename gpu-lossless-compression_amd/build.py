@@ -23,6 +23,9 @@ SOURCES = ["cudpp_api.cpp", "bwt_sa.hip", "bwt_bucket.hip", "bwt_periodic.hip", 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"] + os.environ.get("GLC_CXXFLAGS", "").split()
 
 
+LAST = {}                                                      # what the last build() did: {sources, compiled, linked, forced}
+
+
 def _header_mtime():
     m = 0.0
     for d in (CSRC, INC):
@@ -66,6 +69,8 @@ def build(force=False, verbose=False):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hm, os.path.getmtime(src)):
             jobs.append((src, obj))
+    global LAST
+    LAST = {"sources": len(srcs), "compiled": len(jobs), "linked": False, "forced": bool(force)}
     if not jobs and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(os.path.join(OBJ, s + ".o")) for s in srcs):
         return LIB
 
@@ -88,6 +93,7 @@ def build(force=False, verbose=False):
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("hipcc failed linking libglc_amd.so")
+    LAST["linked"] = True
     return LIB
 
 
