@@ -55,7 +55,7 @@ __device__ __forceinline__ bool per_eq16(const uint8_t *a, const uint8_t *b)
 
 // one workgroup per listed block that the other tiers gave up on: smallest period of its beginning, where it breaks
 __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
-                                                       const uint32_t *__restrict__ list, const uint32_t *__restrict__ flag,
+                                                       const uint32_t *__restrict__ list, uint32_t *__restrict__ flag,
                                                        uint4 *__restrict__ info, uint32_t *__restrict__ plist,
                                                        uint32_t *__restrict__ pcount, uint32_t take)
 {
@@ -109,6 +109,12 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         emax = max(emax, e);
         // (a candidate that is no period of the whole block: a larger one may still be -- "abab c abab c ...")
     }
+    // Not this tier's block -- but if its beginning is periodic for an eighth of the block or more, it is not the TOLERANT sample
+    // sorter's either (a quarter of its samples would tie beyond the cap: that attempt took 4.9 ms per 32 blocks of two periodic
+    // halves before it gave up).  The block's flag becomes 2 | 1 -- the value a block that is deep AND had a bucket past its slot
+    // carries, which the tolerant pass does not take either: k_ss_retry_list lists flag == 2 only -- and the general
+    // sorter (whose doubling rounds order a periodic stretch as chains, bwt_sa.hip) takes the block as it takes every flagged one.
+    if (tid == 0 && emax >= n / 8 && flag[b] == 2u) flag[b] = 3u;
 }
 
 // U of every taken block: T[0 .. Z L + 2 p + 1) | 0xFF | T[e - Z L .. n) | zeros up to nu   (below, L stands for Z L)

@@ -787,11 +787,158 @@ __global__ __launch_bounds__(SA_THREADS) void k_isa_fix(uint64_t *__restrict__ k
     }
 }
 
-// rounds >= 1: fill in rank(i+h)
+// ---------------------------------------------------------------------------
+// CHAIN GROUPS (round 6).  A group of the doubling rounds is the set of ALL suffixes that share their first h symbols.  If its
+// members, by position, are i_0 < i_1 = i_0 + d < ... < i_{L-1} = i_0 + (L - 1) d and the text is d-periodic over [i_0, i_{L-1})
+// (T[j] = T[j + d]), then suffix(i_k) = u . suffix(i_{k+1}) with ONE string u = T[i_0 .. i_0 + d) for every k < L - 1, so the
+// comparison of i_k with i_{k+1} is the comparison of i_{k+1} with i_{k+2}, ... down to that of the last two members: the whole
+// group is ONE monotone chain, ascending or descending by position, and the direction is decided where suffix(i_{L-1}) and
+// suffix(i_{L-2}) differ -- within d + h symbols, because i_{L-1} + d is not a member (a group is a full equivalence class).
+// Such groups are what periodic stretches turn into (one residue class of the period per group), and plain doubling needs
+// log2(stretch / h) more rounds over ALL of their members to order them: two periodic halves of a 1 MiB block, 17 rounds of 2.8 ms
+// per 32 blocks.  Here a group found to be a chain gets its final order in ONE round: its members' second key is their place in
+// the chain instead of rank(i + h), the round's sort and rank pass do the rest.
+//   k_chain_init    heads of the unresolved list's groups clear the group's record {min position, ~max position} and its info word
+//   k_chain_minmax  every member: atomic min / max (one pair per wave where a wave's 64 entries are one group)
+//   k_chain_decide  the group's last entry knows L (its SA slot - the head's + 1): d = (max - min) / (L - 1) if that divides and
+//                   d <= CHAIN_DMAX -> candidate
+//   k_chain_verify  every member: on the lattice min + k d?  and T[v .. v + d) == T[v + d .. v + 2 d) where both are below max
+//   k_chain_dir     the last entry: the direction, by the text, from symbol h on (at most d + 16 more)
+// The records live in the round's spare word array (free between the rank pass and the sort), the info words in the group-head
+// array the text-refinement rounds use (dead in doubling rounds).
+// ---------------------------------------------------------------------------
+constexpr uint32_t CHAIN_DMAX = 4096;                          // longest stride tried (the verification reads d bytes per member, the direction walk d + 16)
+constexpr uint32_t CHAIN_CAND = 1u << 31, CHAIN_OK = 1u << 30, CHAIN_DESC = 1u << 29, CHAIN_D = (1u << 20) - 1;
+
+__global__ __launch_bounds__(SA_THREADS) void k_chain_init(const uint64_t *__restrict__ key, const uint32_t *__restrict__ cnt,
+                                                           uint2 *__restrict__ rec, uint32_t *__restrict__ info, uint32_t nmax)
+{
+    const uint32_t b = blockIdx.y, m = cnt[b];
+    const uint64_t *K = key + (size_t)b * nmax;
+    for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
+        const uint32_t g = (uint32_t)(K[i] >> R1_SHIFT);
+        if (i == 0 || (uint32_t)(K[i - 1] >> R1_SHIFT) != g) {
+            rec[(size_t)b * nmax + g - 1] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            info[(size_t)b * nmax + g - 1] = 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SA_THREADS) void k_chain_minmax(const uint64_t *__restrict__ key, const uint32_t *__restrict__ cnt,
+                                                             uint2 *__restrict__ rec, uint32_t nmax)
+{
+    const uint32_t b = blockIdx.y, m = cnt[b];
+    const uint64_t *K = key + (size_t)b * nmax;
+    uint2 *R = rec + (size_t)b * nmax;
+    const uint32_t rounds = (m + gridDim.x * SA_THREADS - 1) / (gridDim.x * SA_THREADS);      // (uniform: every lane of a wave takes the same trips)
+    for (uint32_t t = 0; t < rounds; t++) {
+        const uint32_t i = (t * gridDim.x + blockIdx.x) * SA_THREADS + threadIdx.x;
+        const bool in = i < m;
+        const uint64_t k = in ? K[i] : 0ull;
+        const uint32_t g = (uint32_t)(k >> R1_SHIFT), v = (uint32_t)(k & VAL_MASK);
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        if (__ballot(in && g == g0) == __ballot(true)) {       // the wave's 64 entries are one group: one pair of atomics for all
+            const uint32_t mn = ~wave_max(~v), mx = wave_max(v);
+            if ((threadIdx.x & 63) == 0) { atomicMin(&R[g - 1].x, mn); atomicMin(&R[g - 1].y, ~mx); }
+        } else if (in) { atomicMin(&R[g - 1].x, v); atomicMin(&R[g - 1].y, ~v); }
+    }
+}
+
+__global__ __launch_bounds__(SA_THREADS) void k_chain_decide(const uint64_t *__restrict__ key, const uint32_t *__restrict__ pos,
+                                                             const uint32_t *__restrict__ cnt, const uint2 *__restrict__ rec,
+                                                             uint32_t *__restrict__ info, uint32_t nmax)
+{
+    const uint32_t b = blockIdx.y, m = cnt[b];
+    const uint64_t *K = key + (size_t)b * nmax;
+    const uint32_t *P = pos + (size_t)b * nmax;
+    for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
+        const uint32_t g = (uint32_t)(K[i] >> R1_SHIFT);
+        if (i + 1 < m && (uint32_t)(K[i + 1] >> R1_SHIFT) == g) continue;     // not the group's last entry
+        const uint32_t L = P[i] - (g - 1) + 1;                 // the group's entries hold consecutive SA slots from the head's on
+        const uint2 r = rec[(size_t)b * nmax + g - 1];
+        const uint32_t mn = r.x, mx = ~r.y;
+        if (L >= 2 && mx > mn && (mx - mn) % (L - 1) == 0) {
+            const uint32_t d = (mx - mn) / (L - 1);
+            if (d <= CHAIN_DMAX) info[(size_t)b * nmax + g - 1] = d | CHAIN_CAND;
+        }
+    }
+}
+
+__device__ __forceinline__ bool chain_eq16(const uint8_t *a, const uint8_t *b)
+{
+    uint4 x, y;
+    __builtin_memcpy(&x, a, 16);
+    __builtin_memcpy(&y, b, 16);
+    return x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w;
+}
+
+__global__ __launch_bounds__(SA_THREADS) void k_chain_verify(const uint64_t *__restrict__ key, const uint32_t *__restrict__ cnt,
+                                                             const uint2 *__restrict__ rec, uint32_t *__restrict__ info,
+                                                             uint32_t nmax, const uint8_t *__restrict__ text, size_t text_stride)
+{
+    const uint32_t b = blockIdx.y, m = cnt[b];
+    const uint64_t *K = key + (size_t)b * nmax;
+    const uint8_t *T = text + (size_t)b * text_stride;
+    for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
+        const uint64_t k = K[i];
+        const uint32_t g = (uint32_t)(k >> R1_SHIFT), v = (uint32_t)(k & VAL_MASK);
+        uint32_t *I = info + (size_t)b * nmax + g - 1;
+        const uint32_t inf = *I;
+        if (!(inf & CHAIN_CAND)) continue;
+        const uint32_t d = inf & CHAIN_D;
+        const uint2 r = rec[(size_t)b * nmax + g - 1];
+        const uint32_t mn = r.x, mx = ~r.y;
+        bool ok = (v - mn) % d == 0;
+        if (ok && v + 2 * d <= mx) {                           // u of this member == u of the next one (both strings end below max: inside the text)
+            uint32_t t = 0;
+            for (; ok && t + 16 <= d; t += 16) ok = chain_eq16(T + v + t, T + v + d + t);
+            for (; ok && t < d; t++) ok = T[v + t] == T[v + d + t];
+        }
+        if (!ok) atomicAnd(I, ~CHAIN_CAND);
+    }
+}
+
+__global__ __launch_bounds__(SA_THREADS) void k_chain_dir(const uint64_t *__restrict__ key, const uint32_t *__restrict__ cnt,
+                                                          const uint2 *__restrict__ rec, uint32_t *__restrict__ info, uint32_t nmax,
+                                                          const uint8_t *__restrict__ text, size_t text_stride, uint32_t n, uint32_t h)
+{
+    const uint32_t b = blockIdx.y, m = cnt[b];
+    const uint64_t *K = key + (size_t)b * nmax;
+    const uint8_t *T = text + (size_t)b * text_stride;
+    for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
+        const uint32_t g = (uint32_t)(K[i] >> R1_SHIFT);
+        if (i + 1 < m && (uint32_t)(K[i + 1] >> R1_SHIFT) == g) continue;     // the group's last entry decides
+        uint32_t *I = info + (size_t)b * nmax + g - 1;
+        const uint32_t inf = *I;
+        if (!(inf & CHAIN_CAND)) continue;
+        const uint32_t d = inf & CHAIN_D;
+        const uint32_t mx = ~rec[(size_t)b * nmax + g - 1].y;
+        // suffix(mx) against suffix(mx - d): equal in their first h symbols (one group), different within d + h
+        const uint32_t A = mx, B = mx - d;                     // (A > B: A is the shorter suffix)
+        uint32_t k = h & ~15u;
+        const uint32_t lim = h + d + 16;
+        int less = -1;                                         // suffix(A) < suffix(B) ?
+        while (less < 0 && k <= lim) {
+            if (A + k + 16 <= n) {
+                if (chain_eq16(T + A + k, T + B + k)) { k += 16; continue; }
+            }
+            for (uint32_t t = 0; t < 16 && less < 0; t++) {
+                if (A + k + t >= n) less = 1;                  // suffix(A) ends first: the shorter suffix is the smaller
+                else if (T[A + k + t] != T[B + k + t]) less = T[A + k + t] < T[B + k + t] ? 1 : 0;
+            }
+            k += 16;
+        }
+        if (less < 0) { *I = 0u; continue; }                   // (cannot happen: see above; the group is left to the doubling)
+        *I = d | CHAIN_OK | (less ? CHAIN_DESC : 0u);
+    }
+}
+
+// rounds >= 1: fill in rank(i+h) -- or, for the members of a chain group, their place in the chain
 __global__ __launch_bounds__(SA_THREADS) void k_sa_fill_rank2(uint64_t *__restrict__ key,
                                                               const uint32_t *__restrict__ cnt,
                                                               const uint32_t *__restrict__ isa, uint32_t n,
-                                                              uint32_t h, uint32_t nmax)
+                                                              uint32_t h, uint32_t nmax, const uint2 *__restrict__ rec,
+                                                              const uint32_t *__restrict__ info)
 {
     const uint32_t b = blockIdx.y, m = cnt[b];
     uint64_t *K = key + (size_t)b * nmax;
@@ -799,7 +946,13 @@ __global__ __launch_bounds__(SA_THREADS) void k_sa_fill_rank2(uint64_t *__restri
     for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
         uint64_t k = K[i];
         uint32_t v = (uint32_t)(k & VAL_MASK);
-        uint32_t r2 = (v + h < n) ? ISA[v + h] : 0u;
+        uint32_t r2;
+        const uint32_t inf = info ? info[(size_t)b * nmax + (uint32_t)(k >> R1_SHIFT) - 1] : 0u;
+        if (inf & CHAIN_OK) {
+            const uint2 r = rec[(size_t)b * nmax + (uint32_t)(k >> R1_SHIFT) - 1];
+            const uint32_t d = inf & CHAIN_D, at = (v - r.x) / d, L = (~r.y - r.x) / d + 1;
+            r2 = (inf & CHAIN_DESC) ? L - 1 - at : at;         // descending: the member nearest the chain's end is the smallest
+        } else r2 = (v + h < n) ? ISA[v + h] : 0u;
         K[i] = k | ((uint64_t)r2 << R2_SHIFT);
     }
 }
@@ -1131,7 +1284,7 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
     // prefix doubling doubles it.  Text refinement first: data whose suffixes separate
     // within ~11 symbols (i.i.d. bytes, float mantissas) never builds the rank array.
     int mode = (s.force_isa || resume_depth) ? MODE_ISA : MODE_TEXT;
-    uint32_t depth = resume_depth ? resume_depth : 5, live = n, text_rounds = 0;
+    uint32_t depth = resume_depth ? resume_depth : 5, live = n, text_rounds = 0, isa_rounds = 0;
     int rounds = 0;
     if (mode == MODE_ISA) {
         // ranks are needed from the first refinement on: k_sa_rank<true> writes them in MODE_ISA
@@ -1189,8 +1342,23 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
             depth += 3;
             text_rounds++;
         } else {
+            // chain groups (one residue class of a periodic stretch each) get their final order this round; worth its five light
+            // passes over the list only where a lot is still live (GLC_CHAIN_MIN: tests lower it, 0 switches it off)
+            static const long chain_min = getenv("GLC_CHAIN_MIN") ? atol(getenv("GLC_CHAIN_MIN")) : 16384;
+            static const long chain_every = getenv("GLC_CHAIN_ROUNDS") ? atol(getenv("GLC_CHAIN_ROUNDS")) : 0x1;   // bit r: try in doubling round r (the first: a periodic stretch is all chains at once; later rounds gained nothing on any kind tried and cost five launches each)
+            const bool chains = chain_min > 0 && live_total >= (double)chain_min && pos_cur != nullptr && isa_rounds < 32 && ((chain_every >> isa_rounds) & 1);
+            isa_rounds++;
+            uint2 *rec = reinterpret_cast<uint2 *>(alt);      // (the spare word array: free until the sort below)
+            if (chains) {
+                dim3 cg(fill_blocks, nblk), ct(SA_THREADS);
+                hipLaunchKernelGGL(k_chain_init, cg, ct, 0, st, cur, cnt_cur, rec, s.hdA, s.nmax);
+                hipLaunchKernelGGL(k_chain_minmax, cg, ct, 0, st, cur, cnt_cur, rec, s.nmax);
+                hipLaunchKernelGGL(k_chain_decide, cg, ct, 0, st, cur, pos_cur, cnt_cur, rec, s.hdA, s.nmax);
+                hipLaunchKernelGGL(k_chain_verify, cg, ct, 0, st, cur, cnt_cur, rec, s.hdA, s.nmax, text, text_stride);
+                hipLaunchKernelGGL(k_chain_dir, cg, ct, 0, st, cur, cnt_cur, rec, s.hdA, s.nmax, text, text_stride, n, depth);
+            }
             hipLaunchKernelGGL(k_sa_fill_rank2, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur, s.isa,
-                               n, depth, s.nmax);
+                               n, depth, s.nmax, rec, chains ? s.hdA : (const uint32_t *)nullptr);
             // 42 key bits at [20, 62): 8+8+8+9+9
             PassPlan pp = {5, {VAL_BITS, VAL_BITS + 8, VAL_BITS + 16, VAL_BITS + 24, VAL_BITS + 33}, {8, 8, 8, 9, 9}};
             GLC_TRY(refine_sort(st, cur, alt, cnt_cur, pp, R1_SHIFT, maxc, tiles, nblk, s, live_total));

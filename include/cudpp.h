@@ -279,7 +279,7 @@ CUDPPResult glcPlanLastSortPeriodic(CUDPPHandle planHandle, unsigned int *out);
    out2[1] = the length of that streak.  A wrong guess costs time, never correctness. */
 CUDPPResult glcPlanLastSortSkipped(CUDPPHandle planHandle, unsigned int *out2);
 /* diagnostics (tests, tools/exp): per-block give-up flags of the last sort (bucket sorter: 1 bucket overflow / text-like, 2 deep,
- * 4 work list full; sample sorter: 1 bucket overflow, 2 deep), numBlocks entries each, either pointer may be NULL; and the
+ * 4 work list full; sample sorter: 1 bucket overflow, 2 deep; 3 also marks a deep block whose beginning is periodic for an eighth of the block or more: not worth the tolerant pass), numBlocks entries each, either pointer may be NULL; and the
  * 512 bucket fills of one block as the last bucketing pass left them.  Both wait for the plan's stream. */
 CUDPPResult glcPlanDebugSortFlags(CUDPPHandle planHandle, unsigned int *out_fs, unsigned int *out_ss, size_t numBlocks);
 CUDPPResult glcPlanDebugBucketFill(CUDPPHandle planHandle, size_t block, unsigned int *out512);
