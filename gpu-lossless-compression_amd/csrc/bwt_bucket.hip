@@ -1329,6 +1329,7 @@ __global__ __launch_bounds__(SSA_NT) void k_ss_sample(const uint8_t *__restrict_
     uint2 *s_tab = reinterpret_cast<uint2 *>(&s_k[0][0]);
     __shared__ uint32_t s_deep, s_ties, s_work, s_big;
     const uint32_t b = list[blockIdx.x], tid = threadIdx.x, nb = 1u << nbl;
+    if (flag[b]) return;                                       // (uniform) flagged before the attempt: per_probe, a mostly periodic block
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t S = min(nb * SS_PER_BUCKET, n);
     uint32_t S2 = 1;
@@ -2770,6 +2771,7 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
     if (attempt == 0) {
         GLC_TRY(hipMemsetAsync(s.ss_flag, 0, (size_t)s.rows * 4, st));
         GLC_TRY(hipMemsetAsync(s.fs_fill, 0, (size_t)s.rows * FS_MAXNB * 4, st));
+        GLC_TRY(per_probe(st, text, text_stride, n, nflag, s));   // (blocks that are mostly one periodic stretch: not this sorter's)
     }
     if (tol)
         hipLaunchKernelGGL(k_ss_sample<true>, dim3(nflag), dim3(SSA_NT), 0, st, text, text_stride, n, nbl, s.fs_tab, list,

@@ -57,12 +57,16 @@ __device__ __forceinline__ bool per_eq16(const uint8_t *a, const uint8_t *b)
 __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                        const uint32_t *__restrict__ list, uint32_t *__restrict__ flag,
                                                        uint4 *__restrict__ info, uint32_t *__restrict__ plist,
-                                                       uint32_t *__restrict__ pcount, uint32_t take)
+                                                       uint32_t *__restrict__ pcount, uint32_t take, bool probe)
 {
     __shared__ uint32_t s_cand[PER_PMAX / 32];
     __shared__ uint32_t s_e, s_p;
     const uint32_t b = list[blockIdx.x], tid = threadIdx.x;
-    if (!flag[b] || n < 16 * PER_PMAX) return;                 // finished by an earlier tier / too small to be worth a tier
+    // probe (before the sample sorter's first attempt, every listed block): nothing is taken -- a block whose beginning is periodic
+    // for 3/8 of the block or more is flagged (2 | 1) so that the sample sorter leaves it alone: a quarter of its samples would tie
+    // beyond any cap, its exact attempt (2.3 ms per 32 blocks of two periodic halves, 0.6 per 64 deep_repeats blocks) and its
+    // tolerant one (4.9) can only give up.  The tier proper then looks at the block as at any other flagged one.
+    if ((!probe && !flag[b]) || n < 16 * PER_PMAX) return;     // finished by an earlier tier / too small to be worth a tier
     const uint8_t *T = text + (size_t)b * stride;
     for (uint32_t i = tid; i < PER_PMAX / 32; i += PER_NT) s_cand[i] = 0;
     if (tid == 0) s_p = 0;
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         // p is the SMALLEST period of T[0 .. e) iff no smaller candidate reached as far (the rotations of a smallest period are
         // distinct, which the closed form rests on: "11111" taken with p = 5 would have five equal classes)
         const uint32_t t = n - e, L = PER_Z * per_span(p, t);    // (L: the explicit zone, Z spans)
+        if (probe) { emax = max(emax, e); if (emax >= n / 8 * 3) break; continue; }
         if (e > emax && t <= PER_PMAX && L <= PER_Z * PER_PMAX && e >= L + 2 * p + 1 && per_text_len(p, t) + 16 <= PER_NU) {
             if (tid == 0) {
                 const uint32_t slot = atomicAdd(pcount, 1u);   // (past `take` slots: the block stays with the tiers behind this one; the host clamps the count)
@@ -109,12 +114,12 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         emax = max(emax, e);
         // (a candidate that is no period of the whole block: a larger one may still be -- "abab c abab c ...")
     }
-    // Not this tier's block -- but if its beginning is periodic for an eighth of the block or more, it is not the TOLERANT sample
+    // Not this tier's block -- but if its beginning is periodic for 3/8 of the block or more, it is not the TOLERANT sample
     // sorter's either (a quarter of its samples would tie beyond the cap: that attempt took 4.9 ms per 32 blocks of two periodic
     // halves before it gave up).  The block's flag becomes 2 | 1 -- the value a block that is deep AND had a bucket past its slot
     // carries, which the tolerant pass does not take either: k_ss_retry_list lists flag == 2 only -- and the general
     // sorter (whose doubling rounds order a periodic stretch as chains, bwt_sa.hip) takes the block as it takes every flagged one.
-    if (tid == 0 && emax >= n / 8 && flag[b] == 2u) flag[b] = 3u;
+    if (tid == 0 && emax >= n / 8 * 3 && (probe || flag[b] == 2u)) flag[b] = 3u;
 }
 
 // U of every taken block: T[0 .. Z L + 2 p + 1) | 0xFF | T[e - Z L .. n) | zeros up to nu   (below, L stands for Z L)
@@ -234,7 +239,15 @@ hipError_t per_detect(hipStream_t st, const uint8_t *text, size_t text_stride, u
 {
     GLC_TRY(hipMemsetAsync(s.per_count, 0, 16, st));
     hipLaunchKernelGGL(k_per_detect, dim3(nlisted), dim3(PER_NT), 0, st, text, text_stride, n, s.ss_list, s.ss_flag, s.per_info,
-                       s.per_list, s.per_count, s.rows < PER_TAKE ? s.rows : PER_TAKE);
+                       s.per_list, s.per_count, s.rows < PER_TAKE ? s.rows : PER_TAKE, false);
+    return hipGetLastError();
+}
+
+hipError_t per_probe(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nlisted, SaScratch &s)
+{
+    if (n < 16 * PER_PMAX) return hipSuccess;
+    hipLaunchKernelGGL(k_per_detect, dim3(nlisted), dim3(PER_NT), 0, st, text, text_stride, n, s.ss_list, s.ss_flag, (uint4 *)nullptr,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, true);
     return hipGetLastError();
 }
 

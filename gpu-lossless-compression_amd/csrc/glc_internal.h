@@ -277,6 +277,8 @@ hipError_t ss_split_masks(hipStream_t st, uint32_t nblk, SaScratch &s);
 // fs_lcnt of every block it finishes and counts them in s.per_count[2]
 hipError_t per_reserve(SaScratch &s);
 hipError_t per_detect(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nlisted, SaScratch &s);
+// before the sample sorter's first attempt: listed blocks whose beginning is periodic for 3/8 of the block or more get ss_flag = 3
+hipError_t per_probe(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nlisted, SaScratch &s);
 hipError_t per_text(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nper, uint32_t nu, SaScratch &s);
 hipError_t per_expand(hipStream_t st, const uint8_t *text, size_t text_stride, uint32_t n, uint32_t nper, uint32_t nu, SaScratch &s,
                       uint8_t *bwt_out, size_t bwt_stride, int *d_index);
