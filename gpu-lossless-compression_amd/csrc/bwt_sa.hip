@@ -872,13 +872,19 @@ __device__ __forceinline__ bool chain_eq16(const uint8_t *a, const uint8_t *b)
     return x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w;
 }
 
+// (vcache: one halfword per 16 text bytes, cleared before the pass: the stride d for which T[q .. q + 16) == T[q + d .. q + d + 16) has
+//  been found to hold.  The d residue classes of ONE periodic stretch are d groups, and every one of them needs the stretch to be
+//  d-periodic: without the cache each 16-byte piece of it was compared d times -- 4.8 ms per 32 blocks of two periodic halves, a third
+//  of the call.  Two members that look at a piece at the same time both compare it and both store d: harmless.)
 __global__ __launch_bounds__(SA_THREADS) void k_chain_verify(const uint64_t *__restrict__ key, const uint32_t *__restrict__ cnt,
                                                              const uint2 *__restrict__ rec, uint32_t *__restrict__ info,
-                                                             uint32_t nmax, const uint8_t *__restrict__ text, size_t text_stride)
+                                                             uint32_t nmax, const uint8_t *__restrict__ text, size_t text_stride,
+                                                             uint16_t *__restrict__ vcache)
 {
     const uint32_t b = blockIdx.y, m = cnt[b];
     const uint64_t *K = key + (size_t)b * nmax;
     const uint8_t *T = text + (size_t)b * text_stride;
+    uint16_t *VC = vcache + (size_t)b * nmax * 2;              // (the spare slot array: 4 bytes per suffix, n / 16 halfwords used)
     for (uint32_t i = blockIdx.x * SA_THREADS + threadIdx.x; i < m; i += gridDim.x * SA_THREADS) {
         const uint64_t k = K[i];
         const uint32_t g = (uint32_t)(k >> R1_SHIFT), v = (uint32_t)(k & VAL_MASK);
@@ -890,9 +896,15 @@ __global__ __launch_bounds__(SA_THREADS) void k_chain_verify(const uint64_t *__r
         const uint32_t mn = r.x, mx = ~r.y;
         bool ok = (v - mn) % d == 0;
         if (ok && v + 2 * d <= mx) {                           // u of this member == u of the next one (both strings end below max: inside the text)
-            uint32_t t = 0;
-            for (; ok && t + 16 <= d; t += 16) ok = chain_eq16(T + v + t, T + v + d + t);
-            for (; ok && t < d; t++) ok = T[v + t] == T[v + d + t];
+            const uint32_t end = v + d, a = min((v + 15u) & ~15u, end), z = max(end & ~15u, a);
+            uint32_t q = v;
+            for (; ok && q < a; q++) ok = T[q] == T[q + d];
+            for (q = a; ok && q < z; q += 16) {
+                if (VC[q >> 4] == (uint16_t)d) continue;       // (d <= CHAIN_DMAX < 65536, never 0)
+                ok = chain_eq16(T + q, T + q + d);
+                if (ok) VC[q >> 4] = (uint16_t)d;
+            }
+            for (q = z; ok && q < end; q++) ok = T[q] == T[q + d];
         }
         if (!ok) atomicAnd(I, ~CHAIN_CAND);
     }
@@ -1354,7 +1366,10 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
                 hipLaunchKernelGGL(k_chain_init, cg, ct, 0, st, cur, cnt_cur, rec, s.hdA, s.nmax);
                 hipLaunchKernelGGL(k_chain_minmax, cg, ct, 0, st, cur, cnt_cur, rec, s.nmax);
                 hipLaunchKernelGGL(k_chain_decide, cg, ct, 0, st, cur, pos_cur, cnt_cur, rec, s.hdA, s.nmax);
-                hipLaunchKernelGGL(k_chain_verify, cg, ct, 0, st, cur, cnt_cur, rec, s.hdA, s.nmax, text, text_stride);
+                // (the verification's cache, n / 16 halfwords at the head of every block's part of pos_next -- which the NEXT rank pass writes)
+                GLC_TRY(hipMemset2DAsync(pos_next, (size_t)s.nmax * 4, 0, ((size_t)n / 16 + 1) * 2, nblk, st));
+                hipLaunchKernelGGL(k_chain_verify, cg, ct, 0, st, cur, cnt_cur, rec, s.hdA, s.nmax, text, text_stride,
+                                   reinterpret_cast<uint16_t *>(pos_next));
                 hipLaunchKernelGGL(k_chain_dir, cg, ct, 0, st, cur, cnt_cur, rec, s.hdA, s.nmax, text, text_stride, n, depth);
             }
             hipLaunchKernelGGL(k_sa_fill_rank2, dim3(fill_blocks, nblk), dim3(SA_THREADS), 0, st, cur, cnt_cur, s.isa,
