@@ -1357,8 +1357,15 @@ static hipError_t sa_build_general(hipStream_t st, const uint8_t *text, size_t t
             // chain groups (one residue class of a periodic stretch each) get their final order this round; worth its five light
             // passes over the list only where a lot is still live (GLC_CHAIN_MIN: tests lower it, 0 switches it off)
             static const long chain_min = getenv("GLC_CHAIN_MIN") ? atol(getenv("GLC_CHAIN_MIN")) : 16384;
-            static const long chain_every = getenv("GLC_CHAIN_ROUNDS") ? atol(getenv("GLC_CHAIN_ROUNDS")) : 0x1;   // bit r: try in doubling round r (the first: a periodic stretch is all chains at once; later rounds gained nothing on any kind tried and cost five launches each)
-            const bool chains = chain_min > 0 && live_total >= (double)chain_min && pos_cur != nullptr && isa_rounds < 32 && ((chain_every >> isa_rounds) & 1);
+            // ... in the FIRST doubling round (a periodic stretch over a large alphabet is all chains at once), and again in rounds
+            // 2 and 4 where more than half of everything is still live: over a small alphabet the period's 5-grams repeat, a group of
+            // the first round holds several residue classes and only becomes chains once the depth tells them apart (two periodic
+            // halves over {0, 1}: 50.1 ms per 32 blocks with the first round alone, 15.6 with all three; blocks with something deep
+            // INSIDE have a few per cent live and are spared the later attempts' launches: 9.2 against 9.6 ms per 64)
+            static const long chain_every = getenv("GLC_CHAIN_ROUNDS") ? atol(getenv("GLC_CHAIN_ROUNDS")) : 0x15;   // bit r: try in doubling round r
+            const bool mostly_live = live_total >= 0.5 * (double)n * nsorted;
+            const bool chains = chain_min > 0 && live_total >= (double)chain_min && pos_cur != nullptr && isa_rounds < 32 &&
+                                ((chain_every >> isa_rounds) & 1) && (isa_rounds == 0 || mostly_live);
             isa_rounds++;
             uint2 *rec = reinterpret_cast<uint2 *>(alt);      // (the spare word array: free until the sort below)
             if (chains) {
