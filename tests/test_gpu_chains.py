@@ -100,3 +100,24 @@ def test_full_size_blocks_of_the_bench(glc, cuda):
     for k, x in enumerate((h, z)):
         want, widx = O.bwt(x)
         assert int(idx[k]) == widx and np.array_equal(got[k], want), k
+
+
+def test_progressions_that_are_not_chains(glc, cuda):
+    """groups whose members ARE an arithmetic progression with a stride the chain pass tries (<= 4096) but whose text is not periodic
+    over it: a 600-byte phrase every 2048 bytes with different random bytes in between; a periodic stretch with ONE byte changed in
+    its middle (every residue class still has a member every d bytes across the defect); two stretches of one pattern a whole number
+    of periods apart.  The verification must refuse them (plain doubling orders them) -- the bytes are the oracle's either way."""
+    rng = np.random.default_rng(31)
+    n = 1 << 17
+    a = rng.integers(0, 256, n, dtype=np.uint8)
+    phrase = rng.integers(97, 123, 600, dtype=np.uint8)
+    for o in range(1000, n - 700, 2048):
+        a[o:o + 600] = phrase
+    w = rng.integers(0, 4, 23, dtype=np.uint8)
+    b = np.tile(w, n // 23 + 1)[:n].copy()
+    b[n // 2 + 7] ^= 1
+    c = rng.integers(0, 256, n, dtype=np.uint8)
+    w2 = rng.integers(0, 256, 50, dtype=np.uint8)
+    c[10000:30000] = np.tile(w2, 400)
+    c[30000 + 50 * 100:30000 + 50 * 100 + 20000] = np.tile(w2, 400)      # the same phase, 100 periods of other bytes in between
+    _check(glc, cuda, [a, b, c], n, "not chains")
