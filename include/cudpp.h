@@ -274,7 +274,7 @@ CUDPPResult glcPlanLastSortResumed(CUDPPHandle planHandle, unsigned int *out);
 /* out[0] = how many of the blocks the sample sorter gave up on were finished by the periodic tier (see glcPlanSetSorter) */
 CUDPPResult glcPlanLastSortPeriodic(CUDPPHandle planHandle, unsigned int *out);
 /* out2[0] = 1 if the plan's last call went straight to the sample sorter (sorter mode 4, or adaptively: a call of up to 4 blocks
-   behind two calls in a row whose every block the text-likeness probe flagged -- the reference's callers hand over one block per
+   behind eight calls in a row whose every block the text-likeness probe flagged -- the reference's callers hand over one block per
    call, test_compress.cpp:744, and a text block's call spent a fifth of its time on launches that found the block flagged);
    out2[1] = the length of that streak.  A wrong guess costs time, never correctness. */
 CUDPPResult glcPlanLastSortSkipped(CUDPPHandle planHandle, unsigned int *out2);

@@ -419,7 +419,7 @@ def test_stages_of_finished_blocks_beside_the_second_attempt(glc, cuda):
 
 
 def test_small_calls_behind_a_text_like_streak_skip_the_bucket_sorter(glc, cuda):
-    """The reference's callers hand over ONE block per call (test_compress.cpp:744).  After two calls in a row whose every block the
+    """The reference's callers hand over ONE block per call (test_compress.cpp:744).  After eight calls in a row whose every block the
     text-likeness probe flagged, a call of up to four blocks goes straight to the sample sorter (glcPlanLastSortSkipped); the first
     block the probe does not flag -- evaluated in skipped calls too -- ends the streak.  Whatever the guess, every call's outputs
     are the oracle's."""
@@ -431,7 +431,7 @@ def test_small_calls_behind_a_text_like_streak_skip_the_bucket_sorter(glc, cuda)
     dev = {"T": torch.from_numpy(text).to(cuda), "Z": torch.from_numpy(zipf).to(cuda)}
     with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=1) as plan:
         seen = []
-        for kind in "TTTTZZTZTTTZ":
+        for kind in "TTTTTTTTTTZZTZ":
             out = glc.compress_batch(plan, dev[kind], n, 1)
             plan.synchronize()
             w = want[kind]
@@ -441,9 +441,9 @@ def test_small_calls_behind_a_text_like_streak_skip_the_bucket_sorter(glc, cuda)
             assert np.array_equal(out["hist"][:256].cpu().numpy().view(np.uint32), w["hist"]), (kind, seen)
             seen.append((kind, plan.last_sort_skipped()[0], plan.last_sort_stats()[0]))
         skipped = "".join("s" if s else "-" for _, s, _ in seen)
-        #            T T T T Z Z T Z T T T Z
-        assert skipped == "--sss-----ss", seen                 # a Zipf block behind a streak is the one wrong guess; it ends the streak
-        assert [f for _, _, f in seen] == [1, 1, 1, 1, 1, 0, 1, 0, 1, 1, 1, 1], seen   # (a skipped call sends its block on whatever it is)
+        #            T T T T T T T T T T Z Z T Z      (the streak is eight calls long before a call skips)
+        assert skipped == "--------sss---", seen               # a Zipf block behind a streak is the one wrong guess; it ends the streak
+        assert [f for _, _, f in seen] == [1] * 10 + [1, 0, 1, 0], seen   # (a skipped call sends its block on whatever it is)
     # a batch of more than four blocks never skips
     with glc.Cudpp() as ctx, glc.Plan(ctx, glc.CUDPP_COMPRESS, n, rows=5) as plan:
         d5 = dev["T"].repeat(5)
