@@ -39,8 +39,9 @@ inline __host__ __device__ uint32_t per_span(uint32_t p, uint32_t t) { const uin
 inline __host__ __device__ uint32_t per_text_len(uint32_t p, uint32_t t) { return 2 * PER_Z * per_span(p, t) + 2 * p + 2 + t; }
 constexpr uint32_t FS_LCP_CAP = 512;             // suffix comparisons and the sample sorter's rounds give up behind this many symbols
 #ifndef GLC_SS_TOL_CAP
-#define GLC_SS_TOL_CAP 128
-#endif
+#define GLC_SS_TOL_CAP 64                        // (128 until round 6.  With chain groups and the capped direct count the doubling rounds are cheap
+#endif                                           //  enough to start earlier: a periodic stretch inside Zipf data 6.4 -> 5.5 ms per 32 blocks, bench.py's
+                                                 //  partly_deep batch 9.15 -> 8.93 per 64; 48: 5.3 / 9.0, 32: 5.1 / 9.7, 256: 8.1 / 10.2)
 constexpr uint32_t SS_TOL_CAP = GLC_SS_TOL_CAP;  // ... and in the sample sorter's tolerant form STOP behind this many: prefix doubling takes over from there (a multiple of 8)
 constexpr uint32_t GRP_SAME = 0x80000000u;        // ... this row continues the group of the row before it (k_grp_flags' result; set up front for the members of a run left at the cap)
 constexpr uint32_t SA_CAND = 0x40000000u;         // tolerant form, in the rows of s.sa: this row may share SS_TOL_CAP symbols with the row before it (it was still in a

@@ -269,7 +269,7 @@ CUDPPResult glcPlanLastSortStatsEx(CUDPPHandle planHandle, unsigned int *out2);
 CUDPPResult glcPlanLastSortRetries(CUDPPHandle planHandle, unsigned int *out);
 /* out[0] = how many of the blocks the sample sorter gave up on FOR DEPTH ALONE (out2[1] above counts them) were finished by
  * prefix doubling RESUMED from its order -- the sample sorter run once more in a form that leaves suffixes agreeing in more
- * than 128 symbols (SS_TOL_CAP) as they come, doubling from that depth over the rows that still tie -- instead of from scratch */
+ * than 64 symbols (SS_TOL_CAP; 128 until round 6) as they come, doubling from that depth over the rows that still tie -- instead of from scratch */
 CUDPPResult glcPlanLastSortResumed(CUDPPHandle planHandle, unsigned int *out);
 /* out[0] = how many of the blocks the sample sorter gave up on were finished by the periodic tier (see glcPlanSetSorter) */
 CUDPPResult glcPlanLastSortPeriodic(CUDPPHandle planHandle, unsigned int *out);
