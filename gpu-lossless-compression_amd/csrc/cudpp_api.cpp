@@ -613,7 +613,7 @@ CUDPPResult glcPlanSetSorter(CUDPPHandle planHandle, int mode)
     if (!s) return CUDPP_ERROR_INVALID_PLAN;
     if (mode < 0 || mode > 7) return CUDPP_ERROR_ILLEGAL_CONFIGURATION;
     s->sorter = mode >= 5 ? 0 : mode;
-    s->resume_min = mode == 5 ? 0u : (mode == 6 ? 1u : 4u);
+    s->resume_min = mode == 5 ? 0u : (mode == 6 ? 1u : 2u);
     s->periodic = mode != 7 && mode != 5;                      // (5: "from scratch" for everything the sample sorter gives up on)
     return CUDPP_SUCCESS;
 }

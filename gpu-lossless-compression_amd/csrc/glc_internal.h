@@ -202,7 +202,9 @@ struct SaScratch {
     uint32_t *per_base = nullptr;                // [min(rows, PER_TAKE)][PER_NU + 1] first row of every representative
     uint8_t  *per_text = nullptr;                // [min(rows, PER_TAKE)][PER_NU] the texts of representatives
     uint32_t  last_periodic = 0;                 // blocks of the last sa_build this tier finished
-    uint32_t  resume_min = 4;                    // fewest blocks given up on for depth that are worth the tolerant pass (0: never; sorter modes 5 / 6)
+    uint32_t  resume_min = 2;                    // fewest blocks given up on for depth that are worth the tolerant pass (0: never; sorter modes 5 / 6).  4 until round 6;
+                                                 // with chain groups and the tolerant cap at 64: 2 blocks 2.1-2.6 -> 1.6-2.1 ms per call, 3 blocks 2.4-2.9 -> 1.7-2.2; a lone
+                                                 // block 1.8-2.3 against 1.6-2.7 (three kinds of four gain, log lines with runs lose: left as it was)
     bool      skip_tier1 = false;                // sorter 4: no bucket-sorter attempt, every block goes to the sample sorter
     // ... and, adaptively, for SMALL calls (sa_skips_tier1): the reference's callers hand over one block per call, and a text
     // block's call spent 0.13 of its 0.69 ms on the bucket sorter's fourteen launches that find the block flagged.  After
