@@ -75,7 +75,8 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         if (per_eq16(T, T + j)) atomicOr(&s_cand[(j - 1) >> 5], 1u << ((j - 1) & 31));
     __syncthreads();
     uint32_t from = 0, emax = 0;                               // candidates are looked at in ascending order; furthest break so far
-    for (uint32_t tries = 0; tries < PER_TRIES; tries++) {
+    uint32_t seen_p[PER_TRIES], seen_e[PER_TRIES];             // candidates examined so far and where each broke
+    for (uint32_t tries = 0; tries < PER_TRIES;) {
         uint32_t p = 0;
         for (uint32_t w = from >> 5; w < PER_PMAX / 32 && !p; w++) {
             const uint32_t m = s_cand[w] & (w == (from >> 5) ? ~0u << (from & 31) : ~0u);
@@ -83,6 +84,13 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         }
         if (!p) break;                                         // (uniform: every thread reads the same words)
         from = p;                                              // (bit p - 1 is this candidate: the next search starts behind it)
+        // a multiple k q of an examined candidate q whose period held up to position k q or beyond breaks exactly where q broke
+        // (T[e] != T[e - q] = T[e - k q]): nothing new to learn, and no scan of the block -- a periodic block offers q, 2 q, 3 q, ...
+        // as candidates, and eight scans of it were 0.2 ms of a lone block's call
+        bool known = false;
+#pragma unroll
+        for (uint32_t k = 0; k < PER_TRIES; k++) known |= k < tries && p % seen_p[k] == 0 && seen_e[k] >= p;
+        if (known) continue;
         if (tid == 0) s_e = n;
         __syncthreads();
         // first position e >= p with T[e] != T[e - p]
@@ -96,6 +104,8 @@ __global__ __launch_bounds__(PER_NT) void k_per_detect(const uint8_t *__restrict
         __syncthreads();
         const uint32_t e = s_e;
         __syncthreads();
+        seen_p[tries] = p; seen_e[tries] = e;
+        tries++;
         // p is the SMALLEST period of T[0 .. e) iff no smaller candidate reached as far (the rotations of a smallest period are
         // distinct, which the closed form rests on: "11111" taken with p = 5 would have five equal classes)
         const uint32_t t = n - e, L = PER_Z * per_span(p, t);    // (L: the explicit zone, Z spans)
