@@ -1214,11 +1214,14 @@ static hipError_t radix_sort(hipStream_t st, uint64_t *&cur, uint64_t *&alt, con
     // `tiles` counts SA_TILE-word tiles (rank kernel); the radix kernels use RS_TILE
     const uint32_t rs_tiles = (tiles * (uint32_t)SA_TILE + RS_TILE - 1) / RS_TILE;
     GLC_TRY(hipMemsetAsync(s.ghist, 0, (size_t)nblk * RS_MAXPASS * SA_MAXRADIX * 4, st));
+    // workgroups per block of the histogram pass: 32 where the blocks of a call fill the chip between them, up to 256 for a
+    // call of a few (a lone block's second sort waited 112 us for 32 workgroups to read its 8 MB list)
+    const uint32_t ph = nblk >= 8 ? 32u : (nblk >= 2 ? 128u : 256u), phg = rs_tiles < ph ? rs_tiles : ph;
     if (src)
-        hipLaunchKernelGGL(k_rs_prehist<true>, dim3(rs_tiles < 32 ? rs_tiles : 32, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed,
+        hipLaunchKernelGGL(k_rs_prehist<true>, dim3(phg, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed,
                            pp, s.ghist, s.nmax, *src);
     else
-        hipLaunchKernelGGL(k_rs_prehist<false>, dim3(rs_tiles < 32 ? rs_tiles : 32, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed,
+        hipLaunchKernelGGL(k_rs_prehist<false>, dim3(phg, nblk), dim3(RS_NT), 0, st, cur, cnt, nfixed,
                            pp, s.ghist, s.nmax, TextSrc{});
     hipLaunchKernelGGL(k_rs_digitbase, dim3(nblk, pp.npass), dim3(512), 0, st, s.ghist, s.digit_base);
     for (uint32_t p = 0; p < pp.npass; p++) {
