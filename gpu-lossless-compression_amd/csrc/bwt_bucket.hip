@@ -2325,7 +2325,9 @@ __device__ __forceinline__ bool ss_undecided_t(uint32_t g) { return ((g >> 12) &
 #ifndef GLC_SSW_WAVES
 #define GLC_SSW_WAVES 7
 #endif
-template <bool TOL>
+// SHARES one-wave workgroups per bucket, a share each (batches: 3 -- more shares are more, smaller windows at the shares' ends; a call
+// of a few blocks: 12 -- a lone block's 1536 waves left most of the chip idle behind chains of three windows each)
+template <bool TOL, int SHARES = (int)SS_SHARES>
 __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t *__restrict__ text, size_t stride, uint32_t n,
                                                       const uint64_t *__restrict__ keys, size_t kstride,
                                                       const uint32_t *__restrict__ fill, const uint32_t *__restrict__ fbase,
@@ -2339,10 +2341,11 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
     __shared__ ulonglong2 s_kw[SS_WIN];                        // keys of the window's members {hi, lo}, at their slots
     __shared__ uint32_t s_vw[SS_WIN];                          // ... and their words (index << 8 | BWT byte)
     __shared__ uint8_t s_inv[SS_WIN];                          // the slot whose member comes to a place
-    __shared__ uint32_t s_bound[SS_SHARES + 1];
+    __shared__ uint32_t s_bound[SHARES + 1];
     uint32_t gx, gy;
     xcd_order(gx, gy);
-    const uint32_t b = list[gy], bk = gx / SSW_PER_BUCKET, w0 = gx % SSW_PER_BUCKET;
+    constexpr uint32_t PER = SHARES == (int)SS_SHARES ? (uint32_t)SSW_PER_BUCKET : (uint32_t)SHARES;   // (the small-call form: a wave per share)
+    const uint32_t b = list[gy], bk = gx / PER, w0 = gx % PER;
     const uint32_t lane = threadIdx.x;
     const uint8_t *T = text + (size_t)b * stride;
     const uint32_t c = fill[(size_t)b * FS_MAXNB + bk];
@@ -2353,8 +2356,8 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
     const uint32_t l0 = l0_in[(size_t)b * FS_MAXNB + bk];
     SS_CLK_BEGIN();
     // shares [A, B) of the positions; a share ends where a run ends
-    for (uint32_t t = lane; t <= SS_SHARES; t += 64) {
-        uint32_t A = (uint32_t)(((uint64_t)c * t) / SS_SHARES);
+    for (uint32_t t = lane; t <= (uint32_t)SHARES; t += 64) {
+        uint32_t A = (uint32_t)(((uint64_t)c * t) / (uint32_t)SHARES);
         if (A > 0 && A < c) { const uint32_t g = (uint32_t)(K[A] >> 32); if ((g & 0xFFFu) < A) A = (g >> 12) & 0xFFFu; }
         s_bound[t] = A;
     }
@@ -2362,7 +2365,7 @@ __global__ __launch_bounds__(64, GLC_SSW_WAVES) void k_ss_windows(const uint8_t 
     SS_CLK(0);                                                 // prologue + share bounds
     uint8_t *O = bwt_out ? bwt_out + (size_t)b * bwt_stride + R0 : nullptr;
     uint32_t *SAo = sa_out ? sa_out + (size_t)b * sa_stride + R0 : nullptr;
-    for (uint32_t ch = w0; ch < SS_SHARES; ch += SSW_PER_BUCKET) {
+    for (uint32_t ch = w0; ch < (uint32_t)SHARES; ch += PER) {
         const uint32_t A = s_bound[ch], B = s_bound[ch + 1];
         uint32_t pos = A;
         while (pos < B) {
@@ -2794,8 +2797,15 @@ hipError_t ss_build(hipStream_t st, const uint8_t *text, size_t text_stride, uin
                        s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count, tol);
     hipLaunchKernelGGL((k_ss_long<FS_FILLMAX, 256, true>), dim3(256 * 2), dim3(256), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                        s.ss_flag, s.ss_l0, s.ss_long, long_cap, s.ss_long_count, tol);
-    if (tol)
+    constexpr int FEW = 12;                                    // shares (= waves) per bucket for a call of up to four blocks
+    if (tol && nflag <= 4)
+        hipLaunchKernelGGL((k_ss_windows<true, FEW>), dim3(nb * FEW, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+                           s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+    else if (tol)
         hipLaunchKernelGGL(k_ss_windows<true>, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
+                           s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
+    else if (nflag <= 4)
+        hipLaunchKernelGGL((k_ss_windows<false, FEW>), dim3(nb * FEW, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
                            s.fs_fill, s.fs_base, s.ss_flag, list, s.ss_l0, bwt_out, bwt_stride, d_index, sa_out, (size_t)s.nmax);
     else
         hipLaunchKernelGGL(k_ss_windows<false>, dim3(nb * SSW_PER_BUCKET, nflag), dim3(64), 0, st, text, text_stride, n, s.keyA, s.fs_kstride,
