@@ -121,3 +121,41 @@ def test_progressions_that_are_not_chains(glc, cuda):
     c[10000:30000] = np.tile(w2, 400)
     c[30000 + 50 * 100:30000 + 50 * 100 + 20000] = np.tile(w2, 400)      # the same phase, 100 periods of other bytes in between
     _check(glc, cuda, [a, b, c], n, "not chains")
+
+
+@pytest.mark.gpu_long
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("GLC_MOSAIC_SEEDS", "6"))))
+def test_random_mosaics_of_periodic_pieces(glc, cuda, seed):
+    """blocks glued from random pieces -- periodic stretches of random period and alphabet, runs, random bytes, copies of earlier
+    pieces -- through the general sorter alone (mode 1), the tiers' own choice (0) and with the periodic tier off (7)"""
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.choice([1 << 16, (1 << 16) + 123, 1 << 17, 200000]))
+    blocks = []
+    for _ in range(12):
+        x = np.empty(n, dtype=np.uint8)
+        o = 0
+        pieces = []
+        while o < n:
+            kind = int(rng.integers(0, 5))
+            m = int(min(n - o, rng.integers(50, n // 2)))
+            if kind == 0:
+                p = int(rng.integers(1, 600))
+                al = int(rng.choice([2, 3, 4, 26, 256]))
+                seg = np.tile(rng.integers(0, al, p, dtype=np.uint8), m // p + 1)[:m]
+            elif kind == 1:
+                seg = np.full(m, int(rng.integers(0, 256)), dtype=np.uint8)
+            elif kind == 2 and pieces:
+                src = pieces[int(rng.integers(0, len(pieces)))]
+                seg = np.resize(src, m)
+            else:
+                seg = rng.integers(0, int(rng.choice([2, 4, 256])), m, dtype=np.uint8)
+            x[o:o + m] = seg
+            pieces.append(seg[:min(m, 5000)])
+            o += m
+        blocks.append(x)
+    for mode in (1, 0, 7):
+        got, idx, _, _ = _bwt_batch(glc, cuda, blocks, n, mode)
+        for k, x in enumerate(blocks):
+            want, widx = O.bwt(x)
+            assert int(idx[k]) == widx, (seed, mode, k)
+            assert np.array_equal(got[k], want), (seed, mode, k, int(np.nonzero(got[k] != want)[0][0]))
